@@ -1,0 +1,172 @@
+"""Parameter inventory of the score network and the blob layout of the C ABI.
+
+The blob handed to ``dfm_model_create`` is the concatenation, in ``PARAM_SPECS``
+order, of every tensor of the reference ``Score_Net.state_dict()`` flattened
+row-major as float32 (reference: src/models/score_net_mlsb.py:249-341,
+src/models/egnn.py:37-93; Lightning checkpoints prefix every key with ``net.``).
+
+``make_random_weights`` is the build's own deterministic generator (numpy
+PCG64).  It is NOT the reference initialiser: it draws O(1)-conditioned weights
+so that parity tests exercise the non-linearities, the clamp and the GraphNorm
+statistics; both the reference (through ``load_state_dict``) and this engine
+load the very same numbers, which is all parity needs.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, asdict
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class HParams:
+    """configs/model/score_model_mlsb.yaml:3-27 + score_net_mlsb.py:85,33."""
+    lm_embed_dim: int = 1301
+    positional_embed_dim: int = 66
+    spatial_embed_dim: int = 100
+    node_dim: int = 256
+    edge_dim: int = 128
+    inner_dim: int = 128
+    depth: int = 6
+    knn: int = 20
+    n_sample: int = 40
+    cut_off: float = 20.0
+    mask_dist: float = 22.0
+    r3_min_sigma: float = 0.1
+    r3_max_sigma: float = 30.0
+    so3_min_sigma: float = 0.1
+    so3_max_sigma: float = 1.5
+
+    def as_dict(self):
+        return asdict(self)
+
+
+def param_specs(hp: HParams = HParams()):
+    """(name, shape) in reference state_dict order."""
+    H, He, Hi = hp.node_dim, hp.edge_dim, hp.inner_dim
+    s = [
+        ("single_embed.weight", (H, hp.lm_embed_dim)),
+        ("spatial_embed.weight", (He, hp.spatial_embed_dim)),
+        ("positional_embed.weight", (He, hp.positional_embed_dim)),
+    ]
+    for l in range(hp.depth):
+        p = f"network.EGNN_{l}.egcl."
+        s += [
+            (p + "edge_mlp.0.weight", (H, 2 * H + 1 + He)),
+            (p + "edge_mlp.0.bias", (H,)),
+            (p + "edge_mlp.2.weight", (H, H)),
+            (p + "edge_mlp.2.bias", (H,)),
+            (p + "node_mlp.0.weight", (H, 2 * H)),
+            (p + "node_mlp.0.bias", (H,)),
+            (p + "node_mlp.1.weight", (H,)),
+            (p + "node_mlp.1.bias", (H,)),
+            (p + "node_mlp.1.mean_scale", (H,)),
+            (p + "node_mlp.3.weight", (H, H)),
+            (p + "node_mlp.3.bias", (H,)),
+        ]
+        if l == hp.depth - 1:
+            s += [
+                (p + "coord_mlp.0.weight", (H, H)),
+                (p + "coord_mlp.0.bias", (H,)),
+                (p + "coord_mlp.2.weight", (1, H)),
+            ]
+        s += [
+            (p + "att_mlp.0.weight", (1, H)),
+            (p + "att_mlp.0.bias", (1,)),
+        ]
+    s += [
+        ("to_energy.0.weight", (H, 2 * H)),
+        ("to_energy.1.weight", (H,)),
+        ("to_energy.1.bias", (H,)),
+        ("to_energy.3.weight", (1, H)),
+        ("to_ires.0.weight", (2 * H, H)),
+        ("to_ires.0.bias", (2 * H,)),
+        ("to_ires.2.weight", (2 * H, 2 * H)),
+        ("to_ires.2.bias", (2 * H,)),
+        ("to_ires.4.weight", (1, 2 * H)),
+        ("to_ires.4.bias", (1,)),
+        ("t_embed.0.W", (Hi // 2,)),
+        ("t_embed.1.weight", (Hi, Hi)),
+        ("tr_scale.0.weight", (Hi, Hi + 1)),
+        ("tr_scale.1.weight", (Hi,)),
+        ("tr_scale.1.bias", (Hi,)),
+        ("tr_scale.4.weight", (1, Hi)),
+        ("rot_scale.0.weight", (Hi, Hi + 1)),
+        ("rot_scale.1.weight", (Hi,)),
+        ("rot_scale.1.bias", (Hi,)),
+        ("rot_scale.4.weight", (1, Hi)),
+    ]
+    return s
+
+
+def n_params(hp: HParams = HParams()) -> int:
+    return sum(int(np.prod(sh)) for _, sh in param_specs(hp))
+
+
+def make_random_weights(seed: int = 0, hp: HParams = HParams()) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic, well-conditioned float32 parameters (build-owned)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = OrderedDict()
+    H = hp.node_dim
+    for name, shape in param_specs(hp):
+        leaf = name.split(".")[-1]
+        if name == "t_embed.0.W":
+            w = rng.standard_normal(shape)
+        elif leaf == "mean_scale":
+            w = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif ("node_mlp.1." in name or "to_energy.1." in name
+              or "tr_scale.1." in name or "rot_scale.1." in name):
+            # GraphNorm / LayerNorm affine
+            w = (1.0 + 0.1 * rng.standard_normal(shape)) if leaf == "weight" \
+                else 0.1 * rng.standard_normal(shape)
+        elif leaf == "bias":
+            w = 0.1 * rng.standard_normal(shape)
+        elif name.endswith("coord_mlp.2.weight"):
+            w = rng.standard_normal(shape) * (2.0 / math.sqrt(shape[1]))
+        elif name in ("tr_scale.4.weight", "rot_scale.4.weight"):
+            # no bias in this layer: a negative mean keeps softplus(.) ~ 1e-2 so
+            # that Euler-Maruyama rollouts move by Angstroms, not hundreds of them
+            w = -0.15 + 0.02 * rng.standard_normal(shape)
+        elif name.endswith("node_mlp.3.weight"):
+            # residual branch: keep h from blowing up over 6 layers
+            w = rng.standard_normal(shape) * (0.5 / math.sqrt(shape[1]))
+        else:
+            w = rng.standard_normal(shape) * (1.0 / math.sqrt(shape[-1]))
+            if name.endswith("edge_mlp.0.weight"):
+                # column 2H multiplies radial = |x_i-x_j|^2 (up to ~1e4 A^2)
+                w[:, 2 * H] = rng.standard_normal(shape[0]) * 2e-3
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out
+
+
+def pack_blob(weights, hp: HParams = HParams()) -> np.ndarray:
+    """state_dict-like mapping (optionally ``net.``-prefixed) -> flat float32 blob."""
+    parts = []
+    for name, shape in param_specs(hp):
+        if name in weights:
+            w = weights[name]
+        elif "net." + name in weights:
+            w = weights["net." + name]
+        else:
+            raise KeyError(f"missing parameter {name}")
+        if hasattr(w, "detach"):
+            w = w.detach().cpu().numpy()
+        w = np.asarray(w, dtype=np.float32)
+        if tuple(w.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {tuple(w.shape)} != {tuple(shape)}")
+        parts.append(w.reshape(-1))
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+def unpack_blob(blob: np.ndarray, hp: HParams = HParams()):
+    out = OrderedDict()
+    off = 0
+    for name, shape in param_specs(hp):
+        n = int(np.prod(shape))
+        out[name] = blob[off:off + n].reshape(shape)
+        off += n
+    if off != blob.size:
+        raise ValueError(f"blob has {blob.size} floats, expected {off}")
+    return out
