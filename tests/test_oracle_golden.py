@@ -1,0 +1,196 @@
+"""Pin the CPU oracle (oracle/dfm_oracle.c) to golden vectors captured from the reference.
+
+Every check here compares the plain-C restatement with numbers produced by running the
+reference's own functions (tests/golden/make_golden.py).  CPU only.
+"""
+import numpy as np
+import pytest
+
+from conftest import complex_for, load_golden
+from oracle import oracle as ora
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+# ---- a-3 / a-4 -------------------------------------------------------------------------
+def test_diffusion_coefficients():
+    k = load_golden("scalar_kats.npz")
+    g3, gso, s3, sso = ora.diffusion_coefs(k["ts"])
+    np.testing.assert_allclose(g3, k["g_r3"], rtol=1e-13)
+    np.testing.assert_allclose(gso, k["g_so3"], rtol=1e-13)
+    np.testing.assert_allclose(s3, k["sigma_r3"], rtol=1e-13)
+    np.testing.assert_allclose(sso, k["sigma_so3"], rtol=1e-13)
+    # SURVEY section 8 known answers
+    assert abs(g3[0] - 101.325260692) < 1e-8 and abs(gso[0] - 1.503399185) < 1e-8
+    assert abs(g3[-1] - 0.339682831) < 1e-8 and abs(gso[-1] - 0.792314388) < 1e-8
+    # so3 sigma raises ValueError outside [0,1] in the reference -> NaN in the oracle
+    assert np.isnan(ora.diffusion_coefs([1.5])[3][0])
+
+
+def test_torch_reverse_zero_noise():
+    k = load_golden("scalar_kats.npz")
+    g3, gso, _, _ = ora.diffusion_coefs(k["ts"])
+    for i in range(len(k["ts"])):
+        a = ora.torch_reverse(g3[i], k["rev_score"], k["dt"], 0.0, np.zeros(3))
+        b = ora.torch_reverse(gso[i], k["rev_score"], k["dt"], 0.0, np.zeros(3))
+        np.testing.assert_array_equal(a, k["rev_r3"][i, 0])   # bit-exact float32
+        np.testing.assert_array_equal(b, k["rev_so3"][i, 0])
+
+
+# ---- a-14 ------------------------------------------------------------------------------
+def test_rotation_conversions():
+    k = load_golden("scalar_kats.npz")
+    m = ora.axis_angle_to_matrix(k["axis_angle"]).reshape(-1, 3, 3)
+    np.testing.assert_allclose(m, k["matrices"], atol=2e-7)
+    np.testing.assert_allclose(m[0, 0], [0.3065077, -0.9414502, -0.1404437], atol=1e-6)
+    back = ora.matrix_to_axis_angle(k["matrices"].reshape(-1, 9))
+    np.testing.assert_allclose(back, k["axis_angle_back"], atol=3e-6)
+    q = ora.matrix_to_quaternion(k["matrices"].reshape(-1, 9))
+    np.testing.assert_allclose(q, k["quaternions"], atol=2e-7)
+    c = ora.rot_compose(k["compose_r1"], k["compose_r2"])
+    np.testing.assert_allclose(c, k["compose_out"], atol=5e-6)
+
+
+def test_modify_coords_and_clash_force():
+    k = load_golden("scalar_kats.npz")
+    out = ora.modify_coords(k["mc_x"], k["mc_rot"], k["mc_tr"])
+    np.testing.assert_allclose(out, k["mc_out"], atol=1e-5)
+    cf = ora.clash_force(k["cf_rec"], k["cf_lig"])
+    np.testing.assert_allclose(cf, k["cf_out"], rtol=2e-4, atol=1e-6)
+
+
+# ---- a-6 / a-7 / a-8 / a-10 ------------------------------------------------------------
+def test_coords6d_and_bins_full_matrix():
+    g = load_golden("geometry_small.npz")
+    pos = g["pos_centered"]
+    N = pos.shape[0]
+    dist, omega, theta, phi = ora.coords6d_full(pos)
+    off = ~np.eye(N, dtype=bool)
+    np.testing.assert_allclose(dist, g["dist"], atol=2e-5)
+    for mine, ref in ((omega, g["omega"]), (theta, g["theta"]), (phi, g["phi"])):
+        assert np.isnan(ref[~off]).all() and np.isnan(mine[~off]).all()   # NaN diagonal (-> bin 0)
+        d = np.abs(mine[off] - ref[off])
+        d = np.minimum(d, 360.0 - d)
+        assert d.max() < 2e-2, d.max()          # degrees; ill-conditioned near +-180 only
+        assert np.median(d) < 1e-5
+    bins = ora.bins_full(pos)
+    mism = int((bins != g["bins"]).sum())
+    assert mism <= 2, f"{mism} bin flips out of {bins.size}"
+    assert (bins[~off][:, 1:] == 0).all()
+    rel = ora.relpos_full(40, 30)
+    np.testing.assert_array_equal(rel, g["relpos"])
+
+
+def test_knn_matches_reference_topk():
+    g = load_golden("geometry_small.npz")
+    ca = g["pos_centered"][:, 1, :]
+    e = ora.knn_sample(ca, seed=1)
+    assert e.shape == (70, 60)
+    np.testing.assert_array_equal(e[:, :20], g["knn"])      # sorted ascending, slot 0 = self
+    assert (e[:, 0] == np.arange(70)).all()
+    for i in range(70):                                     # sampled slots: no repeats, disjoint from kNN
+        assert len(set(e[i])) == 60
+
+
+def test_sampling_distribution_inverse_cubic():
+    """Sampled-slot inclusion frequencies follow successive sampling with p ~ 1/d^3."""
+    g = load_golden("geometry_small.npz")
+    ca = g["pos_centered"][:, 1, :]
+    N = ca.shape[0]
+    cnt = np.zeros((N, N))
+    T = 400
+    for s in range(T):
+        e = ora.knn_sample(ca, seed=1000 + s)
+        for i in (0, 17, 55):
+            cnt[i, e[i, 20:]] += 1
+    rng = np.random.default_rng(0)
+    for i in (0, 17, 55):
+        d = np.linalg.norm(ca - ca[i], axis=1)
+        knn = set(g["knn"][i].tolist())
+        pool = np.array([j for j in range(N) if j not in knn])
+        w = 1.0 / np.maximum(d[pool], 1e-10) ** 3
+        exp = np.zeros(N)
+        M = 4000
+        for _ in range(M):   # Monte-Carlo expectation of inclusion under the same scheme
+            keys = rng.exponential(size=pool.size) / w
+            exp[pool[np.argsort(keys)[:40]]] += 1
+        exp /= M
+        got = cnt[i] / T
+        assert np.abs(got - exp).max() < 0.09, np.abs(got - exp).max()
+
+
+# ---- a-5 (+ a-9, a-11, a-12, a-13): one score evaluation -------------------------------
+FWD_CASES = ["fwd_syn_9_7", "fwd_syn_24_16", "fwd_syn_64_48_p0", "fwd_syn_64_48_p1", "fwd_syn_64_48_p2",
+             "fwd_7CEI_p0", "fwd_7CEI_p1", "fwd_7CEI_p2", "fwd_7CEI_p3"]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+def test_score_matches_reference(case, blob):
+    g = load_golden(case + ".npz")
+    o = ora.Oracle(blob, complex_for(case))
+    r = o.score(g["lig_pos"], float(g["t"]), edges=g["edges"])
+    flips = int((r["bins"] != g["bins"]).sum())
+    assert flips == 0, f"{flips} feature-bin flips"
+    np.testing.assert_array_equal(r["relpos"], g["relpos"])
+    assert r["num_clashes"] == int(g["num_clashes"])
+    habs = np.abs(r["h_layers"]).reshape(o.hp.depth, -1)
+    np.testing.assert_allclose(habs.mean(1), g["h_absmean"], rtol=1e-5)
+    assert rel_inf(r["h_layers"][0], g["h_first"]) < 2e-5
+    assert rel_inf(r["h_layers"][-1], g["h_last"]) < 5e-5
+    assert rel_inf(r["pos_out"], g["pos_out"]) < 1e-6
+    # SURVEY 8(d) gate 1: <= 1e-4 rel (L-inf / |.|-inf) on scores and f, <= 1e-4 abs on energy
+    assert rel_inf(r["f"], g["f"]) < 1e-4
+    assert rel_inf(r["tr_score"], g["tr_score"]) < 1e-4
+    assert rel_inf(r["rot_score"], g["rot_score"]) < 1e-4
+    assert abs(float(r["energy"]) - float(g["energy"])) < 1e-4
+    assert rel_inf(r["ires"], g["ires"][:, 0]) < 1e-4
+
+
+# ---- a-1 / a-2: the sampler ------------------------------------------------------------
+@pytest.mark.parametrize("case,steps", [("rollout_syn_24_16", 40), ("rollout_syn_64_48", 40), ("rollout_7CEI", 6)])
+def test_sampler_rollout_injected(case, steps, blob):
+    g = load_golden(case + ".npz")
+    o = ora.Oracle(blob, complex_for(case))
+    inj = dict(R0=g["R0"], tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"])
+    r = o.sample(num_steps=steps, inject=inj, trace=True, seed=0)
+    assert r["forwards"] == steps + 1
+    np.testing.assert_allclose(r["init_pose"], g["init_pose"], atol=2e-5)
+    ca = r["trace_pose"][:, :, 1, :]
+    ref = g["poses"][:, :, 1, :]
+    rmsd = np.sqrt(((ca - ref) ** 2).sum(-1).mean(-1))
+    # gate 3: short injected rollouts stay within 0.05 A (fp32); whole run reported
+    assert rmsd[:5].max() < 0.05, rmsd[:5]
+    assert rmsd.max() < 0.5, rmsd.max()
+    # free-running: pose drift feeds back into the scores, so this is looser than the teacher-forced gate
+    np.testing.assert_allclose(r["trace_scores"][:5, 0:3], g["tr_score"][:5], rtol=0,
+                               atol=1e-3 * np.abs(g["tr_score"]).max())
+    if rmsd.max() < 1e-3:
+        assert abs(float(r["energy"]) - float(g["final_energy"])) < 1e-3
+        np.testing.assert_allclose(r["tr_update"], g["tr_update"], atol=2e-3)
+        np.testing.assert_allclose(r["rot_update"], g["rot_update"], atol=2e-4)
+
+
+@pytest.mark.parametrize("case,steps", [("rollout_syn_64_48", 40)])
+def test_sampler_teacher_forced_steps(case, steps, blob):
+    """Per-step: feed the reference's pose, compare the scores and the Euler-Maruyama update."""
+    g = load_golden(case + ".npz")
+    o = ora.Oracle(blob, complex_for(case))
+    k = load_golden("scalar_kats.npz")
+    ts, dt = k["time_steps"], k["dt"]
+    g3, gso, _, _ = ora.diffusion_coefs(ts)
+    for i in (0, 1, 7, 20, 38, 39):
+        pose = g["init_pose"] if i == 0 else g["poses"][i - 1]
+        r = o.score(pose, ts[i], edges=g["edges"][i], debug=False)
+        assert rel_inf(r["tr_score"], g["tr_score"][i]) < 1e-4
+        assert rel_inf(r["rot_score"], g["rot_score"][i]) < 1e-4
+        assert abs(float(r["energy"]) - float(g["energy"][i])) < 1e-4
+        ns = 0.0 if i == steps - 1 else 0.5
+        rot = ora.torch_reverse(gso[i], g["rot_score"][i], dt, ns, g["z_rot"][i])
+        tr = ora.torch_reverse(g3[i], g["tr_score"][i], dt, ns, g["z_tr"][i])
+        np.testing.assert_allclose(rot, g["step_rot"][i], atol=1e-7, rtol=1e-6)
+        np.testing.assert_allclose(tr, g["step_tr"][i], atol=1e-6, rtol=1e-6)
+        nxt = ora.modify_coords(pose, g["step_rot"][i], g["step_tr"][i])
+        assert np.abs(nxt - g["poses"][i]).max() < 1e-4
