@@ -1,0 +1,694 @@
+// api.hip - C ABI of the engine (include/dfmdock_amd.h): handles, weight packing, the per-evaluation
+// kernel schedule and the Euler-Maruyama loop.  Everything runs on one HIP stream per complex handle;
+// the host only enqueues (no sync inside the 40-step loop).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dfm_device.h"
+#include "dfm_internal.h"
+
+using namespace dfm;
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+extern "C" const char *dfm_last_error(void) { return g_err.c_str(); }
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            return fail(_e == hipErrorOutOfMemory ? DFM_E_OOM : DFM_E_HIP,                         \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                       \
+        }                                                                                         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+struct DevPool {
+    std::vector<void *> ptrs;
+    ~DevPool() { release(); }
+    void release()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+    template <typename T> hipError_t alloc(T **out, size_t n)
+    {
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+        if (e == hipSuccess) { ptrs.push_back(p); *out = reinterpret_cast<T *>(p); }
+        return e;
+    }
+    template <typename T> hipError_t upload(T **out, const T *host, size_t n)
+    {
+        hipError_t e = alloc(out, n);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*out, host, n * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+struct dfm_model {
+    dfm_hparams hp;
+    DevPool pool;
+    float *single_embed = nullptr;   // [256][lm]
+    LayerDev layers[8];
+    HeadsDev heads;
+    float *en0_w = nullptr;          // [256][512]
+};
+
+struct Workspace {
+    int Bcap = 0;
+    DevPool pool;
+    float *pos = nullptr; float4 *ca4 = nullptr, *cb4 = nullptr;
+    int32_t *edges = nullptr; uint32_t *codes = nullptr; float *radial = nullptr;
+    float *h = nullptr, *h2 = nullptr, *A = nullptr, *Bm = nullptr, *agg = nullptr, *u = nullptr;
+    uint16_t *Bmb = nullptr, *mbuf = nullptr;
+    float *gn_shift = nullptr, *gn_den = nullptr;
+    float *fvec = nullptr, *en_part = nullptr; int32_t *clash_part = nullptr;
+    float *scores = nullptr, *lig_cur = nullptr, *tr_update = nullptr, *rot_update = nullptr, *t_dev = nullptr;
+};
+
+struct dfm_complex {
+    dfm_model *m = nullptr;
+    int R = 0, L = 0, N = 0, K = 0, knn = 0, nsamp = 0;
+    DevPool pool;
+    float *rec_pos = nullptr, *lig0 = nullptr;
+    float *h0 = nullptr, *A0 = nullptr, *Bm0 = nullptr; uint16_t *Bmb0 = nullptr;
+    Workspace ws;
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev;      // profiling events (pairs)
+    size_t ev_used = 0;
+    hipEvent_t ev_total[2] = {nullptr, nullptr};
+    dfm_profile prof = {0, 0, 0, 0};
+    uint32_t fwd_counter = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+extern "C" void dfm_default_hparams(dfm_hparams *hp)
+{
+    hp->lm_embed_dim = 1301; hp->positional_embed_dim = 66; hp->spatial_embed_dim = 100;
+    hp->node_dim = 256; hp->edge_dim = 128; hp->inner_dim = 128; hp->depth = 6; hp->knn = 20; hp->n_sample = 40;
+    hp->cut_off = 20.0f; hp->mask_dist = 22.0f;
+    hp->r3_min_sigma = 0.1; hp->r3_max_sigma = 30.0; hp->so3_min_sigma = 0.1; hp->so3_max_sigma = 1.5;
+}
+
+struct BlobMap {
+    const float *single_embed, *spatial_embed, *positional_embed;
+    struct Lw {
+        const float *e1_w, *e1_b, *e2_w, *e2_b, *n1_w, *n1_b, *gn_w, *gn_b, *gn_ms, *n2_w, *n2_b, *c1_w, *c1_b, *c2_w,
+            *att_w, *att_b;
+    } layer[8];
+    const float *en0_w, *en_ln_w, *en_ln_b, *en3_w;
+    const float *t_W, *t_lin, *trs0, *trs_ln_w, *trs_ln_b, *trs4, *rots0, *rots_ln_w, *rots_ln_b, *rots4;
+    int64_t total;
+};
+
+static void map_blob(const dfm_hparams *hp, const float *blob, BlobMap *w)
+{   // state_dict order of Score_Net (score_net_mlsb.py:249-341, egnn.py:37-93); see dfmdock_amd/weights.py
+    const int64_t Hh = hp->node_dim, He = hp->edge_dim, Hi = hp->inner_dim;
+    const float *p = blob;
+    auto take = [&](const float *&dst, int64_t n) { dst = p; p += n; };
+    take(w->single_embed, Hh * hp->lm_embed_dim);
+    take(w->spatial_embed, He * hp->spatial_embed_dim);
+    take(w->positional_embed, He * hp->positional_embed_dim);
+    for (int l = 0; l < hp->depth; ++l) {
+        auto &Lw = w->layer[l];
+        take(Lw.e1_w, Hh * (2 * Hh + 1 + He)); take(Lw.e1_b, Hh);
+        take(Lw.e2_w, Hh * Hh); take(Lw.e2_b, Hh);
+        take(Lw.n1_w, Hh * 2 * Hh); take(Lw.n1_b, Hh);
+        take(Lw.gn_w, Hh); take(Lw.gn_b, Hh); take(Lw.gn_ms, Hh);
+        take(Lw.n2_w, Hh * Hh); take(Lw.n2_b, Hh);
+        if (l == hp->depth - 1) { take(Lw.c1_w, Hh * Hh); take(Lw.c1_b, Hh); take(Lw.c2_w, Hh); }
+        else Lw.c1_w = Lw.c1_b = Lw.c2_w = nullptr;
+        take(Lw.att_w, Hh); take(Lw.att_b, 1);
+    }
+    take(w->en0_w, Hh * 2 * Hh); take(w->en_ln_w, Hh); take(w->en_ln_b, Hh); take(w->en3_w, Hh);
+    const float *skip;
+    take(skip, 2 * Hh * Hh); take(skip, 2 * Hh); take(skip, 4 * Hh * Hh); take(skip, 2 * Hh);   // to_ires.{0,2}
+    take(skip, 2 * Hh); take(skip, 1);                                                          // to_ires.4
+    take(w->t_W, Hi / 2); take(w->t_lin, Hi * Hi);
+    take(w->trs0, Hi * (Hi + 1)); take(w->trs_ln_w, Hi); take(w->trs_ln_b, Hi); take(w->trs4, Hi);
+    take(w->rots0, Hi * (Hi + 1)); take(w->rots_ln_w, Hi); take(w->rots_ln_b, Hi); take(w->rots4, Hi);
+    w->total = (int64_t)(p - blob);
+}
+
+extern "C" int64_t dfm_param_count(const dfm_hparams *hp)
+{
+    if (!hp || hp->depth < 1 || hp->depth > 8) return -1;
+    BlobMap w;
+    map_blob(hp, nullptr, &w);
+    return w.total;
+}
+
+extern "C" int dfm_device_count(int *count)
+{
+    if (!count) return fail(DFM_E_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(DFM_E_NODEVICE, hipGetErrorString(e)); }
+    *count = n;
+    return DFM_OK;
+}
+
+extern "C" int dfm_set_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(DFM_E_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(DFM_E_INVALID, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DFM_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    return DFM_OK;
+}
+
+static int degree_of(const dfm_hparams &hp, int N, int *knn, int *ns)
+{   // score_net_mlsb.py:89-94
+    int k = hp.knn, s = hp.n_sample;
+    if (N < k) { k = N; s = 0; }
+    if (N < k + s) s = N - k;
+    *knn = k; *ns = s;
+    return k + s;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int dfm_diffusion_coef(const dfm_hparams *hp, int which, double t, double *g_out, double *sigma_out)
+{
+    if (!hp) return fail(DFM_E_INVALID, "hp is NULL");
+    double sigma, g;
+    if (which == 0) {          // r3_diffuser.py:20-24
+        sigma = hp->r3_min_sigma * std::pow(hp->r3_max_sigma / hp->r3_min_sigma, t);
+        g = sigma * std::sqrt(2.0 * (std::log(hp->r3_max_sigma) - std::log(hp->r3_min_sigma)));
+    } else if (which == 1) {   // so3_diffuser.py:210-227
+        if (t < 0.0 || t > 1.0 || t != t) return fail(DFM_E_INVALID, "Invalid t (so3 sigma needs 0 <= t <= 1)");
+        sigma = std::log(t * std::exp(hp->so3_max_sigma) + (1.0 - t) * std::exp(hp->so3_min_sigma));
+        g = std::sqrt(2.0 * (std::exp(hp->so3_max_sigma) - std::exp(hp->so3_min_sigma)) * sigma / std::exp(sigma));
+    } else {
+        return fail(DFM_E_INVALID, "which must be 0 (R^3) or 1 (SO(3))");
+    }
+    if (g_out) *g_out = g;
+    if (sigma_out) *sigma_out = sigma;
+    return DFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static std::vector<uint16_t> pack_frags(const float *W /*[256 out][256 in]*/)
+{   // bf16 B-operand fragments of v_mfma_f32_32x32x16_bf16: [kk][nt][lane][e] = W[nt*32 + lane%32][chan(kk, lane/32, e)]
+    std::vector<uint16_t> f((size_t)16 * 8 * 64 * 8);
+    for (int kk = 0; kk < 16; ++kk)
+        for (int nt = 0; nt < 8; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int n = nt * 32 + (lane & 31), k = frag_channel(kk, lane >> 5, e);
+                    f[(((size_t)kk * 8 + nt) * 64 + lane) * 8 + e] = f2bf(W[(size_t)n * H + k]);
+                }
+    return f;
+}
+static std::vector<float> transpose256(const float *W)
+{
+    std::vector<float> t((size_t)H * H);
+    for (int o = 0; o < H; ++o)
+        for (int k = 0; k < H; ++k) t[(size_t)k * H + o] = W[(size_t)o * H + k];
+    return t;
+}
+
+extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const dfm_hparams *hp)
+{
+    if (!blob || !hp) { fail(DFM_E_INVALID, "blob or hp is NULL"); return nullptr; }
+    if (hp->node_dim != H || hp->edge_dim != HE || hp->inner_dim != HI || hp->spatial_embed_dim != 100 ||
+        hp->positional_embed_dim != 66 || hp->depth < 1 || hp->depth > 8 || hp->knn < 1 || hp->n_sample < 0 ||
+        hp->knn + hp->n_sample > 60 || hp->lm_embed_dim < 1) {
+        fail(DFM_E_INVALID, "unsupported hyper-parameters (kernels are built for node 256 / edge 128 / inner 128, degree <= 60)");
+        return nullptr;
+    }
+    BlobMap w;
+    map_blob(hp, blob, &w);
+    if ((int64_t)n_floats != w.total) {
+        fail(DFM_E_INVALID, "blob has " + std::to_string(n_floats) + " floats, expected " + std::to_string(w.total));
+        return nullptr;
+    }
+    dfm_model *m = new dfm_model();
+    m->hp = *hp;
+    DevPool &P = m->pool;
+    bool ok = true;
+    auto up = [&](float **dst, const float *src, size_t n) { ok = ok && P.upload(dst, src, n) == hipSuccess; };
+    auto up16 = [&](uint16_t **dst, const std::vector<uint16_t> &v) { ok = ok && P.upload(dst, v.data(), v.size()) == hipSuccess; };
+    const int Kin1 = 2 * H + 1 + HE;
+    up(&m->single_embed, w.single_embed, (size_t)H * hp->lm_embed_dim);
+    for (int l = 0; l < hp->depth && ok; ++l) {
+        const auto &Lw = w.layer[l];
+        LayerDev &D = m->layers[l];
+        std::memset(&D, 0, sizeof(D));
+        std::vector<float> Wab((size_t)2 * H * H), bias_ab(2 * H, 0.f), w_r(H);
+        for (int c = 0; c < H; ++c) {
+            std::memcpy(&Wab[(size_t)c * H], Lw.e1_w + (size_t)c * Kin1, H * sizeof(float));
+            std::memcpy(&Wab[(size_t)(H + c) * H], Lw.e1_w + (size_t)c * Kin1 + H, H * sizeof(float));
+            bias_ab[c] = Lw.e1_b[c];
+            w_r[c] = Lw.e1_w[(size_t)c * Kin1 + 2 * H];
+        }
+        // T[idx][c] = sum_k We[c][k] * SP[k][idx]  (one_hot @ spatial/positional_embed^T then We: a row gather)
+        std::vector<float> T((size_t)NTAB * H);
+        std::vector<uint16_t> Tb((size_t)NTAB * H);
+        for (int idx = 0; idx < NTAB; ++idx)
+            for (int c = 0; c < H; ++c) {
+                double s = 0;
+                for (int k = 0; k < HE; ++k) {
+                    const float sp = idx < 100 ? w.spatial_embed[(size_t)k * 100 + idx]
+                                               : w.positional_embed[(size_t)k * 66 + (idx - 100)];
+                    s += (double)Lw.e1_w[(size_t)c * Kin1 + 2 * H + 1 + k] * sp;
+                }
+                T[(size_t)idx * H + c] = (float)s;
+                Tb[(size_t)idx * H + c] = f2bf((float)s);
+            }
+        up(&D.Wab, Wab.data(), Wab.size()); up(&D.bias_ab, bias_ab.data(), bias_ab.size());
+        up(&D.w_r, w_r.data(), w_r.size()); up(&D.T, T.data(), T.size()); up16(&D.Tb, Tb);
+        const std::vector<float> W2t = transpose256(Lw.e2_w);
+        up(&D.W2t, W2t.data(), W2t.size()); up16(&D.W2f, pack_frags(Lw.e2_w));
+        up(&D.b2, Lw.e2_b, H); up(&D.att_w, Lw.att_w, H); D.att_b = Lw.att_b[0];
+        up(&D.W3, Lw.n1_w, (size_t)H * 2 * H); up(&D.b3, Lw.n1_b, H);
+        up(&D.gn_w, Lw.gn_w, H); up(&D.gn_b, Lw.gn_b, H); up(&D.gn_ms, Lw.gn_ms, H);
+        up(&D.W4, Lw.n2_w, (size_t)H * H); up(&D.b4, Lw.n2_b, H);
+        if (Lw.c1_w) {
+            const std::vector<float> Wc1t = transpose256(Lw.c1_w);
+            up(&D.Wc1t, Wc1t.data(), Wc1t.size()); up16(&D.Wc1f, pack_frags(Lw.c1_w));
+            up(&D.bc1, Lw.c1_b, H); up(&D.wc2, Lw.c2_w, H);
+        }
+    }
+    HeadsDev &Hd = m->heads;
+    std::memset(&Hd, 0, sizeof(Hd));
+    up(&m->en0_w, w.en0_w, (size_t)H * 2 * H);
+    Hd.en_wa = m->en0_w; Hd.en_wb = m->en0_w ? m->en0_w + H : nullptr;
+    up(&Hd.en_ln_w, w.en_ln_w, H); up(&Hd.en_ln_b, w.en_ln_b, H); up(&Hd.en_w3, w.en3_w, H);
+    up(&Hd.t_W, w.t_W, HI / 2); up(&Hd.t_lin, w.t_lin, (size_t)HI * HI);
+    up(&Hd.trs0, w.trs0, (size_t)HI * (HI + 1)); up(&Hd.trs_ln_w, w.trs_ln_w, HI); up(&Hd.trs_ln_b, w.trs_ln_b, HI);
+    up(&Hd.trs4, w.trs4, HI);
+    up(&Hd.rots0, w.rots0, (size_t)HI * (HI + 1)); up(&Hd.rots_ln_w, w.rots_ln_w, HI); up(&Hd.rots_ln_b, w.rots_ln_b, HI);
+    up(&Hd.rots4, w.rots4, HI);
+    if (!ok) {
+        fail(DFM_E_HIP, std::string("weight upload failed: ") + hipGetErrorString(hipGetLastError()));
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+
+extern "C" void dfm_model_destroy(dfm_model *m) { delete m; }
+
+// ------------------------------------------------------------------------------------------------
+extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, const float *lig_x, const float *rec_pos,
+                                           const float *lig_pos, int R, int L)
+{
+    if (!m || !rec_x || !lig_x || !rec_pos || !lig_pos) { fail(DFM_E_INVALID, "NULL argument"); return nullptr; }
+    if (R < 1 || L < 1 || R + L > MAX_NODES) { fail(DFM_E_INVALID, "need 1 <= R, L and R + L <= 4096"); return nullptr; }
+    dfm_complex *cx = new dfm_complex();
+    cx->m = m; cx->R = R; cx->L = L; cx->N = R + L;
+    cx->K = degree_of(m->hp, cx->N, &cx->knn, &cx->nsamp);
+    const int N = cx->N, lm = m->hp.lm_embed_dim;
+    DevPool &P = cx->pool;
+    bool ok = hipStreamCreate(&cx->stream) == hipSuccess;
+    ok = ok && hipEventCreate(&cx->ev_total[0]) == hipSuccess && hipEventCreate(&cx->ev_total[1]) == hipSuccess;
+    float *x = nullptr;
+    ok = ok && hipMalloc(reinterpret_cast<void **>(&x), (size_t)N * lm * sizeof(float)) == hipSuccess;
+    ok = ok && hipMemcpy(x, rec_x, (size_t)R * lm * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(x + (size_t)R * lm, lig_x, (size_t)L * lm * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && P.upload(&cx->rec_pos, rec_pos, (size_t)R * 9) == hipSuccess;
+    ok = ok && P.upload(&cx->lig0, lig_pos, (size_t)L * 9) == hipSuccess;
+    ok = ok && P.alloc(&cx->h0, (size_t)N * H) == hipSuccess && P.alloc(&cx->A0, (size_t)N * H) == hipSuccess;
+    ok = ok && P.alloc(&cx->Bm0, (size_t)N * H) == hipSuccess && P.alloc(&cx->Bmb0, (size_t)N * H) == hipSuccess;
+    if (ok) {
+        // node = single_embed(cat[rec_x, lig_x]) (score_net_mlsb.py:365-366): pose independent, once per complex
+        GemmArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.A0 = x; g.lda = lm; g.K = lm; g.W = m->single_embed; g.ldw = lm; g.M = N; g.Nout = H; g.C = cx->h0; g.ldc = H;
+        ok = launch_gemm_f32(g, cx->stream) == hipSuccess;
+        // layer-0 [Wa|Wb] projection is pose independent as well
+        std::memset(&g, 0, sizeof(g));
+        g.A0 = cx->h0; g.lda = H; g.K = H; g.W = m->layers[0].Wab; g.ldw = H; g.bias = m->layers[0].bias_ab; g.M = N;
+        g.Nout = 2 * H; g.epi = 2; g.C = cx->A0; g.ldc = H; g.C2 = cx->Bm0; g.C2b = cx->Bmb0;
+        ok = ok && launch_gemm_f32(g, cx->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(cx->stream) == hipSuccess;
+    }
+    if (x) (void)hipFree(x);
+    if (!ok) {
+        fail(DFM_E_HIP, std::string("complex creation failed: ") + hipGetErrorString(hipGetLastError()));
+        dfm_complex_destroy(cx);
+        return nullptr;
+    }
+    return cx;
+}
+
+extern "C" void dfm_complex_destroy(dfm_complex *cx)
+{
+    if (!cx) return;
+    if (cx->stream) { (void)hipStreamSynchronize(cx->stream); (void)hipStreamDestroy(cx->stream); }
+    for (hipEvent_t e : cx->ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) if (cx->ev_total[i]) (void)hipEventDestroy(cx->ev_total[i]);
+    delete cx;
+}
+
+extern "C" int dfm_complex_degree(const dfm_complex *cx) { return cx ? cx->K : -1; }
+
+// ------------------------------------------------------------------------------------------------
+static int ensure_workspace(dfm_complex *cx, int B, bool bf16)
+{
+    Workspace &W = cx->ws;
+    const bool need_mbuf = bf16 && !W.mbuf;
+    if (B <= W.Bcap && !need_mbuf) return DFM_OK;
+    if (B > W.Bcap) {
+        HIPCHK(hipStreamSynchronize(cx->stream));
+        W.pool.release();
+        W = Workspace();
+        const size_t N = cx->N, L = cx->L, R = cx->R, K = cx->K, b = B;
+        HIPCHK(W.pool.alloc(&W.pos, b * N * 9)); HIPCHK(W.pool.alloc(&W.ca4, b * N)); HIPCHK(W.pool.alloc(&W.cb4, b * N));
+        HIPCHK(W.pool.alloc(&W.edges, b * N * K)); HIPCHK(W.pool.alloc(&W.codes, b * N * K));
+        HIPCHK(W.pool.alloc(&W.radial, b * N * K));
+        HIPCHK(W.pool.alloc(&W.h, b * N * H)); HIPCHK(W.pool.alloc(&W.h2, b * N * H));
+        HIPCHK(W.pool.alloc(&W.A, b * N * H)); HIPCHK(W.pool.alloc(&W.Bm, b * N * H));
+        HIPCHK(W.pool.alloc(&W.Bmb, b * N * H)); HIPCHK(W.pool.alloc(&W.agg, b * N * H));
+        HIPCHK(W.pool.alloc(&W.u, b * N * H));
+        HIPCHK(W.pool.alloc(&W.gn_shift, b * H)); HIPCHK(W.pool.alloc(&W.gn_den, b * H));
+        HIPCHK(W.pool.alloc(&W.fvec, b * L * 3)); HIPCHK(W.pool.alloc(&W.en_part, b * R * 2));
+        HIPCHK(W.pool.alloc(&W.clash_part, b * R)); HIPCHK(W.pool.alloc(&W.scores, b * 8));
+        HIPCHK(W.pool.alloc(&W.lig_cur, b * L * 9)); HIPCHK(W.pool.alloc(&W.tr_update, b * 3));
+        HIPCHK(W.pool.alloc(&W.rot_update, b * 3)); HIPCHK(W.pool.alloc(&W.t_dev, b));
+        W.Bcap = B;
+    }
+    if (bf16 && !W.mbuf) HIPCHK(W.pool.alloc(&W.mbuf, (size_t)W.Bcap * cx->L * KPAD * H));
+    return DFM_OK;
+}
+
+__global__ void k_bcast_rows(const float *__restrict__ src, float *__restrict__ dst, long long per, long long total)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i % per];
+}
+__global__ void k_fill(float *dst, float v, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
+struct FwdOpts {
+    bool bf16 = false, want_energy = false, profile = false;
+    const int32_t *edges_dev = nullptr;   // [B][N][K] already on device (or nullptr = sample natively)
+    int64_t edges_pitch = 0;              // elements between trajectories in edges_dev
+    uint64_t seed = 0;
+    float *h_first_out = nullptr;         // device [B][N][H] tap (dfm_score debug)
+};
+
+// One batched score evaluation of the poses in ws.lig_cur at times ws.t_dev; leaves f in ws.fvec, the
+// node features in ws.h and (optionally) the energy partials.  Everything is enqueued on cx->stream.
+static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
+{
+    const dfm_model *m = cx->m;
+    Workspace &W = cx->ws;
+    hipStream_t s = cx->stream;
+    const int N = cx->N, R = cx->R, L = cx->L, K = cx->K, depth = m->hp.depth;
+    const uint32_t stream_id = cx->fwd_counter++;
+
+    HIPCHK(launch_prep_pose(cx->rec_pos, W.lig_cur, B, R, L, W.pos, W.ca4, W.cb4, s));
+    if (o.edges_dev) {
+        HIPCHK(hipMemcpy2DAsync(W.edges, (size_t)N * K * 4, o.edges_dev, (size_t)o.edges_pitch * 4, (size_t)N * K * 4, B,
+                                hipMemcpyDeviceToDevice, s));
+    } else {
+        HIPCHK(launch_knn_sample(W.ca4, B, N, cx->knn, cx->nsamp, o.seed, stream_id, W.edges, s));
+    }
+    HIPCHK(launch_edge_feat(W.pos, W.ca4, W.cb4, W.edges, B, N, R, K, m->hp.mask_dist, W.codes, W.radial, s));
+    {   // h <- node embedding, identical for every trajectory
+        const long long per = (long long)N * H / 4, total = per * B;
+        hipLaunchKernelGGL(k_bcast_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cx->h0, W.h, per, total);
+        HIPCHK(hipGetLastError());
+    }
+    float *h = W.h, *hn = W.h2;
+    const int M = B * N;
+    for (int l = 0; l < depth; ++l) {
+        const LayerDev &Lw = m->layers[l];
+        const bool last = (l == depth - 1);
+        EdgeArgs e;
+        std::memset(&e, 0, sizeof(e));
+        if (l == 0) { e.A = cx->A0; e.Bm = cx->Bm0; e.Bmb = cx->Bmb0; e.ab_bstride = 0; }
+        else { e.A = W.A; e.Bm = W.Bm; e.Bmb = W.Bmb; e.ab_bstride = (int64_t)N * H; }
+        e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
+        e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = last; e.fout = W.fvec; e.mbuf = W.mbuf;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (o.profile) {
+            if (cx->ev_used + 2 > cx->ev.size()) {
+                hipEvent_t a, b2;
+                HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b2));
+                cx->ev.push_back(a); cx->ev.push_back(b2);
+            }
+            e0 = cx->ev[cx->ev_used++]; e1 = cx->ev[cx->ev_used++];
+            HIPCHK(hipEventRecord(e0, s));
+        }
+        if (o.bf16) HIPCHK(launch_edge_bf16(e, s)); else HIPCHK(launch_edge_f32(e, s));
+        if (o.profile) {
+            HIPCHK(hipEventRecord(e1, s));
+            cx->prof.edge_kernel_launches += 1;
+            cx->prof.edge_rows += (int64_t)B * N * K;
+        }
+        if (last && o.bf16) HIPCHK(launch_coord_bf16(e, s));
+        // node_model (egnn.py:106-116): u = Linear(cat[h, agg]); GraphNorm; SiLU; Linear; residual
+        GemmArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.A0 = h; g.A1 = W.agg; g.lda = H; g.K = 2 * H; g.pro = 1; g.W = Lw.W3; g.ldw = 2 * H; g.bias = Lw.b3;
+        g.M = M; g.Nout = H; g.C = W.u; g.ldc = H;
+        HIPCHK(launch_gemm_f32(g, s));
+        HIPCHK(launch_gn_stats(W.u, B, N, Lw.gn_ms, W.gn_shift, W.gn_den, s));
+        std::memset(&g, 0, sizeof(g));
+        g.A0 = W.u; g.lda = H; g.K = H; g.pro = 2; g.gn_shift = W.gn_shift; g.gn_den = W.gn_den; g.gn_w = Lw.gn_w;
+        g.gn_b = Lw.gn_b; g.rows_per_graph = N; g.W = Lw.W4; g.ldw = H; g.bias = Lw.b4; g.M = M; g.Nout = H;
+        g.epi = 1; g.R = h; g.C = hn; g.ldc = H;
+        HIPCHK(launch_gemm_f32(g, s));
+        { float *tmp = h; h = hn; hn = tmp; }
+        if (l == 0 && o.h_first_out)
+            HIPCHK(hipMemcpyAsync(o.h_first_out, h, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (!last) {   // next layer's per-node halves of edge_mlp.0: A = Wa h + b1, Bm = Wb h
+            const LayerDev &Ln = m->layers[l + 1];
+            std::memset(&g, 0, sizeof(g));
+            g.A0 = h; g.lda = H; g.K = H; g.W = Ln.Wab; g.ldw = H; g.bias = Ln.bias_ab; g.M = M; g.Nout = 2 * H;
+            g.epi = 2; g.C = W.A; g.ldc = H; g.C2 = W.Bm; g.C2b = W.Bmb;
+            HIPCHK(launch_gemm_f32(g, s));
+        }
+    }
+    if (h != W.h) {   // keep the final node features in W.h (depth odd)
+        HIPCHK(hipMemcpyAsync(W.h, h, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (o.want_energy) {
+        // to_energy.0 on cat[h_r, h_l] = Wa h_r + Wb h_l: project every node once (reuses A / Bm buffers)
+        GemmArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.A0 = W.h; g.lda = H; g.K = H; g.W = m->heads.en_wa; g.ldw = 2 * H; g.M = M; g.Nout = H; g.C = W.A; g.ldc = H;
+        HIPCHK(launch_gemm_f32(g, s));
+        g.W = m->heads.en_wb; g.C = W.Bm;
+        HIPCHK(launch_gemm_f32(g, s));
+        HIPCHK(launch_energy_pairs(W.A, W.Bm, W.ca4, B, R, L, m->hp.cut_off, &m->heads, 1, W.en_part, W.clash_part, s));
+    }
+    return DFM_OK;
+}
+
+static void fill_head_args(dfm_complex *cx, int B, bool want_energy, HeadArgs *a)
+{
+    Workspace &W = cx->ws;
+    std::memset(a, 0, sizeof(*a));
+    a->fvec = W.fvec; a->ca4 = W.ca4; a->B = B; a->R = cx->R; a->L = cx->L; a->t = W.t_dev; a->hw = &cx->m->heads;
+    a->scores = W.scores; a->want_energy = want_energy; a->en_part = W.en_part; a->clash_part = W.clash_part;
+    a->lig_cur = W.lig_cur; a->tr_update = W.tr_update; a->rot_update = W.rot_update;
+}
+
+static int finish_profile(dfm_complex *cx)
+{
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, cx->ev_total[0], cx->ev_total[1]));
+    cx->prof.total_ms = ms;
+    for (size_t i = 0; i + 1 < cx->ev_used; i += 2) {
+        HIPCHK(hipEventElapsedTime(&ms, cx->ev[i], cx->ev[i + 1]));
+        cx->prof.edge_kernel_ms += ms;
+    }
+    return DFM_OK;
+}
+
+extern "C" int dfm_get_profile(const dfm_complex *cx, dfm_profile *p)
+{
+    if (!cx || !p) return fail(DFM_E_INVALID, "NULL argument");
+    *p = cx->prof;
+    return DFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const float *t, const int32_t *edges,
+                         uint64_t seed, uint32_t flags, dfm_score_out *out)
+{
+    if (!cx || !lig_pos || !t || !out || !out->tr_score || !out->rot_score) return fail(DFM_E_INVALID, "NULL argument");
+    if (B < 1) return fail(DFM_E_INVALID, "B must be >= 1");
+    const bool bf16 = flags & DFM_F_BF16, want_energy = flags & DFM_F_ENERGY;
+    int rc = ensure_workspace(cx, B, bf16);
+    if (rc) return rc;
+    Workspace &W = cx->ws;
+    hipStream_t s = cx->stream;
+    const size_t N = cx->N, L = cx->L, K = cx->K;
+    cx->prof = dfm_profile{0, 0, 0, 0};
+    cx->ev_used = 0;
+    HIPCHK(hipMemcpyAsync(W.lig_cur, lig_pos, (size_t)B * L * 9 * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(W.t_dev, t, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    int32_t *edges_dev = nullptr;
+    float *h_first_dev = nullptr;
+    if (edges) {
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&edges_dev), (size_t)B * N * K * 4));
+        HIPCHK(hipMemcpyAsync(edges_dev, edges, (size_t)B * N * K * 4, hipMemcpyHostToDevice, s));
+    }
+    if (out->h_first) HIPCHK(hipMalloc(reinterpret_cast<void **>(&h_first_dev), (size_t)B * N * H * 4));
+    FwdOpts o;
+    o.bf16 = bf16; o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
+    o.edges_pitch = (int64_t)N * K; o.seed = seed; o.h_first_out = h_first_dev;
+    HIPCHK(hipEventRecord(cx->ev_total[0], s));
+    rc = enqueue_forward(cx, B, o);
+    if (rc == DFM_OK) {
+        HeadArgs ha;
+        fill_head_args(cx, B, want_energy, &ha);
+        hipError_t e = launch_heads(ha, s);
+        if (e != hipSuccess) rc = fail(DFM_E_HIP, hipGetErrorString(e));
+    }
+    if (rc == DFM_OK) {
+        std::vector<float> sc((size_t)B * 8);
+        hipError_t e = hipEventRecord(cx->ev_total[1], s);
+        if (e == hipSuccess) e = hipMemcpyAsync(sc.data(), W.scores, sc.size() * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && out->f) e = hipMemcpyAsync(out->f, W.fvec, (size_t)B * L * 3 * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && out->h_last) e = hipMemcpyAsync(out->h_last, W.h, (size_t)B * N * H * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && out->h_first) e = hipMemcpyAsync(out->h_first, h_first_dev, (size_t)B * N * H * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && out->edges) e = hipMemcpyAsync(out->edges, W.edges, (size_t)B * N * K * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && out->edge_codes) e = hipMemcpyAsync(out->edge_codes, W.codes, (size_t)B * N * K * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = fail(DFM_E_HIP, hipGetErrorString(e));
+        else {
+            for (int b = 0; b < B; ++b) {
+                for (int k = 0; k < 3; ++k) { out->tr_score[b * 3 + k] = sc[b * 8 + k]; out->rot_score[b * 3 + k] = sc[b * 8 + 3 + k]; }
+                if (out->energy) out->energy[b] = sc[b * 8 + 6];
+                if (out->num_clashes) out->num_clashes[b] = (int32_t)sc[b * 8 + 7];
+            }
+            if (o.profile) rc = finish_profile(cx);
+        }
+    }
+    if (edges_dev) (void)hipFree(edges_dev);
+    if (h_first_dev) (void)hipFree(h_first_dev);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, float tr_noise_scale, float rot_noise_scale,
+                          uint32_t flags, uint64_t seed, const dfm_inject *inj, dfm_traj_out *out)
+{
+    if (!cx || !out) return fail(DFM_E_INVALID, "NULL argument");
+    if (B < 1 || num_steps < 2) return fail(DFM_E_INVALID, "need B >= 1 and num_steps >= 2");
+    const bool bf16 = flags & DFM_F_BF16;
+    int rc = ensure_workspace(cx, B, bf16);
+    if (rc) return rc;
+    Workspace &W = cx->ws;
+    hipStream_t s = cx->stream;
+    const dfm_hparams &hp = cx->m->hp;
+    const size_t N = cx->N, L = cx->L, K = cx->K, S = num_steps;
+    cx->prof = dfm_profile{0, 0, 0, 0};
+    cx->ev_used = 0;
+
+    // time grid: torch.linspace(1, eps, num_steps) in float32; dt = t[0] - t[1]   (inference_base.py:404-405)
+    std::vector<float> ts(S);
+    {
+        const float step = (eps - 1.0f) / (float)(num_steps - 1);
+        for (int i = 0; i < num_steps; ++i)
+            ts[i] = i < num_steps / 2 ? 1.0f + step * (float)i : eps - step * (float)(num_steps - 1 - i);
+    }
+    const float dt = ts[0] - ts[1];
+    std::vector<double> gr(S), gt(S);
+    for (int i = 0; i < num_steps; ++i) {
+        rc = dfm_diffusion_coef(&hp, 1, (double)ts[i], &gr[i], nullptr);   // ValueError parity: t outside [0,1]
+        if (rc) return rc;
+        dfm_diffusion_coef(&hp, 0, (double)ts[i], &gt[i], nullptr);
+    }
+
+    DevPool tmp;   // per-call device buffers (injections, traces)
+    float *R0_d = nullptr, *trd_d = nullptr, *zr_d = nullptr, *zt_d = nullptr, *tp_d = nullptr, *tsc_d = nullptr,
+          *ip_d = nullptr;
+    int32_t *ed_d = nullptr;
+    if (inj) {
+        if (inj->R0) HIPCHK(tmp.upload(&R0_d, inj->R0, (size_t)B * 9));
+        if (inj->tr_draw) HIPCHK(tmp.upload(&trd_d, inj->tr_draw, (size_t)B * 3));
+        if (inj->z_rot) HIPCHK(tmp.upload(&zr_d, inj->z_rot, (size_t)B * S * 3));
+        if (inj->z_tr) HIPCHK(tmp.upload(&zt_d, inj->z_tr, (size_t)B * S * 3));
+        if (inj->edges) HIPCHK(tmp.upload(&ed_d, inj->edges, (size_t)B * (S + 1) * N * K));
+    }
+    if (out->trace_pose) HIPCHK(tmp.alloc(&tp_d, (size_t)B * S * L * 9));
+    if (out->trace_scores) HIPCHK(tmp.alloc(&tsc_d, (size_t)B * (S + 1) * 8));
+
+    HIPCHK(hipEventRecord(cx->ev_total[0], s));
+    HIPCHK(launch_init_pose(cx->rec_pos, cx->lig0, B, cx->R, cx->L, R0_d, trd_d, seed, W.lig_cur, W.tr_update,
+                            W.rot_update, s));
+    if (out->init_pose) {
+        HIPCHK(tmp.alloc(&ip_d, (size_t)B * L * 9));
+        HIPCHK(hipMemcpyAsync(ip_d, W.lig_cur, (size_t)B * L * 9 * 4, hipMemcpyDeviceToDevice, s));
+    }
+    FwdOpts o;
+    o.bf16 = bf16; o.profile = flags & DFM_F_PROFILE; o.seed = seed; o.edges_pitch = (int64_t)(S + 1) * N * K;
+    const bool step_energy = (flags & DFM_F_STEP_ENERGY) != 0;
+    for (int i = 0; i < num_steps; ++i) {
+        const bool is_last = (i == num_steps - 1);
+        hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, W.t_dev, ts[i], B);
+        HIPCHK(hipGetLastError());
+        o.edges_dev = ed_d ? ed_d + (size_t)i * N * K : nullptr;
+        o.want_energy = step_energy;
+        rc = enqueue_forward(cx, B, o);
+        if (rc) return rc;
+        HeadArgs ha;
+        fill_head_args(cx, B, step_energy, &ha);
+        ha.do_update = 1;
+        ha.g2_r = (float)(gr[i] * gr[i]); ha.g_r = (float)gr[i]; ha.hg2_r = (float)(0.5 * (gr[i] * gr[i]));
+        ha.g2_t = (float)(gt[i] * gt[i]); ha.g_t = (float)gt[i]; ha.hg2_t = (float)(0.5 * (gt[i] * gt[i]));
+        ha.dt = dt; ha.sqrt_dt = std::sqrt(dt);
+        if (flags & DFM_F_NOISE_ANNEALING) { ha.tr_noise = ts[i]; ha.rot_noise = ts[i]; }       // inference_base.py:428-430
+        else { ha.tr_noise = is_last ? 0.0f : tr_noise_scale; ha.rot_noise = is_last ? 0.0f : rot_noise_scale; }
+        ha.ode = (flags & DFM_F_ODE) ? 1 : 0;
+        ha.z_rot = zr_d ? zr_d + (size_t)i * 3 : nullptr; ha.z_tr = zt_d ? zt_d + (size_t)i * 3 : nullptr;
+        ha.z_bstride = (int64_t)S * 3; ha.seed = seed; ha.step = (uint32_t)i;
+        if (tp_d) { ha.trace_pose = tp_d + (size_t)i * L * 9; ha.trace_bstride = (int64_t)S * L * 9; }
+        if (tsc_d) { ha.trace_scores = tsc_d + (size_t)i * 8; ha.trace_s_bstride = (int64_t)(S + 1) * 8; }
+        HIPCHK(launch_heads(ha, s));
+        if (flags & DFM_F_CLASH_FORCE) {   // inference_base.py:458-461
+            HIPCHK(launch_clash_force(cx->rec_pos, B, cx->R, cx->L, W.lig_cur, W.tr_update, s));
+            if (tp_d) HIPCHK(hipMemcpy2DAsync(tp_d + (size_t)i * L * 9, S * L * 9 * 4, W.lig_cur, L * 9 * 4, L * 9 * 4, B,
+                                              hipMemcpyDeviceToDevice, s));
+        }
+    }
+    // final evaluation of the last pose, with the energy head (inference_base.py:463-466); same t as the last step
+    o.edges_dev = ed_d ? ed_d + (size_t)num_steps * N * K : nullptr;
+    o.want_energy = true;
+    rc = enqueue_forward(cx, B, o);
+    if (rc) return rc;
+    {
+        HeadArgs ha;
+        fill_head_args(cx, B, true, &ha);
+        if (tsc_d) { ha.trace_scores = tsc_d + (size_t)num_steps * 8; ha.trace_s_bstride = (int64_t)(S + 1) * 8; }
+        HIPCHK(launch_heads(ha, s));
+    }
+    HIPCHK(hipEventRecord(cx->ev_total[1], s));
+    std::vector<float> sc((size_t)B * 8);
+    HIPCHK(hipMemcpyAsync(sc.data(), W.scores, sc.size() * 4, hipMemcpyDeviceToHost, s));
+    if (out->lig_pos) HIPCHK(hipMemcpyAsync(out->lig_pos, W.lig_cur, (size_t)B * L * 9 * 4, hipMemcpyDeviceToHost, s));
+    if (out->rot_update) HIPCHK(hipMemcpyAsync(out->rot_update, W.rot_update, (size_t)B * 3 * 4, hipMemcpyDeviceToHost, s));
+    if (out->tr_update) HIPCHK(hipMemcpyAsync(out->tr_update, W.tr_update, (size_t)B * 3 * 4, hipMemcpyDeviceToHost, s));
+    if (tp_d) HIPCHK(hipMemcpyAsync(out->trace_pose, tp_d, (size_t)B * S * L * 9 * 4, hipMemcpyDeviceToHost, s));
+    if (tsc_d) HIPCHK(hipMemcpyAsync(out->trace_scores, tsc_d, (size_t)B * (S + 1) * 8 * 4, hipMemcpyDeviceToHost, s));
+    if (ip_d) HIPCHK(hipMemcpyAsync(out->init_pose, ip_d, (size_t)B * L * 9 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b) {
+        if (out->energy) out->energy[b] = sc[b * 8 + 6];
+        if (out->num_clashes) out->num_clashes[b] = (int32_t)sc[b * 8 + 7];
+    }
+    if (o.profile) return finish_profile(cx);
+    return DFM_OK;
+}

@@ -1,0 +1,165 @@
+// dfm_device.h - device-side helpers: Philox4x32-10, bf16 pack/unpack, wave reductions, SO(3) maps.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dfm {
+
+// ---- Philox4x32-10 (Salmon et al. 2011): counter-based, keyed by (seed) ---------------------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+// uniform in (0,1): never 0 or 1
+__host__ __device__ inline float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// RNG stream ids (counter word 3)
+enum : uint32_t { RNG_EDGES = 1, RNG_NOISE = 2, RNG_INIT = 3 };
+
+// ---- bf16 <-> f32 (round to nearest even) -----------------------------------------------------------
+__host__ __device__ inline uint16_t f2bf(float f)
+{
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((v.u >> 16) | 0x40);   // NaN
+    const uint32_t r = 0x7fffu + ((v.u >> 16) & 1u);
+    return (uint16_t)((v.u + r) >> 16);
+}
+__host__ __device__ inline float bf2f(uint16_t b)
+{
+    union { float f; uint32_t u; } v;
+    v.u = (uint32_t)b << 16;
+    return v.f;
+}
+__device__ inline float bflo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ inline float bfhi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+__device__ inline uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ inline float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ inline float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+__device__ inline float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- wave (64-lane) reductions ------------------------------------------------------------------------
+__device__ inline float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ inline double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+// sum over the 32 lanes that share lane>>5
+__device__ inline float half_sum(float v)
+{
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// block-wide sum of a double via LDS scratch (>= blockDim/64 doubles); result broadcast to all threads
+__device__ inline double block_sum_d(double v, double *scratch)
+{
+    v = wave_sum_d(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    double t = 0;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+    return t;
+}
+
+// ---- SO(3) maps, float32, same operation order as the reference (src/utils/geometry.py) --------------
+__device__ inline void aa_to_quat(const float aa[3], float q[4])
+{   // geometry.py:154-183
+    const float ang = sqrtf(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+    const float half = 0.5f * ang;
+    const float s = (fabsf(ang) < 1e-6f) ? (0.5f - (ang * ang) / 48.0f) : (sinf(half) / ang);
+    q[0] = cosf(half); q[1] = aa[0] * s; q[2] = aa[1] * s; q[3] = aa[2] * s;
+}
+__device__ inline void quat_to_mat(const float q[4], float R[9])
+{   // geometry.py:18-45
+    const float r = q[0], i = q[1], j = q[2], k = q[3];
+    const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+    R[0] = 1 - two_s * (j * j + k * k); R[1] = two_s * (i * j - k * r); R[2] = two_s * (i * k + j * r);
+    R[3] = two_s * (i * j + k * r); R[4] = 1 - two_s * (i * i + k * k); R[5] = two_s * (j * k - i * r);
+    R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1 - two_s * (i * i + j * j);
+}
+__device__ inline void aa_to_mat(const float aa[3], float R[9])
+{
+    float q[4];
+    aa_to_quat(aa, q);
+    quat_to_mat(q, R);
+}
+__device__ inline void mat_to_quat(const float R[9], float q[4])
+{   // geometry.py:64-123
+    const float m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7],
+                m22 = R[8];
+    float qa[4] = {1.0f + m00 + m11 + m22, 1.0f + m00 - m11 - m22, 1.0f - m00 + m11 - m22, 1.0f - m00 - m11 + m22};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qa[c] = qa[c] > 0 ? sqrtf(qa[c]) : 0.0f;
+    int best = 0;
+#pragma unroll
+    for (int c = 1; c < 4; ++c) if (qa[c] > qa[best]) best = c;
+    float cand[4];
+    if (best == 0) { cand[0] = qa[0] * qa[0]; cand[1] = m21 - m12; cand[2] = m02 - m20; cand[3] = m10 - m01; }
+    else if (best == 1) { cand[0] = m21 - m12; cand[1] = qa[1] * qa[1]; cand[2] = m10 + m01; cand[3] = m02 + m20; }
+    else if (best == 2) { cand[0] = m02 - m20; cand[1] = m10 + m01; cand[2] = qa[2] * qa[2]; cand[3] = m12 + m21; }
+    else { cand[0] = m10 - m01; cand[1] = m20 + m02; cand[2] = m21 + m12; cand[3] = qa[3] * qa[3]; }
+    const float qb = qa[best];
+    const float den = 2.0f * (qb > 0.1f ? qb : 0.1f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q[c] = cand[c] / den;
+}
+__device__ inline void quat_to_aa(const float q[4], float aa[3])
+{   // geometry.py:126-151 (angle in [0, 2pi], not wrapped)
+    const float n = sqrtf(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float half = atan2f(n, q[0]);
+    const float ang = 2.0f * half;
+    const float s = (fabsf(ang) < 1e-6f) ? (0.5f - (ang * ang) / 48.0f) : (sinf(half) / ang);
+    aa[0] = q[1] / s; aa[1] = q[2] / s; aa[2] = q[3] / s;
+}
+__device__ inline void mat_to_aa(const float R[9], float aa[3])
+{
+    float q[4];
+    mat_to_quat(R, q);
+    quat_to_aa(q, aa);
+}
+// inference_base.py:311-316: axis_angle(R(r2) @ R(r1))
+__device__ inline void rot_compose(const float r1[3], const float r2[3], float out[3])
+{
+    float R1[9], R2[9], Rm[9];
+    aa_to_mat(r1, R1);
+    aa_to_mat(r2, R2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float s = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s += R2[i * 3 + j] * R1[j * 3 + k];
+            Rm[i * 3 + k] = s;
+        }
+    mat_to_aa(Rm, out);
+}
+
+}  // namespace dfm

@@ -1,0 +1,158 @@
+// dfm_internal.h - shared declarations of the gfx950 engine (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dfmdock_amd.h"
+
+namespace dfm {
+
+constexpr int H = 256;        // node_dim (kernels are specialised for it)
+constexpr int HE = 128;       // edge_dim
+constexpr int HI = 128;       // inner_dim
+constexpr int NTAB = 166;     // 100 spatial + 66 positional one-hot slots
+constexpr int KPAD = 64;      // edges per node padded to two 32-row MFMA tiles
+constexpr int MAX_NODES = 4096;
+
+// packed per-edge feature code: T-table row offsets are implied by the field
+// (dist 0..39 | omega 40.. | theta 64.. | phi 88.. | relpos 100..)
+__host__ __device__ inline uint32_t pack_code(int d, int om, int th, int ph, int rp)
+{
+    return (uint32_t)d | ((uint32_t)om << 6) | ((uint32_t)th << 11) | ((uint32_t)ph << 16) | ((uint32_t)rp << 20);
+}
+
+// channel handled by (k-step kk, lane-half h, element e) of the bf16 MFMA operands: each lane half
+// owns 128 contiguous channels so that per-lane gathers are 256-byte runs.
+__host__ __device__ inline int frag_channel(int kk, int h, int e) { return h * 128 + kk * 8 + e; }
+
+struct LayerDev {
+    float *Wab;       // [512][256]   rows 0..255 = edge_mlp.0.weight[:, 0:256] (h_i), 256..511 = [:, 256:512] (h_j)
+    float *bias_ab;   // [512]        [edge_mlp.0.bias ; 0]
+    float *w_r;       // [256]        edge_mlp.0.weight[:, 512] (radial column)
+    float *T;         // [166][256]   T = ([S|P]^T We^T): per-layer edge-feature lookup table, fp32
+    uint16_t *Tb;     // [166][256]   same, bf16
+    float *W2t;       // [256 in][256 out] edge_mlp.2.weight transposed (fp32 kernel)
+    uint16_t *W2f;    // [16][8][64][8] bf16 MFMA B-fragments of edge_mlp.2.weight
+    float *b2;        // [256]
+    float *att_w;     // [256]
+    float att_b;
+    float *W3;        // [256][512]   node_mlp.0.weight
+    float *b3;        // [256]
+    float *gn_w, *gn_b, *gn_ms;   // GraphNorm
+    float *W4;        // [256][256]   node_mlp.3.weight
+    float *b4;
+    float *Wc1t;      // [256 in][256 out] coord_mlp.0.weight transposed (last layer)
+    uint16_t *Wc1f;   // bf16 fragments of coord_mlp.0.weight
+    float *bc1;       // [256]
+    float *wc2;       // [256]
+};
+
+struct HeadsDev {
+    float *en_wa;     // [256][256] to_energy.0.weight[:, :256]
+    float *en_wb;     // [256][256] to_energy.0.weight[:, 256:]
+    float *en_ln_w, *en_ln_b, *en_w3;
+    float *t_W;       // [64]
+    float *t_lin;     // [128][128]
+    float *trs0, *trs_ln_w, *trs_ln_b, *trs4;   // [128][129], [128], [128], [128]
+    float *rots0, *rots_ln_w, *rots_ln_b, *rots4;
+};
+
+// ---- kernel launchers (each returns the hipError of the launch) ---------------------------------
+struct GemmArgs {
+    const float *A0;      // [M][lda0]
+    const float *A1;      // second half of a concatenated A (PRO_CONCAT) or nullptr
+    int lda;              // leading dimension of A0 (and A1)
+    int K;                // total K (for PRO_CONCAT: 2*256)
+    const float *W;       // [Nout][ldw]
+    int ldw;
+    const float *bias;    // [Nout] or nullptr
+    int M, Nout;
+    // prologue: GraphNorm + SiLU applied to A on load (rows grouped by trajectory: b = row / rows_per_graph)
+    int pro;              // 0 plain, 1 concat(A0,A1) each K/2 wide, 2 graphnorm+silu
+    const float *gn_shift;   // [B][256]  mean*mean_scale
+    const float *gn_den;     // [B][256]  sqrt(var+eps)
+    const float *gn_w, *gn_b;
+    int rows_per_graph;
+    // epilogue
+    int epi;              // 0 store, 1 residual add (C = R + acc + bias), 2 split into C (cols<256) and C2 (cols>=256, + bf16 copy)
+    const float *R;       // residual [M][ldc]
+    float *C;             // [M][ldc]
+    int ldc;
+    float *C2;            // [M][256]  (epi 2)
+    uint16_t *C2b;        // [M][256]  bf16 copy of C2 (epi 2), may be nullptr
+};
+hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s);
+
+hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, float *pos,
+                            float4 *ca4, float4 *cb4, hipStream_t s);
+hipError_t launch_knn_sample(const float4 *ca4, int B, int N, int knn, int nsamp, uint64_t seed, uint32_t stream_id,
+                             int32_t *edges, hipStream_t s);
+hipError_t launch_edge_feat(const float *pos, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B,
+                            int N, int R, int K, float mask_dist, uint32_t *codes, float *radial, hipStream_t s);
+
+struct EdgeArgs {
+    const float *A;        // [Ab][N][256]  Wa h_i + b1   (Ab = 1 when a_bstride == 0)
+    const float *Bm;       // [Ab][N][256]  Wb h_j        fp32
+    const uint16_t *Bmb;   // same, bf16
+    int64_t ab_bstride;    // elements between trajectories (0 for layer 0: pose independent)
+    const int32_t *edges;  // [B][N][K]
+    const uint32_t *codes; // [B][N][K]
+    const float *radial;   // [B][N][K]
+    const float4 *ca4;     // [B][N]
+    int B, N, R, K;
+    const LayerDev *lw;    // host copy of the layer's device pointers
+    float *agg;            // [B][N][256]
+    int last;              // last layer: also the coordinate update for ligand nodes
+    float *fout;           // [B][L][3]   (last)
+    uint16_t *mbuf;        // [B][L][64][256] bf16 gated messages (bf16 path, last)
+};
+hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);
+hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s);
+hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s);
+
+hipError_t launch_gn_stats(const float *u, int B, int N, const float *mean_scale, float *shift, float *den,
+                           hipStream_t s);
+
+struct HeadArgs {
+    const float *fvec;       // [B][L][3]
+    const float4 *ca4;       // [B][N]
+    int B, R, L;
+    const float *t;          // [B] device
+    const HeadsDev *hw;
+    float *scores;           // [B][8] tr(3) rot(3) energy clashes
+    // energy (optional)
+    int want_energy;
+    const float *en_part;    // [B][R][2]
+    const int32_t *clash_part;  // [B][R]
+    // Euler-Maruyama update (optional)
+    int do_update;
+    float g2_r, g_r, hg2_r, g2_t, g_t, hg2_t;   // float32-rounded diffusion coefficients of this step
+    float dt, sqrt_dt, rot_noise, tr_noise;
+    int ode;
+    const float *z_rot;      // [B][3] injected or nullptr (Philox)
+    const float *z_tr;
+    int64_t z_bstride;       // stride between trajectories in z arrays
+    uint64_t seed;
+    uint32_t step;
+    float *lig_cur;          // [B][L][9] in/out
+    float *tr_update;        // [B][3]
+    float *rot_update;       // [B][3]
+    float *trace_pose;       // [B][steps][L][9] or nullptr (already offset to this step)
+    int64_t trace_bstride;
+    float *trace_scores;     // [B][steps+1][8] or nullptr (already offset)
+    int64_t trace_s_bstride;
+};
+hipError_t launch_heads(const HeadArgs &a, hipStream_t s);
+
+hipError_t launch_energy_pairs(const float *enA, const float *enB, const float4 *ca4, int B, int R, int L,
+                               float cut_off, const HeadsDev *hw, int want_energy, float *en_part,
+                               int32_t *clash_part, hipStream_t s);
+
+hipError_t launch_init_pose(const float *rec_pos, const float *lig0, int B, int R, int L, const float *R0,
+                            const float *tr_draw, uint64_t seed, float *lig_cur, float *tr_update,
+                            float *rot_update, hipStream_t s);
+hipError_t launch_clash_force(const float *rec_pos, int B, int R, int L, float *lig_cur, float *tr_update,
+                              hipStream_t s);
+
+}  // namespace dfm

@@ -1,0 +1,469 @@
+// kernels_edge.hip - the EGNN edge model, attention gate, fixed-degree segment sum and the last layer's
+// coordinate update (reference: src/models/egnn.py:95-159).  This is ~92 % of the algorithmic FLOPs.
+//
+// Exact restructuring used by both kernels:
+//   Linear_1([h_i, h_j, radial, e_ij]) = (Wa h_i + b1) + Wb h_j + w_r * radial + sum of 5 rows of T_l
+// with A = Wa h + b1 and Bm = Wb h per NODE (kernels_dense.hip) and T_l = [S|P]^T We_l^T a per-layer
+// lookup table (one-hot -> Linear == row gather).  Every node has exactly K out-edges stored
+// contiguously, so scatter_add is a dense K-row reduction: no atomics anywhere.
+//
+//   k_edge_f32  : exact fp32 (VALU) - the parity-reference precision of the engine.
+//   k_edge_bf16 : 256x256 contraction on v_mfma_f32_32x32x16_bf16, fp32 accumulate; A-fragments are
+//                 built in registers straight from the gathers, the weight matrix lives in LDS for the
+//                 whole (persistent) workgroup.
+#include "dfm_device.h"
+#include "dfm_internal.h"
+
+namespace dfm {
+
+// =================================================================================================
+// fp32 kernel: one 256-thread workgroup per (trajectory, node); thread = channel.
+constexpr int KF = 60;   // accumulator rows held in registers (K <= 60 always: knn 20 + sample 40)
+
+struct EdgeKArgs {
+    const float *A, *Bm;
+    const uint16_t *Bmb;
+    long long ab_bstride;
+    const int32_t *edges;
+    const uint32_t *codes;
+    const float *radial;
+    const float4 *ca4;
+    int B, N, R, K, L;
+    const float *w_r, *T, *W2t, *b2, *att_w;
+    const uint16_t *Tb;
+    const uint4 *Wf;
+    float att_b;
+    const float *Wc1t, *bc1, *wc2;
+    float *agg;
+    int last;
+    float *fout;
+    uint16_t *mbuf;
+};
+
+__device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
+                               int c, float bias, float (&acc)[KF])
+{
+#pragma unroll
+    for (int s = 0; s < KF; ++s) acc[s] = bias;
+    for (int k = 0; k < H; k += 4) {
+        const float w0 = Wt[(size_t)(k + 0) * H + c], w1 = Wt[(size_t)(k + 1) * H + c],
+                    w2 = Wt[(size_t)(k + 2) * H + c], w3 = Wt[(size_t)(k + 3) * H + c];
+#pragma unroll
+        for (int s = 0; s < KF; ++s) {
+            const float4 a = *reinterpret_cast<const float4 *>(lds_rows + s * H + k);   // broadcast read
+            float t = acc[s];
+            t = fmaf(a.x, w0, t); t = fmaf(a.y, w1, t); t = fmaf(a.z, w2, t); t = fmaf(a.w, w3, t);
+            acc[s] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *rows = reinterpret_cast<float *>(smem);            // [KF][256]
+    float *s_rad = rows + KF * H;                             // [64]
+    float *s_gate = s_rad + 64;                               // [64]
+    int *s_j = reinterpret_cast<int *>(s_gate + 64);          // [64]
+    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_j + 64);   // [64]
+
+    const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const long long node = blockIdx.x;
+    const int b = (int)(node / p.N), i = (int)(node % p.N), K = p.K;
+    const size_t ebase = (size_t)node * K;
+    if (c < 64) {
+        const bool v = c < K;
+        s_j[c] = v ? p.edges[ebase + c] : i;
+        s_code[c] = v ? p.codes[ebase + c] : 0u;
+        s_rad[c] = v ? p.radial[ebase + c] : 0.f;
+    }
+    __syncthreads();
+    const size_t ab = (size_t)b * p.ab_bstride;
+    const float Ai = p.A[ab + (size_t)i * H + c];
+    const float wr = p.w_r[c];
+    // edge_mlp.0 + SiLU  (egnn.py:95-101)
+    for (int s = 0; s < KF; ++s) {
+        float v = 0.f;
+        if (s < K) {
+            const uint32_t code = s_code[s];
+            const int j = s_j[s];
+            float pre = Ai + p.Bm[ab + (size_t)j * H + c];
+            pre += wr * s_rad[s];
+            pre += p.T[(size_t)(code & 63u) * H + c];
+            pre += p.T[(size_t)(40u + ((code >> 6) & 31u)) * H + c];
+            pre += p.T[(size_t)(64u + ((code >> 11) & 31u)) * H + c];
+            pre += p.T[(size_t)(88u + ((code >> 16) & 15u)) * H + c];
+            pre += p.T[(size_t)(100u + ((code >> 20) & 127u)) * H + c];
+            v = silu_exact(pre);
+        }
+        rows[s * H + c] = v;
+    }
+    __syncthreads();
+    // edge_mlp.2 + SiLU
+    float acc[KF];
+    row_dot(rows, p.W2t, c, p.b2[c], acc);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KF; ++s) {
+        acc[s] = silu_exact(acc[s]);
+        rows[s * H + c] = acc[s];
+    }
+    __syncthreads();
+    // attention gate (egnn.py:102-104): sigmoid(att_w . m + att_b) per edge
+    for (int s = wave; s < KF; s += 4) {
+        const float4 m4 = *reinterpret_cast<const float4 *>(rows + s * H + lane * 4);
+        const float4 w4 = *reinterpret_cast<const float4 *>(p.att_w + lane * 4);
+        float t = m4.x * w4.x + m4.y * w4.y + m4.z * w4.z + m4.w * w4.w;
+        t = wave_sum(t);
+        if (lane == 0) s_gate[s] = (s < K) ? sigmoid_exact(t + p.att_b) : 0.f;
+    }
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KF; ++s) {
+        acc[s] *= s_gate[s];
+        sum += acc[s];   // unsorted_segment_sum over this node's edges, in edge order
+    }
+    p.agg[(size_t)node * H + c] = sum;
+
+    if (p.last && i >= p.R) {
+        // coord_model (egnn.py:118-137) for ligand nodes (lig_mask)
+#pragma unroll
+        for (int s = 0; s < KF; ++s) rows[s * H + c] = acc[s];
+        __syncthreads();
+        float cacc[KF];
+        row_dot(rows, p.Wc1t, c, p.bc1[c], cacc);
+        __syncthreads();
+        const float w2 = p.wc2[c];
+#pragma unroll
+        for (int s = 0; s < KF; ++s) rows[s * H + c] = silu_exact(cacc[s]) * w2;
+        __syncthreads();
+        for (int s = wave; s < KF; s += 4) {
+            const float4 m4 = *reinterpret_cast<const float4 *>(rows + s * H + lane * 4);
+            float t = (m4.x + m4.y) + (m4.z + m4.w);
+            t = wave_sum(t);
+            if (lane == 0) s_gate[s] = fminf(fmaxf(t, -2.0f), 2.0f);   // clamp_(-2, 2)
+        }
+        __syncthreads();
+        if (c < 3) {
+            const float4 *ca = p.ca4 + (size_t)b * p.N;
+            const float4 xi = ca[i];
+            const float xi_d = c == 0 ? xi.x : (c == 1 ? xi.y : xi.z);
+            float a = 0.f;
+            for (int s = 0; s < K; ++s) {
+                const float4 xj = ca[s_j[s]];
+                const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                const float r2 = (dx * dx + dy * dy) + dz * dz;
+                const float nrm = sqrtf(r2 + 1e-8f) + 1.0f;      // coord2radial, normalize=True
+                const float dd = (c == 0 ? dx : (c == 1 ? dy : dz)) / nrm;
+                a += dd * s_gate[s];
+            }
+            a = a / (float)(K > 1 ? K : 1);                        // unsorted_segment_mean
+            const float moved = xi_d + a;                          // coord + agg * lig_mask
+            p.fout[((size_t)b * p.L + (i - p.R)) * 3 + c] = moved - xi_d;   // f = pos_out - r
+        }
+    }
+}
+
+// =================================================================================================
+// bf16 MFMA kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+union Frag { uint4 u; bf16x8 b; };
+
+constexpr int LDS_WF_BYTES = 16 * 8 * 64 * 16;   // 131072: bf16 B-fragments of one 256x256 matrix
+constexpr int LDS_EDGE_BYTES = LDS_WF_BYTES + 3 * H * 4;
+
+struct RawK {            // gathered operands of one k-step (8 channels) of one edge row
+    float4 a0, a1;       // A[i]   (fp32)
+    uint4 bm;            // Bm[j]  (bf16 x 8)
+    uint4 t0, t1, t2, t3, t4;   // five T rows (bf16 x 8)
+};
+
+__device__ inline void acc8(float (&v)[8], const uint4 &q)
+{
+    v[0] += bflo(q.x); v[1] += bfhi(q.x); v[2] += bflo(q.y); v[3] += bfhi(q.y);
+    v[4] += bflo(q.z); v[5] += bfhi(q.z); v[6] += bflo(q.w); v[7] += bfhi(q.w);
+}
+
+template <int MODE>   // 0: edge messages (+ optional store of gated messages), 1: coordinate MLP on stored messages
+__global__ __launch_bounds__(512) void k_edge_bf16(EdgeKArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *Wf = reinterpret_cast<uint4 *>(smem);
+    float *s_wr = reinterpret_cast<float *>(smem + LDS_WF_BYTES);   // [256] radial column (MODE 0)
+    float *s_b = s_wr + H;                                          // [256] bias of this contraction
+    float *s_v = s_b + H;                                           // [256] att_w (MODE 0) / wc2 (MODE 1)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    for (int q = tid; q < LDS_WF_BYTES / 16; q += 512) Wf[q] = p.Wf[q];
+    if (tid < H) {
+        s_wr[tid] = MODE == 0 ? p.w_r[tid] : 0.f;
+        s_b[tid] = MODE == 0 ? p.b2[tid] : p.bc1[tid];
+        s_v[tid] = MODE == 0 ? p.att_w[tid] : p.wc2[tid];
+    }
+    __syncthreads();
+
+    // XCD-aware task order (speed only): workgroup g runs on XCD g % 8; give every XCD whole
+    // trajectories so that the gathered rows of Bm stay in that XCD's L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int NT = MODE == 0 ? p.N : p.L;                 // node tasks per trajectory
+    const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;   // few trajectories: split each over several XCDs
+    const int NTc = (NT + nsplit - 1) / nsplit;           // nodes per chunk
+    const int U = p.B * nsplit;                           // chunks; chunk u lives on XCD u % 8
+    const int nb = U > xcd ? (U - xcd + 7) >> 3 : 0;      // chunks owned by this XCD
+    const long long ntask = (long long)nb * NTc;
+    const int K = p.K, ntile = (K + 31) >> 5;
+
+    for (long long tt = (long long)slot * 8 + wave; tt < ntask; tt += (long long)wg_per_xcd * 8) {
+        const int u = xcd + 8 * (int)(tt / NTc);
+        const int b = __builtin_amdgcn_readfirstlane(u / nsplit);                    // wave-uniform -> SGPRs
+        const int idx = __builtin_amdgcn_readfirstlane((u % nsplit) * NTc + (int)(tt % NTc));
+        if (idx >= NT) continue;
+        const int i = (MODE == 0 ? 0 : p.R) + idx;
+        const size_t node = (size_t)b * p.N + i;
+        const size_t ebase = node * K;
+        const size_t ab = (size_t)b * p.ab_bstride;
+        float colsum[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) colsum[nt] = 0.f;
+        float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // MODE 1: sum_s cdiff * w
+
+        for (int mt = 0; mt < ntile; ++mt) {
+            const int s = mt * 32 + l31;
+            const bool valid = s < K;
+            f32x16 acc[8];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+            if (MODE == 0) {
+                const int j = valid ? p.edges[ebase + s] : i;
+                const uint32_t code = valid ? p.codes[ebase + s] : 0u;
+                const float rad = valid ? p.radial[ebase + s] : 0.f;
+                const float *Arow = p.A + ab + (size_t)i * H + h * 128;
+                const uint16_t *Brow = p.Bmb + ab + (size_t)j * H + h * 128;
+                const uint16_t *Tbase = p.Tb + h * 128;
+                const uint32_t o0 = (code & 63u) * H, o1 = (40u + ((code >> 6) & 31u)) * H,
+                               o2 = (64u + ((code >> 11) & 31u)) * H, o3 = (88u + ((code >> 16) & 15u)) * H,
+                               o4 = (100u + ((code >> 20) & 127u)) * H;
+                auto gather = [&](int kk, RawK &r) {
+                    r.a0 = *reinterpret_cast<const float4 *>(Arow + kk * 8);
+                    r.a1 = *reinterpret_cast<const float4 *>(Arow + kk * 8 + 4);
+                    r.bm = *reinterpret_cast<const uint4 *>(Brow + kk * 8);
+                    r.t0 = *reinterpret_cast<const uint4 *>(Tbase + o0 + kk * 8);
+                    r.t1 = *reinterpret_cast<const uint4 *>(Tbase + o1 + kk * 8);
+                    r.t2 = *reinterpret_cast<const uint4 *>(Tbase + o2 + kk * 8);
+                    r.t3 = *reinterpret_cast<const uint4 *>(Tbase + o3 + kk * 8);
+                    r.t4 = *reinterpret_cast<const uint4 *>(Tbase + o4 + kk * 8);
+                };
+                // one raw buffer, refilled in place: the gathers of k-step kk+1 fly under the SiLU + 8 MFMAs of kk
+                RawK raw;
+                gather(0, raw);
+#pragma unroll 1
+                for (int kk = 0; kk < 16; ++kk) {
+                    float v[8] = {raw.a0.x, raw.a0.y, raw.a0.z, raw.a0.w, raw.a1.x, raw.a1.y, raw.a1.z, raw.a1.w};
+                    acc8(v, raw.bm); acc8(v, raw.t0); acc8(v, raw.t1); acc8(v, raw.t2); acc8(v, raw.t3); acc8(v, raw.t4);
+                    if (kk + 1 < 16) gather(kk + 1, raw);
+                    const float4 w0 = *reinterpret_cast<const float4 *>(s_wr + h * 128 + kk * 8);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(s_wr + h * 128 + kk * 8 + 4);
+                    v[0] = fmaf(w0.x, rad, v[0]); v[1] = fmaf(w0.y, rad, v[1]); v[2] = fmaf(w0.z, rad, v[2]);
+                    v[3] = fmaf(w0.w, rad, v[3]); v[4] = fmaf(w1.x, rad, v[4]); v[5] = fmaf(w1.y, rad, v[5]);
+                    v[6] = fmaf(w1.z, rad, v[6]); v[7] = fmaf(w1.w, rad, v[7]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = valid ? silu(v[e]) : 0.f;
+                    Frag af;
+                    af.u = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt) {
+                        Frag bf;
+                        bf.u = Wf[(kk * 8 + nt) * 64 + lane];
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.b, bf.b, acc[nt], 0, 0, 0);
+                    }
+                }
+            } else {
+                const uint16_t *Mrow = p.mbuf + (((size_t)b * p.L + (i - p.R)) * KPAD + (valid ? s : 0)) * H + h * 128;
+                uint4 cur[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const uint4 *>(Mrow + q * 8);
+#pragma unroll 1
+                for (int g = 0; g < 4; ++g) {
+                    uint4 a4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a4[q] = valid ? cur[q] : make_uint4(0, 0, 0, 0);
+                    if (g < 3) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const uint4 *>(Mrow + ((g + 1) * 4 + q) * 8);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        Frag af;
+                        af.u = a4[q];
+#pragma unroll
+                        for (int nt = 0; nt < 8; ++nt) {
+                            Frag bf;
+                            bf.u = Wf[((g * 4 + q) * 8 + nt) * 64 + lane];
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.b, bf.b, acc[nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+
+            // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) -------------
+            float part[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const float bias = s_b[nt * 32 + l31], vv = s_v[nt * 32 + l31];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float m = silu(acc[nt][r] + bias);
+                    acc[nt][r] = m;
+                    part[r] = fmaf(m, vv, part[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r] = half_sum(part[r]);   // all 32 lanes of the half hold the row sum
+
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    part[r] = row < K ? 1.0f / (1.0f + __expf(-(part[r] + p.att_b))) : 0.f;   // attention gate
+                }
+                const bool store_m = p.last && i >= p.R;
+                uint16_t *Mout = store_m ? p.mbuf + (((size_t)b * p.L + (i - p.R)) * KPAD) * H : nullptr;
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    float cs = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float mg = acc[nt][r] * part[r];
+                        cs += mg;
+                        if (store_m) {
+                            // stored in operand order: element (row, channel) at [row][channel]; the consumer
+                            // (MODE 1) reads channel = h*128 + kk*8 + e, so store by natural channel index
+                            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            Mout[(size_t)row * H + nt * 32 + l31] = f2bf(mg);
+                        }
+                    }
+                    colsum[nt] += cs;
+                }
+            } else {
+                // coord_mlp: w = clamp(sum_c silu(.) * wc2, +-2); x_i += mean_s (x_i - x_j)/(|x_i - x_j| + 1) * w
+                if (l31 == 0) {
+                    const float4 *ca = p.ca4 + (size_t)b * p.N;
+                    const float4 xi = ca[i];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (row < K) {
+                            const float w = fminf(fmaxf(part[r], -2.0f), 2.0f);
+                            const float4 xj = ca[p.edges[ebase + row]];
+                            const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                            const float nrm = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f) + 1.0f;
+                            cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;
+                        }
+                    }
+                }
+            }
+        }   // mt
+
+        if (MODE == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const float t = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
+                if (h == 0) p.agg[node * H + nt * 32 + l31] = t;
+            }
+        } else {
+            cacc0 += __shfl_xor(cacc0, 32, 64);
+            cacc1 += __shfl_xor(cacc1, 32, 64);
+            cacc2 += __shfl_xor(cacc2, 32, 64);
+            if (lane == 0) {
+                const float4 xi = p.ca4[node];
+                const float inv = 1.0f / (float)(K > 1 ? K : 1);
+                float *fo = p.fout + ((size_t)b * p.L + (i - p.R)) * 3;
+                fo[0] = (xi.x + cacc0 * inv) - xi.x;
+                fo[1] = (xi.y + cacc1 * inv) - xi.y;
+                fo[2] = (xi.z + cacc2 * inv) - xi.z;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+static EdgeKArgs to_kargs(const EdgeArgs &a)
+{
+    EdgeKArgs k;
+    k.A = a.A; k.Bm = a.Bm; k.Bmb = a.Bmb; k.ab_bstride = a.ab_bstride;
+    k.edges = a.edges; k.codes = a.codes; k.radial = a.radial; k.ca4 = a.ca4;
+    k.B = a.B; k.N = a.N; k.R = a.R; k.K = a.K; k.L = a.N - a.R;
+    const LayerDev *w = a.lw;
+    k.w_r = w->w_r; k.T = w->T; k.W2t = w->W2t; k.b2 = w->b2; k.att_w = w->att_w; k.Tb = w->Tb;
+    k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
+    k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
+    k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf;
+    return k;
+}
+
+hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s)
+{
+    static bool attr_set = false;
+    const int lds = KF * H * 4 + 4 * 64 * 4;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_f32),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const EdgeKArgs k = to_kargs(a);
+    hipLaunchKernelGGL(k_edge_f32, dim3((unsigned)((long long)a.B * a.N)), dim3(256), lds, s, k);
+    return hipGetLastError();
+}
+
+static int persistent_grid(long long wave_tasks)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    long long wgs = (wave_tasks + 7) / 8;
+    long long g = wgs < cus ? wgs : cus;
+    g = (g + 7) / 8 * 8;   // multiple of the XCD count
+    return (int)g;
+}
+
+hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_bf16<0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_EDGE_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const EdgeKArgs k = to_kargs(a);
+    const int grid = persistent_grid((long long)a.B * a.N);
+    hipLaunchKernelGGL(k_edge_bf16<0>, dim3(grid), dim3(512), LDS_EDGE_BYTES, s, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_bf16<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_EDGE_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    EdgeKArgs k = to_kargs(a);
+    k.Wf = reinterpret_cast<const uint4 *>(a.lw->Wc1f);
+    const int grid = persistent_grid((long long)a.B * (a.N - a.R));
+    hipLaunchKernelGGL(k_edge_bf16<1>, dim3(grid), dim3(512), LDS_EDGE_BYTES, s, k);
+    return hipGetLastError();
+}
+
+}  // namespace dfm

@@ -1,0 +1,391 @@
+// kernels_geom.hip - pose preparation, kNN + inverse-cubic edge sampling, per-edge 6-D feature bins,
+// initial pose randomisation, clash force.  HBM/latency-bound integer + fp32 geometry (no MFMA here).
+//
+// Compiled with -ffp-contract=off: the feature bins and the kNN order are discontinuous functions of
+// fp32 geometry, so every operation is rounded exactly like the reference's op-by-op torch evaluation
+// (src/utils/coords6d.py, src/models/score_net_mlsb.py:30-135).
+#include "dfm_device.h"
+#include "dfm_internal.h"
+
+namespace dfm {
+
+// ------------------------------------------------------------------------------------------------
+// prep_pose: centre receptor + ligand on the ligand CA centroid (score_net_mlsb.py:353-359), build
+// CA and virtual-CB arrays (coords6d.py:71-75).  One workgroup per trajectory.
+__global__ __launch_bounds__(256) void k_prep_pose(const float *__restrict__ rec_pos, const float *__restrict__ lig_cur,
+                                                   int R, int L, float *__restrict__ pos, float4 *__restrict__ ca4,
+                                                   float4 *__restrict__ cb4)
+{
+    __shared__ double scratch[8];
+    __shared__ float center[3];
+    const int b = blockIdx.x, N = R + L;
+    const float *lig = lig_cur + (size_t)b * L * 9;
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int q = threadIdx.x; q < L; q += blockDim.x) {
+        s0 += lig[q * 9 + 3]; s1 += lig[q * 9 + 4]; s2 += lig[q * 9 + 5];
+    }
+    s0 = block_sum_d(s0, scratch);
+    s1 = block_sum_d(s1, scratch);
+    s2 = block_sum_d(s2, scratch);
+    if (threadIdx.x == 0) {
+        center[0] = (float)(s0 / L); center[1] = (float)(s1 / L); center[2] = (float)(s2 / L);
+    }
+    __syncthreads();
+    const float cx = center[0], cy = center[1], cz = center[2];
+    float *P = pos + (size_t)b * N * 9;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const float *src = i < R ? rec_pos + (size_t)i * 9 : lig + (size_t)(i - R) * 9;
+        float v[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            v[a * 3 + 0] = src[a * 3 + 0] - cx;
+            v[a * 3 + 1] = src[a * 3 + 1] - cy;
+            v[a * 3 + 2] = src[a * 3 + 2] - cz;
+        }
+#pragma unroll
+        for (int a = 0; a < 9; ++a) P[(size_t)i * 9 + a] = v[a];
+        // Cb = -0.58273431*a + 0.56802827*b - 0.54067466*c + Ca ;  b = Ca - N, c = C - Ca, a = b x c
+        const float bx = v[3] - v[0], by = v[4] - v[1], bz = v[5] - v[2];
+        const float cx_ = v[6] - v[3], cy_ = v[7] - v[4], cz_ = v[8] - v[5];
+        const float ax = by * cz_ - bz * cy_, ay = bz * cx_ - bx * cz_, az = bx * cy_ - by * cx_;
+        float4 cb;
+        cb.x = ((-0.58273431f * ax + 0.56802827f * bx) - 0.54067466f * cx_) + v[3];
+        cb.y = ((-0.58273431f * ay + 0.56802827f * by) - 0.54067466f * cy_) + v[4];
+        cb.z = ((-0.58273431f * az + 0.56802827f * bz) - 0.54067466f * cz_) + v[5];
+        cb.w = 0.f;
+        ca4[(size_t)b * N + i] = make_float4(v[3], v[4], v[5], 0.f);
+        cb4[(size_t)b * N + i] = cb;
+    }
+}
+
+hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, float *pos, float4 *ca4,
+                            float4 *cb4, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prep_pose, dim3(B), dim3(256), 0, s, rec_pos, lig_cur, R, L, pos, ca4, cb4);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// kNN(20) + sample(40, p ~ 1/d^3, without replacement) (score_net_mlsb.py:85-135).
+// One 64-lane wave per (trajectory, node).  The lane owns candidates j = 4*(lane + 64*q) + e
+// (q < NPL/4, e < 4) in registers.  Top-k by repeated wave-wide arg-min on a 64-bit (value, index)
+// key: ascending distance, lowest index first on ties, slot 0 = the node itself.  The sampled slots
+// are an exponential race: key_j = Exp(1)_j * d_j^3, the 40 smallest keys = successive sampling
+// without replacement with p ~ d^-3 (the scheme torch.multinomial uses), Exp(1) from Philox4x32-10.
+__device__ inline unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, m, 64);
+        const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256) void k_knn_sample(const float4 *__restrict__ ca4, int B, int N, int knn, int nsamp,
+                                                    uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
+                                                    int32_t *__restrict__ edges)
+{
+    const int lane = threadIdx.x & 63;
+    const long long node = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (node >= (long long)B * N) return;   // whole wave exits together; no block-level sync below
+    const int b = (int)(node / N), i = (int)(node % N);
+    const float4 *ca = ca4 + (size_t)b * N;
+    const float4 ci = ca[i];
+    const int K = knn + nsamp;
+
+    float val[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL / 4; ++q) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * (lane + 64 * q) + e;
+            float d = __builtin_inff();
+            if (j < N) {
+                const float4 cj = ca[j];
+                const float dx = ci.x - cj.x, dy = ci.y - cj.y, dz = ci.z - cj.z;
+                d = sqrtf((dx * dx + dy * dy) + dz * dz);
+            }
+            val[q * 4 + e] = d;
+        }
+    }
+    float dist[NPL];
+#pragma unroll
+    for (int r = 0; r < NPL; ++r) dist[r] = val[r];
+
+    int my_edge = -1;   // lane s keeps the winner of pass s
+    for (int s = 0; s < K; ++s) {
+        if (s == knn) {
+            // switch from distances to race keys for every candidate not yet taken
+#pragma unroll
+            for (int q = 0; q < NPL / 4; ++q) {
+                const u32x4 rnd = philox4x32((uint32_t)node, (uint32_t)(node >> 32) ^ ((uint32_t)(lane + 64 * q) << 8),
+                                             stream_id, RNG_EDGES, seed_lo, seed_hi);
+                const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = q * 4 + e;
+                    float d = dist[r];
+                    float key = __builtin_inff();
+                    if (val[r] != __builtin_inff()) {   // not taken by kNN, j < N
+                        d = d < 1e-10f ? 1e-10f : d;
+                        key = -logf(u01(rr[e])) * ((d * d) * d);
+                    }
+                    val[r] = key;
+                }
+            }
+        }
+        // lane-local arg-min
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int q = 0; q < NPL / 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = q * 4 + e;
+                const unsigned j = 4u * (lane + 64 * q) + e;
+                const unsigned long long k = ((unsigned long long)__float_as_uint(val[r]) << 32) | j;
+                best = k < best ? k : best;
+            }
+        best = wave_min_u64(best);
+        const int win = (int)(unsigned)best;
+#pragma unroll
+        for (int q = 0; q < NPL / 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * (lane + 64 * q) + e;
+                if (j == win) val[q * 4 + e] = __builtin_inff();
+            }
+        if (lane == s) my_edge = win;
+    }
+    if (lane < K) edges[((size_t)b * N + i) * K + lane] = my_edge;
+}
+
+hipError_t launch_knn_sample(const float4 *ca4, int B, int N, int knn, int nsamp, uint64_t seed, uint32_t stream_id,
+                             int32_t *edges, hipStream_t s)
+{
+    const long long nodes = (long long)B * N;
+    const dim3 grid((unsigned)((nodes + 3) / 4)), block(256);
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+#define LAUNCH(NPL) hipLaunchKernelGGL(k_knn_sample<NPL>, grid, block, 0, s, ca4, B, N, knn, nsamp, lo, hi, stream_id, edges)
+    if (N <= 256) LAUNCH(4);
+    else if (N <= 512) LAUNCH(8);
+    else if (N <= 1024) LAUNCH(16);
+    else if (N <= 2048) LAUNCH(32);
+    else LAUNCH(64);
+#undef LAUNCH
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-edge trRosetta 6-D features -> bins (coords6d.py:10-103, score_net_mlsb.py:30-70), relpos
+// (inference_base.py:255-292) and the EGNN radial |x_i - x_j|^2 (egnn.py:139-148).  One thread per edge.
+struct v3 { float x, y, z; };
+__device__ inline v3 vsub(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ inline v3 vcross(v3 a, v3 b) { return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ inline float vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ inline float vnorm(v3 a) { return sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+__device__ inline v3 vdivs(v3 a, float s) { return v3{a.x / s, a.y / s, a.z / s}; }
+
+__device__ inline float dihedral_deg(v3 a, v3 b, v3 c, v3 d)
+{   // coords6d.py:25-43
+    const v3 b1 = vsub(a, b), b2 = vsub(b, c), b3 = vsub(c, d);
+    v3 n1 = vcross(b1, b2); n1 = vdivs(n1, vnorm(n1));
+    v3 n2 = vcross(b2, b3); n2 = vdivs(n2, vnorm(n2));
+    const v3 m1 = vcross(n1, vdivs(b2, vnorm(b2)));
+    return atan2f(vdot(m1, n2), vdot(n1, n2)) * 180.0f / 3.14159265358979323846f;
+}
+__device__ inline float planar_deg(v3 a, v3 b, v3 c)
+{   // coords6d.py:46-58
+    const v3 v1 = vsub(a, b), v2 = vsub(c, b);
+    return acosf(vdot(v1, v2) / (vnorm(v1) * vnorm(v2))) * 180.0f / 3.14159265358979323846f;
+}
+// torch.linspace(-180, 180, 23) as float32 (golden: tests/golden/scalar_kats.npz angle boundaries)
+__constant__ float c_angle_bounds[23] = {
+    -180.0f, -163.63636779785156f, -147.27273559570312f, -130.90908813476562f, -114.54545593261719f,
+    -98.18182373046875f, -81.81818389892578f, -65.45454406738281f, -49.090911865234375f,
+    -32.72727584838867f, -16.36363983154297f, 3.814697265625e-06f, 16.36363983154297f,
+    32.72727584838867f, 49.090911865234375f, 65.45454406738281f, 81.81818389892578f, 98.18182373046875f,
+    114.54545593261719f, 130.90908813476562f, 147.27273559570312f, 163.63636779785156f, 180.0f};
+
+__device__ inline int bin_angle(float a)
+{   // #(a > boundary); NaN compares false -> bin 0
+    int b = 0;
+#pragma unroll
+    for (int i = 0; i < 23; ++i) b += (a > c_angle_bounds[i]) ? 1 : 0;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void k_edge_feat(const float *__restrict__ pos, const float4 *__restrict__ ca4,
+                                                   const float4 *__restrict__ cb4, const int32_t *__restrict__ edges,
+                                                   long long total, int N, int R, int K, float mask_dist,
+                                                   uint32_t *__restrict__ codes, float *__restrict__ radial)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const long long node = e / K;
+    const int b = (int)(node / N), i = (int)(node % N);
+    const int j = edges[e];
+    const size_t base = (size_t)b * N;
+    const float4 cai4 = ca4[base + i], caj4 = ca4[base + j], cbi4 = cb4[base + i], cbj4 = cb4[base + j];
+    const float *pi = pos + (base + i) * 9;
+    const v3 Ni{pi[0], pi[1], pi[2]};
+    const v3 Cai{cai4.x, cai4.y, cai4.z}, Caj{caj4.x, caj4.y, caj4.z}, Cbi{cbi4.x, cbi4.y, cbi4.z},
+        Cbj{cbj4.x, cbj4.y, cbj4.z};
+    const v3 dv = vsub(Cai, Caj);
+    const float r2 = (dv.x * dv.x + dv.y * dv.y) + dv.z * dv.z;
+    const float d = sqrtf(r2);
+    int bd = 0;
+#pragma unroll
+    for (int q = 0; q < 39; ++q) bd += (d > (3.25f + 1.25f * (float)q)) ? 1 : 0;   // linspace(3.25, 50.75, 39)
+    int bo = 0, bt = 0, bp = 0;
+    if (d < mask_dist && i != j) {   // mask = dist < 22.0, fill_diagonal_(0)
+        const float om = dihedral_deg(Cai, Cbi, Cbj, Caj);
+        const float th = dihedral_deg(Ni, Cai, Cbi, Cbj);
+        const float ph = planar_deg(Cai, Cbi, Cbj);
+        bo = bin_angle(om);
+        bt = bin_angle(th);
+#pragma unroll
+        for (int q = 0; q < 11; ++q) bp += (ph > 18.0f * (float)q) ? 1 : 0;     // linspace(0, 180, 11)
+    }
+    const bool same = (i < R) == (j < R);
+    int off = i - j + 32;
+    off = off < 0 ? 0 : (off > 64 ? 64 : off);
+    const int rp = same ? off : 65;
+    codes[e] = pack_code(bd, bo, bt, bp, rp);
+    radial[e] = r2;
+}
+
+hipError_t launch_edge_feat(const float *pos, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B, int N,
+                            int R, int K, float mask_dist, uint32_t *codes, float *radial, hipStream_t s)
+{
+    const long long total = (long long)B * N * K;
+    hipLaunchKernelGGL(k_edge_feat, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pos, ca4, cb4, edges, total,
+                       N, R, K, mask_dist, codes, radial);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// randomize_pose (inference_base.py:318-340): uniform random rotation about the ligand CA centroid and
+// a N(0, 30^2) translation relative to the receptor centroid.  One workgroup per trajectory.
+__device__ inline float normal_from(uint32_t a, uint32_t b)
+{
+    return sqrtf(-2.0f * logf(u01(a))) * cosf(6.283185307179586f * u01(b));
+}
+
+__global__ __launch_bounds__(256) void k_init_pose(const float *__restrict__ rec_pos, const float *__restrict__ lig0, int R,
+                                                   int L, const float *__restrict__ R0_inj,
+                                                   const float *__restrict__ tr_inj, uint32_t seed_lo, uint32_t seed_hi,
+                                                   float *__restrict__ lig_cur, float *__restrict__ tr_update,
+                                                   float *__restrict__ rot_update)
+{
+    __shared__ double scratch[8];
+    __shared__ float sh[24];   // c2[3], tr[3], R0[9]
+    const int b = blockIdx.x;
+    double a0 = 0, a1 = 0, a2 = 0, l0 = 0, l1 = 0, l2 = 0;
+    for (int q = threadIdx.x; q < R; q += blockDim.x) { a0 += rec_pos[q * 9 + 3]; a1 += rec_pos[q * 9 + 4]; a2 += rec_pos[q * 9 + 5]; }
+    for (int q = threadIdx.x; q < L; q += blockDim.x) { l0 += lig0[q * 9 + 3]; l1 += lig0[q * 9 + 4]; l2 += lig0[q * 9 + 5]; }
+    a0 = block_sum_d(a0, scratch); a1 = block_sum_d(a1, scratch); a2 = block_sum_d(a2, scratch);
+    l0 = block_sum_d(l0, scratch); l1 = block_sum_d(l1, scratch); l2 = block_sum_d(l2, scratch);
+    if (threadIdx.x == 0) {
+        const float c1[3] = {(float)(a0 / R), (float)(a1 / R), (float)(a2 / R)};
+        const float c2[3] = {(float)(l0 / L), (float)(l1 / L), (float)(l2 / L)};
+        float R0[9], draw[3];
+        if (R0_inj) {
+            for (int k = 0; k < 9; ++k) R0[k] = R0_inj[b * 9 + k];
+        } else {
+            // scipy Rotation.random(): normalised Gaussian quaternion (x,y,z,w), matrix in float64
+            const u32x4 r1 = philox4x32((uint32_t)b, 0u, 0u, RNG_INIT, seed_lo, seed_hi);
+            const u32x4 r2 = philox4x32((uint32_t)b, 1u, 0u, RNG_INIT, seed_lo, seed_hi);
+            double q[4] = {(double)normal_from(r1.x, r1.y), (double)normal_from(r1.z, r1.w),
+                           (double)normal_from(r2.x, r2.y), (double)normal_from(r2.z, r2.w)};
+            const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+            const double x = q[0] / n, y = q[1] / n, z = q[2] / n, w = q[3] / n;
+            R0[0] = (float)(1 - 2 * (y * y + z * z)); R0[1] = (float)(2 * (x * y - z * w)); R0[2] = (float)(2 * (x * z + y * w));
+            R0[3] = (float)(2 * (x * y + z * w)); R0[4] = (float)(1 - 2 * (x * x + z * z)); R0[5] = (float)(2 * (y * z - x * w));
+            R0[6] = (float)(2 * (x * z - y * w)); R0[7] = (float)(2 * (y * z + x * w)); R0[8] = (float)(1 - 2 * (x * x + y * y));
+        }
+        if (tr_inj) {
+            for (int k = 0; k < 3; ++k) draw[k] = tr_inj[b * 3 + k];
+        } else {
+            const u32x4 r3 = philox4x32((uint32_t)b, 2u, 0u, RNG_INIT, seed_lo, seed_hi);
+            const u32x4 r4 = philox4x32((uint32_t)b, 3u, 0u, RNG_INIT, seed_lo, seed_hi);
+            draw[0] = 30.0f * normal_from(r3.x, r3.y); draw[1] = 30.0f * normal_from(r3.z, r3.w);
+            draw[2] = 30.0f * normal_from(r4.x, r4.y);
+        }
+        float aa[3];
+        mat_to_aa(R0, aa);
+        for (int k = 0; k < 3; ++k) {
+            const float tr = (draw[k] - c2[k]) + c1[k];
+            sh[k] = c2[k]; sh[3 + k] = tr;
+            tr_update[b * 3 + k] = tr;
+            rot_update[b * 3 + k] = aa[k];
+        }
+        for (int k = 0; k < 9; ++k) sh[6 + k] = R0[k];
+    }
+    __syncthreads();
+    float *out = lig_cur + (size_t)b * L * 9;
+    for (int a = threadIdx.x; a < L * 3; a += blockDim.x) {
+        const float v0 = lig0[a * 3] - sh[0], v1 = lig0[a * 3 + 1] - sh[1], v2 = lig0[a * 3 + 2] - sh[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float s = 0;
+            s += v0 * sh[6 + r * 3]; s += v1 * sh[6 + r * 3 + 1]; s += v2 * sh[6 + r * 3 + 2];
+            out[a * 3 + r] = (s + sh[r]) + sh[3 + r];
+        }
+    }
+}
+
+hipError_t launch_init_pose(const float *rec_pos, const float *lig0, int B, int R, int L, const float *R0,
+                            const float *tr_draw, uint64_t seed, float *lig_cur, float *tr_update, float *rot_update,
+                            hipStream_t s)
+{
+    hipLaunchKernelGGL(k_init_pose, dim3(B), dim3(256), 0, s, rec_pos, lig0, R, L, R0, tr_draw, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), lig_cur, tr_update, rot_update);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_clash_force (inference_base.py:366-384), closed form of the reference's autograd:
+// E = -5 * sum_{d<4} (4-d)^1.5 / (0.75 d) over all backbone-atom pairs; the ligand is shifted rigidly
+// by the mean over its 3L atoms of dE/dx.
+__global__ __launch_bounds__(256) void k_clash_force(const float *__restrict__ rec_pos, int R, int L,
+                                                     float *__restrict__ lig_cur, float *__restrict__ tr_update)
+{
+    __shared__ double scratch[8];
+    __shared__ float shift[3];
+    const int b = blockIdx.x;
+    float *lig = lig_cur + (size_t)b * L * 9;
+    double g0 = 0, g1 = 0, g2 = 0;
+    for (int j = threadIdx.x; j < L * 3; j += blockDim.x) {
+        const double lx = lig[j * 3], ly = lig[j * 3 + 1], lz = lig[j * 3 + 2];
+        for (int i = 0; i < R * 3; ++i) {
+            const double dx = (double)rec_pos[i * 3] - lx, dy = (double)rec_pos[i * 3 + 1] - ly,
+                         dz = (double)rec_pos[i * 3 + 2] - lz;
+            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            if (d < 4.0 && d > 0.0) {
+                const double u = 4.0 - d;
+                const double fp = (-1.5 * sqrt(u) * d - u * sqrt(u)) / (0.75 * d * d);
+                const double dE = -5.0 * fp;
+                g0 += dE * (-dx / d); g1 += dE * (-dy / d); g2 += dE * (-dz / d);
+            }
+        }
+    }
+    g0 = block_sum_d(g0, scratch); g1 = block_sum_d(g1, scratch); g2 = block_sum_d(g2, scratch);
+    if (threadIdx.x == 0) {
+        shift[0] = (float)(g0 / (L * 3)); shift[1] = (float)(g1 / (L * 3)); shift[2] = (float)(g2 / (L * 3));
+        for (int k = 0; k < 3; ++k) tr_update[b * 3 + k] += shift[k];
+    }
+    __syncthreads();
+    for (int a = threadIdx.x; a < L * 9; a += blockDim.x) lig[a] += shift[a % 3];
+}
+
+hipError_t launch_clash_force(const float *rec_pos, int B, int R, int L, float *lig_cur, float *tr_update, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_clash_force, dim3(B), dim3(256), 0, s, rec_pos, R, L, lig_cur, tr_update);
+    return hipGetLastError();
+}
+
+}  // namespace dfm

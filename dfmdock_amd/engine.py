@@ -1,0 +1,172 @@
+"""Numpy-level wrapper over the C ABI: Model / Complex handles, batched score and sample calls."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .weights import HParams
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t=L.F32P):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def hparams_c(hp: HParams | None = None) -> L.HParamsC:
+    hp = hp or HParams()
+    return L.HParamsC(**hp.as_dict())
+
+
+def set_device(index: int = 0):
+    L.check(L.lib().dfm_set_device(int(index)), "dfm_set_device")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = L.lib().dfm_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def diffusion_coef(which: int, t: float, hp: HParams | None = None):
+    """(g, sigma) of the R^3 (which=0) or SO(3) (which=1) VE-SDE, float64 like the reference."""
+    h = hparams_c(hp)
+    g, s = C.c_double(0), C.c_double(0)
+    L.check(L.lib().dfm_diffusion_coef(C.byref(h), int(which), float(t), C.byref(g), C.byref(s)), "diffusion_coef")
+    return g.value, s.value
+
+
+class Model:
+    """Device-resident weights (dfm_model).  `blob` is the flat float32 state_dict (weights.pack_blob)."""
+
+    def __init__(self, blob, hp: HParams | None = None):
+        self.hp = hp or HParams()
+        self._hp_c = hparams_c(self.hp)
+        blob = _f32(blob).reshape(-1)
+        self._h = L.lib().dfm_model_create(_p(blob), blob.size, C.byref(self._hp_c))
+        if not self._h:
+            L.check(-1 if b"blob" in L.lib().dfm_last_error() or b"unsupported" in L.lib().dfm_last_error() else -2,
+                    "dfm_model_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().dfm_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Complex:
+    """One receptor/ligand pair resident on the GPU (dfm_complex)."""
+
+    def __init__(self, model: Model, rec_x, lig_x, rec_pos, lig_pos):
+        self.model = model
+        rec_x, lig_x = _f32(rec_x), _f32(lig_x)
+        rec_pos, lig_pos = _f32(rec_pos).reshape(-1, 9), _f32(lig_pos).reshape(-1, 9)
+        self.R, self.L = rec_x.shape[0], lig_x.shape[0]
+        if rec_x.shape[1] != model.hp.lm_embed_dim or lig_x.shape[1] != model.hp.lm_embed_dim:
+            raise ValueError("node features must be [n, lm_embed_dim]")
+        if rec_pos.shape[0] != self.R or lig_pos.shape[0] != self.L:
+            raise ValueError("positions must be [n, 3, 3] matching the features")
+        self.N = self.R + self.L
+        self._h = L.lib().dfm_complex_create(model._h, _p(rec_x), _p(lig_x), _p(rec_pos), _p(lig_pos), self.R, self.L)
+        if not self._h:
+            L.check(-2, "dfm_complex_create")
+        self.K = L.lib().dfm_complex_degree(self._h)
+        self.lig_pos0 = lig_pos.reshape(self.L, 3, 3).copy()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().dfm_complex_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def score(self, lig_pos, t, edges=None, seed=0, bf16=False, energy=True, debug=False, profile=False):
+        """B score evaluations.  lig_pos [B,L,3,3] (or [L,3,3]), t [B] (or scalar)."""
+        lig_pos = _f32(lig_pos)
+        if lig_pos.ndim == 3:
+            lig_pos = lig_pos[None]
+        B = lig_pos.shape[0]
+        t = np.broadcast_to(_f32(t).reshape(-1), (B,)).copy()
+        N, Lg, K, H = self.N, self.L, self.K, self.model.hp.node_dim
+        o = dict(tr_score=np.zeros((B, 3), np.float32), rot_score=np.zeros((B, 3), np.float32),
+                 energy=np.zeros((B,), np.float32), num_clashes=np.zeros((B,), np.int32),
+                 f=np.zeros((B, Lg, 3), np.float32))
+        out = L.ScoreOutC()
+        out.tr_score, out.rot_score = _p(o["tr_score"]), _p(o["rot_score"])
+        out.energy, out.num_clashes, out.f = _p(o["energy"]), _p(o["num_clashes"], L.I32P), _p(o["f"])
+        if debug:
+            o.update(h_last=np.zeros((B, N, H), np.float32), h_first=np.zeros((B, N, H), np.float32),
+                     edges=np.zeros((B, N, K), np.int32), edge_codes=np.zeros((B, N, K), np.uint32))
+            out.h_last, out.h_first = _p(o["h_last"]), _p(o["h_first"])
+            out.edges, out.edge_codes = _p(o["edges"], L.I32P), _p(o["edge_codes"], L.U32P)
+        e = None
+        if edges is not None:
+            e = np.ascontiguousarray(edges, dtype=np.int32)
+            if e.ndim == 2:
+                e = e[None]
+            if e.shape != (B, N, K):
+                raise ValueError(f"edges must be [B,N,K] = {(B, N, K)}, got {e.shape}")
+        flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_ENERGY if energy else 0) | (L.DFM_F_PROFILE if profile else 0)
+        rc = L.lib().dfm_score(self._h, B, _p(lig_pos), _p(t), _p(e, L.I32P), int(seed), flags, C.byref(out))
+        L.check(rc, "dfm_score")
+        if debug:
+            c = o["edge_codes"]
+            o["bins"] = np.stack([c & 63, (c >> 6) & 31, (c >> 11) & 31, (c >> 16) & 15], -1).astype(np.int8)
+            o["relpos"] = ((c >> 20) & 127).astype(np.int8)
+        return o
+
+    def sample(self, B=1, num_steps=40, eps=1e-3, tr_noise_scale=0.5, rot_noise_scale=0.5, noise_annealing=False,
+               use_clash_force=False, ode=False, seed=0, bf16=False, inject=None, trace=False, profile=False):
+        """B independent Euler-Maruyama trajectories (inference_base.py:390-468 batched)."""
+        Lg, N, K, S = self.L, self.N, self.K, int(num_steps)
+        o = dict(lig_pos=np.zeros((B, Lg, 3, 3), np.float32), rot_update=np.zeros((B, 3), np.float32),
+                 tr_update=np.zeros((B, 3), np.float32), energy=np.zeros((B,), np.float32),
+                 num_clashes=np.zeros((B,), np.int32))
+        out = L.TrajOutC()
+        out.lig_pos, out.rot_update, out.tr_update = _p(o["lig_pos"]), _p(o["rot_update"]), _p(o["tr_update"])
+        out.energy, out.num_clashes = _p(o["energy"]), _p(o["num_clashes"], L.I32P)
+        if trace:
+            o.update(trace_pose=np.zeros((B, S, Lg, 3, 3), np.float32), trace_scores=np.zeros((B, S + 1, 8), np.float32),
+                     init_pose=np.zeros((B, Lg, 3, 3), np.float32))
+            out.trace_pose, out.trace_scores, out.init_pose = _p(o["trace_pose"]), _p(o["trace_scores"]), _p(o["init_pose"])
+        inj, keep = None, []
+        if inject:
+            inj = L.InjectC()
+            shapes = {"R0": (B, 9), "tr_draw": (B, 3), "z_rot": (B, S, 3), "z_tr": (B, S, 3)}
+            for k, shp in shapes.items():
+                if inject.get(k) is not None:
+                    a = _f32(inject[k]).reshape(shp)
+                    keep.append(a)
+                    setattr(inj, k, _p(a))
+            if inject.get("edges") is not None:
+                a = np.ascontiguousarray(inject["edges"], dtype=np.int32).reshape(B, S + 1, N, K)
+                keep.append(a)
+                inj.edges = _p(a, L.I32P)
+        flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_NOISE_ANNEALING if noise_annealing else 0) | \
+                (L.DFM_F_CLASH_FORCE if use_clash_force else 0) | (L.DFM_F_ODE if ode else 0) | \
+                (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if trace else 0)
+        rc = L.lib().dfm_sample(self._h, int(B), S, float(eps), float(tr_noise_scale), float(rot_noise_scale), flags,
+                                int(seed), C.byref(inj) if inj is not None else None, C.byref(out))
+        L.check(rc, "dfm_sample")
+        return o
+
+    def profile(self):
+        p = L.ProfileC()
+        L.check(L.lib().dfm_get_profile(self._h, C.byref(p)), "dfm_get_profile")
+        return dict(edge_kernel_ms=p.edge_kernel_ms, edge_kernel_launches=p.edge_kernel_launches,
+                    edge_rows=p.edge_rows, total_ms=p.total_ms)

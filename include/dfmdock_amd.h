@@ -1,0 +1,153 @@
+/*
+ * dfmdock_amd.h - C ABI of the MI355X-native DFMDock sampling engine.
+ *
+ * This is the drop-in boundary for the ONE hot path this project accelerates
+ * (SURVEY.md section 8): the reverse-diffusion sampler over rigid-body poses and
+ * the score network it calls.  The reference has no FFI layer - the path sits
+ * behind plain Python call signatures - so each entry point below names the
+ * reference call it replaces (paths relative to the reference checkout):
+ *
+ *   dfm_model_create    <- Score_Model.load_from_checkpoint / Score_Net.__init__
+ *                          (src/inference_base.py:611-616, src/models/score_net_mlsb.py:249-341)
+ *   dfm_complex_create  <- get_batch_from_inputs + get_position_matrix
+ *                          (src/inference_base.py:192-253)
+ *   dfm_score           <- Score_Model.forward(batch)  (src/models/score_model_mlsb.py:61-63 ->
+ *                          src/models/score_net_mlsb.py:343-425)
+ *   dfm_sample          <- Euler_Maruyama_sampler(model, batch, ...) (src/inference_base.py:390-468),
+ *                          batched over B independent trajectories
+ *   dfm_diffusion_coef  <- R3Diffuser.diffusion_coef / SO3Diffuser.diffusion_coef
+ *                          (src/utils/r3_diffuser.py:23-24, src/utils/so3_diffuser.py:219-227)
+ *
+ * Conventions: plain pointers and sizes, caller owns every host buffer, the
+ * library owns device memory behind opaque handles, no global state besides the
+ * thread-local error string.  All entry points return 0 on success and a
+ * negative dfm_status otherwise (the reference raises Python exceptions:
+ * ValueError for t outside [0,1] -> DFM_E_INVALID).  Handles must not be shared
+ * between host threads without external locking; one process (or thread) per GPU.
+ * Everything computes on the GPU: there is no CPU fallback in this library.
+ */
+#ifndef DFMDOCK_AMD_H
+#define DFMDOCK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dfm_model dfm_model;
+typedef struct dfm_complex dfm_complex;
+
+typedef enum {
+    DFM_OK = 0,
+    DFM_E_INVALID = -1,   /* bad argument (shape, range, NULL)          */
+    DFM_E_HIP = -2,       /* HIP runtime error (see dfm_last_error)      */
+    DFM_E_OOM = -3,       /* device or host allocation failed            */
+    DFM_E_NODEVICE = -4   /* no usable gfx950 device                     */
+} dfm_status;
+
+/* configs/model/score_model_mlsb.yaml:3-27 (+ score_net_mlsb.py:33,:85 constants) */
+typedef struct {
+    int lm_embed_dim;          /* 1301 = 1280 (ESM-2) + 21 (one-hot)   */
+    int positional_embed_dim;  /* 66                                    */
+    int spatial_embed_dim;     /* 100 = 40 + 24 + 24 + 12               */
+    int node_dim;              /* 256 (only value supported by kernels) */
+    int edge_dim;              /* 128                                   */
+    int inner_dim;             /* 128                                   */
+    int depth;                 /* 6                                     */
+    int knn;                   /* 20                                    */
+    int n_sample;              /* 40                                    */
+    float cut_off;             /* 20.0  energy mask                     */
+    float mask_dist;           /* 22.0  angle-feature mask              */
+    double r3_min_sigma, r3_max_sigma;    /* 0.1, 30.0                  */
+    double so3_min_sigma, so3_max_sigma;  /* 0.1, 1.5 (logarithmic)     */
+} dfm_hparams;
+
+/* flags for dfm_score / dfm_sample */
+enum {
+    DFM_F_BF16 = 1u << 0,            /* per-edge contractions on bf16 MFMA (default: exact fp32) */
+    DFM_F_ENERGY = 1u << 1,          /* dfm_score: also evaluate the energy head                 */
+    DFM_F_NOISE_ANNEALING = 1u << 2, /* inference_base.py:428-430                                */
+    DFM_F_CLASH_FORCE = 1u << 3,     /* inference_base.py:458-461                                */
+    DFM_F_ODE = 1u << 4,             /* so3_diffuser.py:367-368                                  */
+    DFM_F_PROFILE = 1u << 5,         /* time the dominant kernel with HIP events (dfm_get_profile) */
+    DFM_F_STEP_ENERGY = 1u << 6      /* dfm_sample: evaluate the energy head on every step (traces) */
+};
+
+/* Output of dfm_score.  Required: tr_score, rot_score.  Any other pointer may be NULL. */
+typedef struct {
+    float *tr_score;      /* [B,3]                                                      */
+    float *rot_score;     /* [B,3]                                                      */
+    float *energy;        /* [B]      (needs DFM_F_ENERGY)                              */
+    int32_t *num_clashes; /* [B]      (needs DFM_F_ENERGY)                              */
+    float *f;             /* [B,L,3]  per-ligand-residue force                          */
+    /* debug / parity taps */
+    float *h_last;        /* [B,N,H]  node features after the last layer                */
+    float *h_first;       /* [B,N,H]  node features after the first layer               */
+    int32_t *edges;       /* [B,N,K]  edge list actually used                           */
+    uint32_t *edge_codes; /* [B,N,K]  packed feature bins: d | omega<<6 | theta<<11 | phi<<16 | relpos<<20 */
+} dfm_score_out;
+
+/* Injected randomness for parity tests (every pointer may be NULL = draw natively with Philox) */
+typedef struct {
+    const float *R0;       /* [B,9]  initial rotation matrices (row-major)              */
+    const float *tr_draw;  /* [B,3]  the N(0,30^2) draws of randomize_pose               */
+    const float *z_rot;    /* [B,steps,3] N(0,1) draws of the SO(3) update                */
+    const float *z_tr;     /* [B,steps,3] N(0,1) draws of the R^3 update                  */
+    const int32_t *edges;  /* [B,steps+1,N,K] edge lists, one per score evaluation       */
+} dfm_inject;
+
+typedef struct {
+    float *lig_pos;       /* [B,L,9]  final ligand backbone (N,CA,C)                     */
+    float *rot_update;    /* [B,3]    accumulated rotation, axis-angle                   */
+    float *tr_update;     /* [B,3]    accumulated translation                            */
+    float *energy;        /* [B]      energy of the final pose                           */
+    int32_t *num_clashes; /* [B]                                                         */
+    /* optional traces (NULL to skip) */
+    float *trace_pose;    /* [B,steps,L,9]  pose after every step                        */
+    float *trace_scores;  /* [B,steps+1,8]  tr_score, rot_score, energy, num_clashes per evaluation */
+    float *init_pose;     /* [B,L,9]        pose after randomize_pose                    */
+} dfm_traj_out;
+
+typedef struct {
+    double edge_kernel_ms;    /* summed HIP-event time of the per-edge message kernel     */
+    int64_t edge_kernel_launches;
+    int64_t edge_rows;        /* edge rows (B*N*K) processed by those launches           */
+    double total_ms;          /* HIP-event time of the whole last dfm_sample / dfm_score  */
+} dfm_profile;
+
+const char *dfm_last_error(void);
+int dfm_device_count(int *count);
+int dfm_set_device(int device);
+/* fills hp with the reference configuration */
+void dfm_default_hparams(dfm_hparams *hp);
+/* number of floats the blob must hold for hp (state_dict order, see dfmdock_amd/weights.py) */
+int64_t dfm_param_count(const dfm_hparams *hp);
+
+dfm_model *dfm_model_create(const float *blob, size_t n_floats, const dfm_hparams *hp);
+void dfm_model_destroy(dfm_model *m);
+
+dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x /*[R,lm]*/, const float *lig_x /*[L,lm]*/,
+                                const float *rec_pos /*[R,9]*/, const float *lig_pos /*[L,9]*/, int R, int L);
+void dfm_complex_destroy(dfm_complex *cx);
+/* edges per node for this complex: min(N,20) + min(40, N-20) */
+int dfm_complex_degree(const dfm_complex *cx);
+
+/* B score evaluations of poses lig_pos[B,L,9] at times t[B] */
+int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const float *t, const int32_t *edges_or_null,
+              uint64_t seed, uint32_t flags, dfm_score_out *out);
+
+/* B independent trajectories of the Euler-Maruyama sampler */
+int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, float tr_noise_scale, float rot_noise_scale,
+               uint32_t flags, uint64_t seed, const dfm_inject *inj_or_null, dfm_traj_out *out);
+
+int dfm_get_profile(const dfm_complex *cx, dfm_profile *p);
+
+/* which: 0 = R^3 (VE), 1 = SO(3) (logarithmic).  Returns DFM_E_INVALID for t outside [0,1] on SO(3). */
+int dfm_diffusion_coef(const dfm_hparams *hp, int which, double t, double *g_out, double *sigma_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFMDOCK_AMD_H */

@@ -1,0 +1,84 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol include/*.h declares,
+host-only entry points agree with the reference's known answers, and the product fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "dfmdock_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfm_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dfmdock_amd import _lib
+    lib = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/dfmdock_amd.h but not exported"
+    assert sorted(_lib.EXPORTS) == syms
+
+
+def test_param_count_and_default_hparams():
+    from dfmdock_amd import _lib, engine
+    from dfmdock_amd.weights import HParams, n_params
+    hp = _lib.HParamsC()
+    _lib.lib().dfm_default_hparams(C.byref(hp))
+    ref = HParams()
+    for k, v in ref.as_dict().items():
+        assert getattr(hp, k) == pytest.approx(v), k
+    assert _lib.lib().dfm_param_count(C.byref(engine.hparams_c())) == n_params() == 3566919
+
+
+def test_diffusion_coefficients_host_entry_point():
+    from dfmdock_amd import engine
+    k = load_golden("scalar_kats.npz")
+    for i, t in enumerate(k["ts"]):
+        g3, s3 = engine.diffusion_coef(0, t)
+        gso, sso = engine.diffusion_coef(1, t)
+        assert g3 == pytest.approx(k["g_r3"][i], rel=1e-13) and s3 == pytest.approx(k["sigma_r3"][i], rel=1e-13)
+        assert gso == pytest.approx(k["g_so3"][i], rel=1e-13) and sso == pytest.approx(k["sigma_so3"][i], rel=1e-13)
+    with pytest.raises(ValueError):       # so3_diffuser.py:212-213 raises ValueError
+        engine.diffusion_coef(1, 1.5)
+    with pytest.raises(ValueError):
+        engine.diffusion_coef(1, -0.1)
+
+
+def test_weights_blob_roundtrip():
+    from dfmdock_amd.weights import make_random_weights, pack_blob, param_specs, unpack_blob
+    w = make_random_weights(3)
+    blob = pack_blob(w)
+    back = unpack_blob(blob)
+    assert list(back) == [n for n, _ in param_specs()]
+    for k in w:
+        np.testing.assert_array_equal(w[k], back[k])
+    pref = {"net." + k: v for k, v in w.items()}       # Lightning checkpoints prefix keys with net.
+    np.testing.assert_array_equal(pack_blob(pref), blob)
+    with pytest.raises(KeyError):
+        pack_blob({k: v for k, v in list(w.items())[:-1]})
+
+
+def test_no_gpu_fails_loudly():
+    """Without a device the product raises; it never falls back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dfmdock_amd import _lib, engine
+    with pytest.raises(_lib.DfmError):
+        engine.set_device(0)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "dfmdock_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("# oracle", ""), f"{f} references the oracle"
