@@ -536,6 +536,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     const size_t N = cx->N, L = cx->L, K = cx->K;
     cx->prof = dfm_profile{0, 0, 0, 0};
     cx->ev_used = 0;
+    cx->fwd_counter = 0;   // RNG streams are a pure function of (seed, trajectory, evaluation index)
     HIPCHK(hipMemcpyAsync(W.lig_cur, lig_pos, (size_t)B * L * 9 * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(W.t_dev, t, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
     int32_t *edges_dev = nullptr;
@@ -596,6 +597,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     const size_t N = cx->N, L = cx->L, K = cx->K, S = num_steps;
     cx->prof = dfm_profile{0, 0, 0, 0};
     cx->ev_used = 0;
+    cx->fwd_counter = 0;   // evaluation i of this call draws its graph from Philox stream i
 
     // time grid: torch.linspace(1, eps, num_steps) in float32; dt = t[0] - t[1]   (inference_base.py:404-405)
     std::vector<float> ts(S);
