@@ -48,7 +48,8 @@ class InjectC(C.Structure):
 
 class TrajOutC(C.Structure):
     _fields_ = [("lig_pos", F32P), ("rot_update", F32P), ("tr_update", F32P), ("energy", F32P),
-                ("num_clashes", I32P), ("trace_pose", F32P), ("trace_scores", F32P), ("init_pose", F32P)]
+                ("num_clashes", I32P), ("final_scores", F32P), ("trace_pose", F32P), ("trace_scores", F32P),
+                ("init_pose", F32P)]
 
 
 class ProfileC(C.Structure):

@@ -690,6 +690,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     for (int b = 0; b < B; ++b) {
         if (out->energy) out->energy[b] = sc[b * 8 + 6];
         if (out->num_clashes) out->num_clashes[b] = (int32_t)sc[b * 8 + 7];
+        if (out->final_scores) std::memcpy(out->final_scores + (size_t)b * 6, &sc[(size_t)b * 8], 6 * sizeof(float));
     }
     if (o.profile) return finish_profile(cx);
     return DFM_OK;

@@ -136,10 +136,11 @@ class Complex:
         Lg, N, K, S = self.L, self.N, self.K, int(num_steps)
         o = dict(lig_pos=np.zeros((B, Lg, 3, 3), np.float32), rot_update=np.zeros((B, 3), np.float32),
                  tr_update=np.zeros((B, 3), np.float32), energy=np.zeros((B,), np.float32),
-                 num_clashes=np.zeros((B,), np.int32))
+                 num_clashes=np.zeros((B,), np.int32), final_scores=np.zeros((B, 6), np.float32))
         out = L.TrajOutC()
         out.lig_pos, out.rot_update, out.tr_update = _p(o["lig_pos"]), _p(o["rot_update"]), _p(o["tr_update"])
         out.energy, out.num_clashes = _p(o["energy"]), _p(o["num_clashes"], L.I32P)
+        out.final_scores = _p(o["final_scores"])
         if trace:
             o.update(trace_pose=np.zeros((B, S, Lg, 3, 3), np.float32), trace_scores=np.zeros((B, S + 1, 8), np.float32),
                      init_pose=np.zeros((B, Lg, 3, 3), np.float32))

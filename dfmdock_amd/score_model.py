@@ -1,0 +1,177 @@
+"""Host-side mirror of the reference's Python interface for the sampling path.
+
+Same names, argument meaning, dict keys, shapes and error behaviour as the reference, implemented
+over the C ABI (include/dfmdock_amd.h) - nothing here computes on the CPU except scalar schedule
+math.  PyTorch is only the tensor container the reference's callers expect.
+
+  Score_Model                 <- src/models/score_model_mlsb.py:22-63 (forward, r3_diffuser, so3_diffuser)
+  R3Diffuser / SO3Diffuser    <- src/utils/r3_diffuser.py:15-55, src/utils/so3_diffuser.py:140-369
+                                 (sigma, diffusion_coef, torch_reverse only: the IGSO(3) tables are training-only)
+  Euler_Maruyama_sampler      <- src/inference_base.py:390-468
+  sample_trajectories         <- the `for i in range(num_samples)` loops of src/inference_base.py:483,:644,
+                                 batched on the GPU
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from . import engine
+from .weights import HParams, pack_blob
+
+
+def _np(x):
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+class R3Diffuser:
+    """VE-SDE on R^3 (src/utils/r3_diffuser.py)."""
+
+    def __init__(self, hp: HParams):
+        self._hp = hp
+        self.min_sigma, self.max_sigma = hp.r3_min_sigma, hp.r3_max_sigma
+
+    def sigma(self, t):
+        return engine.diffusion_coef(0, float(t), self._hp)[1]
+
+    def diffusion_coef(self, t):
+        return engine.diffusion_coef(0, float(t), self._hp)[0]
+
+    def torch_reverse(self, score_t, dt, t, noise_scale=1.0, ode=False):
+        return _torch_reverse(self.diffusion_coef, score_t, dt, t, noise_scale, ode)
+
+
+class SO3Diffuser:
+    """VE-SDE on SO(3), logarithmic schedule (src/utils/so3_diffuser.py:210-227,:344-369)."""
+
+    def __init__(self, hp: HParams):
+        self._hp = hp
+        self.min_sigma, self.max_sigma, self.schedule = hp.so3_min_sigma, hp.so3_max_sigma, "logarithmic"
+
+    def sigma(self, t):
+        return engine.diffusion_coef(1, float(t), self._hp)[1]     # ValueError outside [0, 1]
+
+    def diffusion_coef(self, t):
+        return engine.diffusion_coef(1, float(t), self._hp)[0]
+
+    def torch_reverse(self, score_t, dt, t, noise_scale=1.0, ode=False):
+        return _torch_reverse(self.diffusion_coef, score_t, dt, t, noise_scale, ode)
+
+
+def _torch_reverse(coef, score_t, dt, t, noise_scale, ode):
+    """One reverse-SDE increment (r3_diffuser.py:40-55 == so3_diffuser.py:344-369), float32 tensor maths."""
+    import torch
+    if not np.isscalar(t):
+        raise ValueError(f"{t} must be a scalar.")
+    g_t = coef(t)
+    dt = torch.as_tensor(dt, dtype=torch.float32)
+    if not ode:
+        z = noise_scale * torch.randn(1, 3, device=score_t.device)
+        perturb = (g_t ** 2) * score_t * dt + g_t * torch.sqrt(dt) * z
+    else:
+        perturb = 0.5 * (g_t ** 2) * score_t * dt
+    return perturb.float()
+
+
+class Score_Model:
+    """Drop-in for the reference's Score_Model at inference: `model(batch) -> dict`.
+
+    batch: {rec_x [R,1301], lig_x [L,1301], rec_pos [R,3,3], lig_pos [L,3,3], t [1]} (position_matrix is
+    accepted and ignored: relpos is derived from (R, L) on the GPU).  Output keys / shapes follow
+    score_net_mlsb.py:413-425: tr_score [1,3], rot_score [1,3], energy [], f [L,3], num_clashes [] (int64).
+    `ires` (unused by the sampler) is not evaluated.
+    """
+
+    def __init__(self, weights, hp: HParams | None = None, precision: str = "bf16", device_index: int = 0, seed: int = 0):
+        self.hp = hp or HParams()
+        blob = weights if isinstance(weights, np.ndarray) and weights.ndim == 1 else pack_blob(weights, self.hp)
+        engine.set_device(device_index)
+        self.model = engine.Model(blob, self.hp)
+        self.precision = precision
+        self.r3_diffuser = R3Diffuser(self.hp)
+        self.so3_diffuser = SO3Diffuser(self.hp)
+        self._cx = None
+        self._cx_key = None
+        self._calls = 0
+        self.seed = seed
+
+    # reference spelling ---------------------------------------------------------------------------
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location=None, **kw):
+        from .weights import load_lightning_checkpoint
+        sd, hp = load_lightning_checkpoint(path)
+        return cls(sd, hp=hp, **kw)
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    # ----------------------------------------------------------------------------------------------
+    def complex_for(self, batch) -> engine.Complex:
+        rec_x, lig_x, rec_pos = batch["rec_x"], batch["lig_x"], _np(batch["rec_pos"])
+        key = (tuple(rec_x.shape), tuple(lig_x.shape), id(rec_x), id(lig_x), hashlib.sha1(rec_pos.tobytes()).hexdigest())
+        if key != self._cx_key:
+            if self._cx is not None:
+                self._cx.close()
+            self._cx = engine.Complex(self.model, _np(rec_x), _np(lig_x), rec_pos, _np(batch["lig_pos"]))
+            self._cx_key = key
+        return self._cx
+
+    def forward(self, batch):
+        import torch
+        cx = self.complex_for(batch)
+        t = _np(batch["t"]).reshape(-1)
+        if t.size != 1:
+            raise ValueError("batch['t'] must hold one time value (the reference runs batch_size=1)")
+        self._calls += 1
+        r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, bf16=self.precision == "bf16", energy=True)
+        return {"tr_score": torch.from_numpy(r["tr_score"]), "rot_score": torch.from_numpy(r["rot_score"]),
+                "energy": torch.tensor(float(r["energy"][0]), dtype=torch.float32), "f": torch.from_numpy(r["f"][0]),
+                "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64)}
+
+    __call__ = forward
+
+
+def Euler_Maruyama_sampler(model: Score_Model, batch, num_steps=40, device="cpu", batch_size=1, eps=1e-3,
+                           use_clash_force=False, noise_annealing=False, tr_noise_scale=0.5, rot_noise_scale=0.5,
+                           seed=None):
+    """One trajectory, reference signature and return tuple (inference_base.py:390-468):
+    (rec_pos, lig_pos [L,3,3], rot_update [1,3], tr_update [1,3], output dict).  The whole 40-step loop runs
+    inside one dfm_sample call on the GPU."""
+    import torch
+    if batch_size != 1:
+        raise ValueError("batch_size must be 1 (as in the reference); use sample_trajectories for batches")
+    cx = model.complex_for(batch)
+    model._calls += 1
+    r = cx.sample(B=1, num_steps=num_steps, eps=eps, tr_noise_scale=tr_noise_scale, rot_noise_scale=rot_noise_scale,
+                  noise_annealing=noise_annealing, use_clash_force=use_clash_force,
+                  seed=(model.seed + model._calls) if seed is None else seed, bf16=model.precision == "bf16")
+    output = {"energy": torch.tensor(float(r["energy"][0])), "num_clashes": torch.tensor(int(r["num_clashes"][0])),
+              "tr_score": torch.from_numpy(r["final_scores"][:, 0:3].copy()),
+              "rot_score": torch.from_numpy(r["final_scores"][:, 3:6].copy())}
+    rec_pos = batch["rec_pos"].clone() if hasattr(batch["rec_pos"], "clone") else torch.from_numpy(_np(batch["rec_pos"]))
+    return (rec_pos, torch.from_numpy(r["lig_pos"][0]), torch.from_numpy(r["rot_update"]),
+            torch.from_numpy(r["tr_update"]), output)
+
+
+def sample_trajectories(model: Score_Model, batch, num_samples=120, num_steps=40, eps=1e-3, use_clash_force=False,
+                        noise_annealing=False, tr_noise_scale=0.5, rot_noise_scale=0.5, seed=0, max_batch=256):
+    """`num_samples` independent trajectories (the reference loops Euler_Maruyama_sampler sequentially,
+    inference_base.py:644-657); returns numpy arrays sorted as drawn, plus the arg-min-energy index."""
+    cx = model.complex_for(batch)
+    outs = []
+    done = 0
+    while done < num_samples:
+        b = min(max_batch, num_samples - done)
+        outs.append(cx.sample(B=b, num_steps=num_steps, eps=eps, tr_noise_scale=tr_noise_scale,
+                              rot_noise_scale=rot_noise_scale, noise_annealing=noise_annealing,
+                              use_clash_force=use_clash_force, seed=seed + done, bf16=model.precision == "bf16"))
+        done += b
+    res = {k: np.concatenate([o[k] for o in outs], 0) for k in ("lig_pos", "rot_update", "tr_update", "energy", "num_clashes")}
+    res["best"] = int(np.argmin(res["energy"]))     # `if outputs["energy"] < min_energy` keeps the first minimum
+    return res

@@ -170,3 +170,81 @@ def unpack_blob(blob: np.ndarray, hp: HParams = HParams()):
     if off != blob.size:
         raise ValueError(f"blob has {blob.size} floats, expected {off}")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Lightning checkpoint reader (reference: Score_Model.load_from_checkpoint, src/inference_base.py:611-614).
+# A Lightning ckpt is a torch-pickled dict with `state_dict` (keys `net.<name>`) and `hyper_parameters`
+# holding omegaconf DictConfig objects.  Neither pytorch_lightning nor omegaconf is needed to read it:
+# unknown classes are unpickled into attribute bags.
+class _Bag:
+    def __init__(self, *a, **k):
+        self._args, self._kwargs = a, k
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__["_state"] = state
+
+    def __call__(self, *a, **k):
+        return self
+
+
+def _stub_pickle_module():
+    import pickle
+    import types
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            root = module.split(".")[0]
+            if root in ("torch", "numpy", "collections", "builtins", "_codecs", "copyreg"):
+                return super().find_class(module, name)
+            return type(name, (_Bag,), {"__module__": module})
+
+    mod = types.ModuleType("dfm_stub_pickle")
+    mod.Unpickler = Unpickler
+    mod.load = lambda f, **kw: Unpickler(f, **kw).load()
+    mod.__name__ = "pickle"
+    for k in ("dump", "dumps", "loads", "HIGHEST_PROTOCOL", "PickleError", "UnpicklingError", "Pickler"):
+        setattr(mod, k, getattr(pickle, k))
+    return mod
+
+
+def _cfg_get(node, key, default=None):
+    """Read `key` from a dict, an attribute bag or an unpickled omegaconf node."""
+    if node is None:
+        return default
+    if isinstance(node, dict):
+        return node.get(key, default)
+    d = getattr(node, "__dict__", {})
+    for holder in (d, d.get("_content", None), d.get("_state", None)):
+        if isinstance(holder, dict) and key in holder:
+            v = holder[key]
+            vd = getattr(v, "__dict__", {})
+            return vd.get("_val", v) if "_val" in vd else v
+    return default
+
+
+def load_lightning_checkpoint(path):
+    """-> (state_dict name->np.float32 array without the `net.` prefix, HParams)."""
+    import torch
+    ck = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_stub_pickle_module())
+    sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
+    out = OrderedDict()
+    for k, v in sd.items():
+        k = k[4:] if k.startswith("net.") else k
+        if hasattr(v, "detach"):
+            out[k] = v.detach().cpu().float().numpy()
+    hp = HParams()
+    hyper = ck.get("hyper_parameters") if isinstance(ck, dict) else None
+    model_cfg = _cfg_get(hyper, "model")
+    if model_cfg is not None:
+        kw = {}
+        for f in ("lm_embed_dim", "positional_embed_dim", "spatial_embed_dim", "node_dim", "edge_dim", "inner_dim", "depth",
+                  "cut_off"):
+            v = _cfg_get(model_cfg, f)
+            if isinstance(v, (int, float)):
+                kw[f] = type(getattr(hp, f))(v)
+        hp = HParams(**{**hp.as_dict(), **kw})
+    return out, hp

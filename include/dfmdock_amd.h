@@ -104,6 +104,7 @@ typedef struct {
     float *tr_update;     /* [B,3]    accumulated translation                            */
     float *energy;        /* [B]      energy of the final pose                           */
     int32_t *num_clashes; /* [B]                                                         */
+    float *final_scores;  /* [B,6]    tr_score, rot_score of the final evaluation (may be NULL) */
     /* optional traces (NULL to skip) */
     float *trace_pose;    /* [B,steps,L,9]  pose after every step                        */
     float *trace_scores;  /* [B,steps+1,8]  tr_score, rot_score, energy, num_clashes per evaluation */

@@ -243,3 +243,43 @@ def test_invalid_arguments(model):
         gx.score(cx["lig_pos"], 0.5, edges=np.zeros((1, 3, 3), np.int32))
     with pytest.raises(ValueError):
         engine.Model(np.zeros(10, np.float32))
+
+
+def test_reference_shaped_python_api(blob):
+    """The host mirror keeps the reference's call shapes: model(batch) -> dict, the sampler's 5-tuple,
+    the diffusers' torch_reverse and their ValueError behaviour."""
+    import torch
+    from dfmdock_amd.score_model import Euler_Maruyama_sampler, Score_Model, sample_trajectories
+    g = load_golden("fwd_7CEI_p2.npz")
+    cx = complex_for("7CEI")
+    m = Score_Model(blob, precision="fp32")
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in cx.items()}
+    batch["lig_pos"] = torch.from_numpy(g["lig_pos"])
+    batch["t"] = torch.tensor([float(g["t"])])
+    out = m(batch)
+    assert out["tr_score"].shape == (1, 3) and out["rot_score"].shape == (1, 3) and out["f"].shape == (127, 3)
+    assert out["energy"].dim() == 0 and out["num_clashes"].dtype == torch.int64
+    # the graph is re-drawn natively, so only the model's own resampling spread separates us from the golden run
+    assert rel_inf(out["tr_score"].numpy(), g["tr_score"]) < 0.25
+    assert abs(float(out["energy"]) - float(g["energy"])) < 0.15 * abs(float(g["energy"])) + 0.05
+    assert int(out["num_clashes"]) == int(g["num_clashes"])
+    rec_pos, lig_pos, rot_update, tr_update, output = Euler_Maruyama_sampler(m, batch, num_steps=6, device="cuda")
+    assert lig_pos.shape == (127, 3, 3) and rot_update.shape == (1, 3) and tr_update.shape == (1, 3)
+    assert torch.equal(rec_pos, batch["rec_pos"]) and {"energy", "num_clashes", "tr_score", "rot_score"} <= set(output)
+    # rigid-body consistency: final pose == original ligand moved by (rot_update, tr_update) about its CA centroid
+    from oracle import oracle as ora
+    moved = ora.modify_coords(cx["lig_pos"], rot_update.numpy(), tr_update.numpy())
+    assert np.abs(moved - lig_pos.numpy()).max() < 2e-3
+    dt = torch.tensor(0.025615394115447998)
+    s = torch.tensor([[0.25, -0.5, 0.125]])
+    k = load_golden("scalar_kats.npz")
+    np.testing.assert_allclose(m.r3_diffuser.torch_reverse(score_t=s, dt=dt, t=1.0, noise_scale=0.0).numpy(), k["rev_r3"][0],
+                               rtol=1e-6)
+    np.testing.assert_allclose(m.so3_diffuser.torch_reverse(score_t=s, dt=dt, t=0.001, noise_scale=0.0).numpy(),
+                               k["rev_so3"][-1], rtol=1e-6)
+    with pytest.raises(ValueError):
+        m.so3_diffuser.torch_reverse(score_t=s, dt=dt, t=np.array([0.5, 0.6]))
+    with pytest.raises(ValueError):
+        m.so3_diffuser.sigma(1.2)
+    res = sample_trajectories(m, batch, num_samples=10, num_steps=4, max_batch=4)
+    assert res["lig_pos"].shape == (10, 127, 3, 3) and res["energy"][res["best"]] == res["energy"].min()
