@@ -212,6 +212,14 @@ static std::vector<uint16_t> pack_frags(const float *W /*[256 out][256 in]*/)
                 }
     return f;
 }
+static void split_bf16(const float *W, size_t n, std::vector<uint16_t> &hi, std::vector<uint16_t> &lo)
+{
+    hi.resize(n); lo.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        hi[i] = f2bf(W[i]);
+        lo[i] = f2bf(W[i] - bf2f(hi[i]));
+    }
+}
 static std::vector<float> transpose256(const float *W)
 {
     std::vector<float> t((size_t)H * H);
@@ -255,8 +263,8 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
             w_r[c] = Lw.e1_w[(size_t)c * Kin1 + 2 * H];
         }
         // T[idx][c] = sum_k We[c][k] * SP[k][idx]  (one_hot @ spatial/positional_embed^T then We: a row gather)
+        std::vector<double> Td((size_t)NTAB * H);
         std::vector<float> T((size_t)NTAB * H);
-        std::vector<uint16_t> Tb((size_t)NTAB * H);
         for (int idx = 0; idx < NTAB; ++idx)
             for (int c = 0; c < H; ++c) {
                 double s = 0;
@@ -265,17 +273,33 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
                                                : w.positional_embed[(size_t)k * 66 + (idx - 100)];
                     s += (double)Lw.e1_w[(size_t)c * Kin1 + 2 * H + 1 + k] * sp;
                 }
+                Td[(size_t)idx * H + c] = s;
                 T[(size_t)idx * H + c] = (float)s;
-                Tb[(size_t)idx * H + c] = f2bf((float)s);
             }
+        std::vector<uint16_t> T2b((size_t)NTAB2 * H);
+        for (int c = 0; c < H; ++c) {
+            for (int om = 0; om < 24; ++om)
+                for (int th = 0; th < 24; ++th)
+                    T2b[(size_t)(om * 24 + th) * H + c] = f2h((float)(Td[(size_t)(40 + om) * H + c] + Td[(size_t)(64 + th) * H + c]));
+            for (int ph = 0; ph < 12; ++ph)
+                for (int d = 0; d < 40; ++d)
+                    T2b[(size_t)(576 + ph * 40 + d) * H + c] = f2h((float)(Td[(size_t)(88 + ph) * H + c] + Td[(size_t)d * H + c]));
+            for (int rp = 0; rp < 66; ++rp) T2b[(size_t)(1056 + rp) * H + c] = f2h((float)Td[(size_t)(100 + rp) * H + c]);
+        }
         up(&D.Wab, Wab.data(), Wab.size()); up(&D.bias_ab, bias_ab.data(), bias_ab.size());
-        up(&D.w_r, w_r.data(), w_r.size()); up(&D.T, T.data(), T.size()); up16(&D.Tb, Tb);
+        up(&D.w_r, w_r.data(), w_r.size()); up(&D.T, T.data(), T.size()); up16(&D.T2b, T2b);
         const std::vector<float> W2t = transpose256(Lw.e2_w);
         up(&D.W2t, W2t.data(), W2t.size()); up16(&D.W2f, pack_frags(Lw.e2_w));
         up(&D.b2, Lw.e2_b, H); up(&D.att_w, Lw.att_w, H); D.att_b = Lw.att_b[0];
         up(&D.W3, Lw.n1_w, (size_t)H * 2 * H); up(&D.b3, Lw.n1_b, H);
         up(&D.gn_w, Lw.gn_w, H); up(&D.gn_b, Lw.gn_b, H); up(&D.gn_ms, Lw.gn_ms, H);
         up(&D.W4, Lw.n2_w, (size_t)H * H); up(&D.b4, Lw.n2_b, H);
+        {
+            std::vector<uint16_t> hi, lo;
+            split_bf16(Wab.data(), Wab.size(), hi, lo); up16(&D.Wab_hi, hi); up16(&D.Wab_lo, lo);
+            split_bf16(Lw.n1_w, (size_t)H * 2 * H, hi, lo); up16(&D.W3_hi, hi); up16(&D.W3_lo, lo);
+            split_bf16(Lw.n2_w, (size_t)H * H, hi, lo); up16(&D.W4_hi, hi); up16(&D.W4_lo, lo);
+        }
         if (Lw.c1_w) {
             const std::vector<float> Wc1t = transpose256(Lw.c1_w);
             up(&D.Wc1t, Wc1t.data(), Wc1t.size()); up16(&D.Wc1f, pack_frags(Lw.c1_w));
@@ -460,13 +484,13 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         std::memset(&g, 0, sizeof(g));
         g.A0 = h; g.A1 = W.agg; g.lda = H; g.K = 2 * H; g.pro = 1; g.W = Lw.W3; g.ldw = 2 * H; g.bias = Lw.b3;
         g.M = M; g.Nout = H; g.C = W.u; g.ldc = H;
-        HIPCHK(launch_gemm_f32(g, s));
+        if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W3_hi, Lw.W3_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         HIPCHK(launch_gn_stats(W.u, B, N, Lw.gn_ms, W.gn_shift, W.gn_den, s));
         std::memset(&g, 0, sizeof(g));
         g.A0 = W.u; g.lda = H; g.K = H; g.pro = 2; g.gn_shift = W.gn_shift; g.gn_den = W.gn_den; g.gn_w = Lw.gn_w;
         g.gn_b = Lw.gn_b; g.rows_per_graph = N; g.W = Lw.W4; g.ldw = H; g.bias = Lw.b4; g.M = M; g.Nout = H;
         g.epi = 1; g.R = h; g.C = hn; g.ldc = H;
-        HIPCHK(launch_gemm_f32(g, s));
+        if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W4_hi, Lw.W4_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         { float *tmp = h; h = hn; hn = tmp; }
         if (l == 0 && o.h_first_out)
             HIPCHK(hipMemcpyAsync(o.h_first_out, h, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -475,7 +499,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             std::memset(&g, 0, sizeof(g));
             g.A0 = h; g.lda = H; g.K = H; g.W = Ln.Wab; g.ldw = H; g.bias = Ln.bias_ab; g.M = M; g.Nout = 2 * H;
             g.epi = 2; g.C = W.A; g.ldc = H; g.C2 = W.Bm; g.C2b = W.Bmb;
-            HIPCHK(launch_gemm_f32(g, s));
+            if (o.bf16) HIPCHK(launch_gemm_split(g, Ln.Wab_hi, Ln.Wab_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         }
     }
     if (h != W.h) {   // keep the final node features in W.h (depth odd)

@@ -46,6 +46,31 @@ __host__ __device__ inline float bf2f(uint16_t b)
     v.u = (uint32_t)b << 16;
     return v.f;
 }
+// float -> IEEE half (round to nearest even, saturating to +-65504: gathered operands must stay finite)
+__host__ __device__ inline uint16_t f2h(float f)
+{
+    union { float f; uint32_t u; } v;
+    v.f = f;
+    const uint32_t sign = (v.u >> 16) & 0x8000u;
+    uint32_t a = v.u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);          // NaN
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7bffu);         // >= 65520 rounds past max: saturate at 65504
+    if (a < 0x33000001u) return (uint16_t)sign;                      // < 2^-25: zero
+    if (a < 0x38800000u) {                                           // subnormal half
+        const uint32_t shift = 126u - (a >> 23);                     // 14..24
+        uint32_t m = (a & 0x7fffffu) | 0x800000u;
+        const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        m >>= shift;
+        if (rem > halfway || (rem == halfway && (m & 1u))) m += 1u;
+        return (uint16_t)(sign | m);
+    }
+    a += 0xc8000000u;                                                // rebias exponent (127 -> 15)
+    const uint32_t rem = a & 0x1fffu;
+    a >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (a & 1u))) a += 1u;
+    return (uint16_t)(sign | a);
+}
+
 __device__ inline float bflo(uint32_t packed) { return __uint_as_float(packed << 16); }
 __device__ inline float bfhi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
 __device__ inline uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }

@@ -22,16 +22,21 @@ __host__ __device__ inline uint32_t pack_code(int d, int om, int th, int ph, int
     return (uint32_t)d | ((uint32_t)om << 6) | ((uint32_t)th << 11) | ((uint32_t)ph << 16) | ((uint32_t)rp << 20);
 }
 
-// channel handled by (k-step kk, lane-half h, element e) of the bf16 MFMA operands: each lane half
-// owns 128 contiguous channels so that per-lane gathers are 256-byte runs.
-__host__ __device__ inline int frag_channel(int kk, int h, int e) { return h * 128 + kk * 8 + e; }
+// channel handled by (k-step kk, lane-half h, element e) of the bf16 MFMA operands (natural order)
+__host__ __device__ inline int frag_channel(int kk, int h, int e) { return kk * 16 + h * 8 + e; }
+
+// merged edge-feature tables of the bf16-MFMA kernel (stored as fp16): 3 row gathers instead of 5
+//   [0, 576)     omega*24 + theta   = T[40+omega] + T[64+theta]
+//   [576, 1056)  576 + phi*40 + d   = T[88+phi]   + T[d]
+//   [1056, 1122) 1056 + relpos      = T[100+relpos]
+constexpr int NTAB2 = 576 + 480 + 66;
 
 struct LayerDev {
     float *Wab;       // [512][256]   rows 0..255 = edge_mlp.0.weight[:, 0:256] (h_i), 256..511 = [:, 256:512] (h_j)
     float *bias_ab;   // [512]        [edge_mlp.0.bias ; 0]
     float *w_r;       // [256]        edge_mlp.0.weight[:, 512] (radial column)
     float *T;         // [166][256]   T = ([S|P]^T We^T): per-layer edge-feature lookup table, fp32
-    uint16_t *Tb;     // [166][256]   same, bf16
+    uint16_t *T2b;    // [1122][256]  merged tables (see NTAB2), fp16
     float *W2t;       // [256 in][256 out] edge_mlp.2.weight transposed (fp32 kernel)
     uint16_t *W2f;    // [16][8][64][8] bf16 MFMA B-fragments of edge_mlp.2.weight
     float *b2;        // [256]
@@ -42,6 +47,7 @@ struct LayerDev {
     float *gn_w, *gn_b, *gn_ms;   // GraphNorm
     float *W4;        // [256][256]   node_mlp.3.weight
     float *b4;
+    uint16_t *Wab_hi, *Wab_lo, *W3_hi, *W3_lo, *W4_hi, *W4_lo;   // bf16 hi/lo splits for launch_gemm_split
     float *Wc1t;      // [256 in][256 out] coord_mlp.0.weight transposed (last layer)
     uint16_t *Wc1f;   // bf16 fragments of coord_mlp.0.weight
     float *bc1;       // [256]
@@ -80,9 +86,11 @@ struct GemmArgs {
     float *C;             // [M][ldc]
     int ldc;
     float *C2;            // [M][256]  (epi 2)
-    uint16_t *C2b;        // [M][256]  bf16 copy of C2 (epi 2), may be nullptr
+    uint16_t *C2b;        // [M][256]  fp16 copy of C2 (epi 2), may be nullptr
 };
 hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s);
+// split-bf16 (hi/lo) variant, ~1e-5 relative error; Whi/Wlo = pre-split weights [Nout][ldw] bf16
+hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s);
 
 hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, float *pos,
                             float4 *ca4, float4 *cb4, hipStream_t s);
@@ -94,7 +102,7 @@ hipError_t launch_edge_feat(const float *pos, const float4 *ca4, const float4 *c
 struct EdgeArgs {
     const float *A;        // [Ab][N][256]  Wa h_i + b1   (Ab = 1 when a_bstride == 0)
     const float *Bm;       // [Ab][N][256]  Wb h_j        fp32
-    const uint16_t *Bmb;   // same, bf16
+    const uint16_t *Bmb;   // same, fp16 (gathered operand of the bf16-MFMA kernel)
     int64_t ab_bstride;    // elements between trajectories (0 for layer 0: pose independent)
     const int32_t *edges;  // [B][N][K]
     const uint32_t *codes; // [B][N][K]

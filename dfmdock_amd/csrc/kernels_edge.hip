@@ -13,6 +13,8 @@
 //                 whole (persistent) workgroup.
 #include <cstdlib>
 
+#include <hip/hip_fp16.h>
+
 #include "dfm_device.h"
 #include "dfm_internal.h"
 
@@ -32,7 +34,7 @@ struct EdgeKArgs {
     const float4 *ca4;
     int B, N, R, K, L;
     const float *w_r, *T, *W2t, *b2, *att_w;
-    const uint16_t *Tb;
+    const uint16_t *T2b;
     const uint4 *Wf;
     float att_b;
     const float *Wc1t, *bc1, *wc2;
@@ -168,44 +170,59 @@ __global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
 }
 
 // =================================================================================================
-// bf16 MFMA kernel.
+// bf16 MFMA kernel (v2).
+//
+// Workgroup = 8 waves, persistent, all 160 KiB of LDS: 128 KiB hold the bf16 B-fragments of the 256x256
+// weight matrix for the whole launch, 32 KiB are eight wave-private 4 KiB staging tiles.  A wave owns one
+// node at a time = two 32-row M-tiles (60 edges + 4 masked rows).  Per M-tile and per 64-channel chunk:
+//   producer  (gather layout: 8 adjacent lanes cover one row's 64 channels = whole 128-B lines):
+//             A_i + Bm_j + w_r*radial + 3 merged T rows (fp16 gathers) -> SiLU -> bf16 -> ds_write_b128 (XOR-swizzled)
+//   consumer  4 k-steps x 8 n-tiles of v_mfma_f32_32x32x16_bf16, A-fragments by ds_read_b128 from the
+//             staging tile, B-fragments by ds_read_b128 from the resident weights.
+// The two waves of a SIMD drift apart, so one wave's gathers/VALU run under the other's MFMAs.
+// Epilogue in the C layout (lane = column, registers = rows): +b2, SiLU, attention gate (in-lane dot +
+// 32-lane butterfly), row mask, 60-row segment sum in registers -> agg; no atomics.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 union Frag { uint4 u; bf16x8 b; };
+union H8 { uint4 u; __half2 h[4]; };   // eight fp16 values of one gathered 16-byte chunk
 
-constexpr int LDS_WF_BYTES = 16 * 8 * 64 * 16;   // 131072: bf16 B-fragments of one 256x256 matrix
-constexpr int LDS_EDGE_BYTES = LDS_WF_BYTES + 3 * H * 4;
+constexpr int LDS_WF_BYTES = 16 * 8 * 64 * 16;     // 131072: bf16 B-fragments of one 256x256 matrix
+constexpr int LDS_STAGE_BYTES = 32 * 64 * 2;       // 4096 per wave: 32 rows x 64 channels bf16
+constexpr int EDGE_WAVES = 8;                      // waves per workgroup (two per SIMD, 256 registers each)
+constexpr int LDS_EDGE_BYTES = LDS_WF_BYTES + 8 * LDS_STAGE_BYTES;   // 163840 = the whole CU
 
-struct RawK {            // gathered operands of one k-step (8 channels) of one edge row
-    float4 a0, a1;       // A[i]   (fp32)
-    uint4 bm;            // Bm[j]  (bf16 x 8)
-    uint4 t0, t1, t2, t3, t4;   // five T rows (bf16 x 8)
-};
+__device__ inline float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ inline float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ inline void acc8(float (&v)[8], const uint4 &q)
 {
     v[0] += bflo(q.x); v[1] += bfhi(q.x); v[2] += bflo(q.y); v[3] += bfhi(q.y);
     v[4] += bflo(q.z); v[5] += bfhi(q.z); v[6] += bflo(q.w); v[7] += bfhi(q.w);
 }
+__device__ inline void acc8f(float (&v)[8], const float4 &a, const float4 &b)
+{
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+}
 
-template <int MODE, int GPREC>   // MODE 0: edge messages (+ optional store of gated messages), 1: coordinate MLP on stored messages
-                                  // GPREC bit0: gather Bm in fp32, bit1: gather the T rows in fp32 (precision experiments)
-__global__ __launch_bounds__(512) void k_edge_bf16(EdgeKArgs p)
+// make every earlier LDS access of this wave visible/ordered before later ones (wave-private staging tile)
+__device__ inline void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int GPREC> struct RawP;            // gathered operands of one producer pass (8 channels of one row)
+template <> struct RawP<0> { uint4 bm, t0, t1, t2; };
+template <> struct RawP<1> { float4 b0, b1; uint4 t0, t1, t2; };
+
+template <int MODE, int GPREC>   // MODE 0: edge messages (+ store of gated messages on the last layer), 1: coordinate MLP
+                                 // GPREC 0: Bm gathered as fp16, 1: Bm gathered as fp32
+__global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *Wf = reinterpret_cast<uint4 *>(smem);
-    float *s_wr = reinterpret_cast<float *>(smem + LDS_WF_BYTES);   // [256] radial column (MODE 0)
-    float *s_b = s_wr + H;                                          // [256] bias of this contraction
-    float *s_v = s_b + H;                                           // [256] att_w (MODE 0) / wc2 (MODE 1)
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char *stage = smem + LDS_WF_BYTES + wave * LDS_STAGE_BYTES;
     const int h = lane >> 5, l31 = lane & 31;
-    for (int q = tid; q < LDS_WF_BYTES / 16; q += 512) Wf[q] = p.Wf[q];
-    if (tid < H) {
-        s_wr[tid] = MODE == 0 ? p.w_r[tid] : 0.f;
-        s_b[tid] = MODE == 0 ? p.b2[tid] : p.bc1[tid];
-        s_v[tid] = MODE == 0 ? p.att_w[tid] : p.wc2[tid];
-    }
+    const int r8 = lane >> 3, c8 = lane & 7;            // producer layout: row-in-pass, 8-channel group
+    for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
     __syncthreads();
 
     // XCD-aware task order (speed only): workgroup g runs on XCD g % 8; give every XCD whole
@@ -218,8 +235,10 @@ __global__ __launch_bounds__(512) void k_edge_bf16(EdgeKArgs p)
     const int nb = U > xcd ? (U - xcd + 7) >> 3 : 0;      // chunks owned by this XCD
     const long long ntask = (long long)nb * NTc;
     const int K = p.K, ntile = (K + 31) >> 5;
+    const float *bias_v = MODE == 0 ? p.b2 : p.bc1;       // bias of this contraction
+    const float *dot_v = MODE == 0 ? p.att_w : p.wc2;     // att_w / wc2
 
-    for (long long tt = (long long)slot * 8 + wave; tt < ntask; tt += (long long)wg_per_xcd * 8) {
+    for (long long tt = (long long)slot * EDGE_WAVES + wave; tt < ntask; tt += (long long)wg_per_xcd * EDGE_WAVES) {
         const int u = xcd + 8 * (int)(tt / NTc);
         const int b = __builtin_amdgcn_readfirstlane(u / nsplit);                    // wave-uniform -> SGPRs
         const int idx = __builtin_amdgcn_readfirstlane((u % nsplit) * NTc + (int)(tt % NTc));
@@ -234,8 +253,6 @@ __global__ __launch_bounds__(512) void k_edge_bf16(EdgeKArgs p)
         float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // MODE 1: sum_s cdiff * w
 
         for (int mt = 0; mt < ntile; ++mt) {
-            const int s = mt * 32 + l31;
-            const bool valid = s < K;
             f32x16 acc[8];
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt)
@@ -243,76 +260,100 @@ __global__ __launch_bounds__(512) void k_edge_bf16(EdgeKArgs p)
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
             if (MODE == 0) {
-                const int j = valid ? p.edges[ebase + s] : i;
-                const uint32_t code = valid ? p.codes[ebase + s] : 0u;
-                const float rad = valid ? p.radial[ebase + s] : 0.f;
-                const float *Arow = p.A + ab + (size_t)i * H + h * 128;
-                const uint16_t *Brow = p.Bmb + ab + (size_t)j * H + h * 128;
-                const float *Brow32 = p.Bm + ab + (size_t)j * H + h * 128;
-                const uint16_t *Tbase = p.Tb + h * 128;
-                const float *Tbase32 = p.T + h * 128;
-                const uint32_t o0 = (code & 63u) * H, o1 = (40u + ((code >> 6) & 31u)) * H,
-                               o2 = (64u + ((code >> 11) & 31u)) * H, o3 = (88u + ((code >> 16) & 15u)) * H,
-                               o4 = (100u + ((code >> 20) & 127u)) * H;
-                auto gather = [&](int kk, RawK &r) {
-                    r.a0 = *reinterpret_cast<const float4 *>(Arow + kk * 8);
-                    r.a1 = *reinterpret_cast<const float4 *>(Arow + kk * 8 + 4);
-                    if (GPREC & 1) {
-                        const float4 x0 = *reinterpret_cast<const float4 *>(Brow32 + kk * 8);
-                        const float4 x1 = *reinterpret_cast<const float4 *>(Brow32 + kk * 8 + 4);
-                        r.a0.x += x0.x; r.a0.y += x0.y; r.a0.z += x0.z; r.a0.w += x0.w;
-                        r.a1.x += x1.x; r.a1.y += x1.y; r.a1.z += x1.z; r.a1.w += x1.w;
-                        r.bm = make_uint4(0, 0, 0, 0);
-                    } else {
-                        r.bm = *reinterpret_cast<const uint4 *>(Brow + kk * 8);
-                    }
-                    if (GPREC & 2) {
-                        const uint32_t oo[5] = {o0, o1, o2, o3, o4};
+                // per-pass row data: pass q handles rows mt*32 + q*8 + r8 (rows >= K: self edge, code 0 - finite filler)
+                int jq[4]; uint32_t codeq[4]; float radq[4];
 #pragma unroll
-                        for (int q = 0; q < 5; ++q) {
-                            const float4 x0 = *reinterpret_cast<const float4 *>(Tbase32 + oo[q] + kk * 8);
-                            const float4 x1 = *reinterpret_cast<const float4 *>(Tbase32 + oo[q] + kk * 8 + 4);
-                            r.a0.x += x0.x; r.a0.y += x0.y; r.a0.z += x0.z; r.a0.w += x0.w;
-                            r.a1.x += x1.x; r.a1.y += x1.y; r.a1.z += x1.z; r.a1.w += x1.w;
-                        }
-                        r.t0 = r.t1 = r.t2 = r.t3 = r.t4 = make_uint4(0, 0, 0, 0);
-                    } else {
-                        r.t0 = *reinterpret_cast<const uint4 *>(Tbase + o0 + kk * 8);
-                        r.t1 = *reinterpret_cast<const uint4 *>(Tbase + o1 + kk * 8);
-                        r.t2 = *reinterpret_cast<const uint4 *>(Tbase + o2 + kk * 8);
-                        r.t3 = *reinterpret_cast<const uint4 *>(Tbase + o3 + kk * 8);
-                        r.t4 = *reinterpret_cast<const uint4 *>(Tbase + o4 + kk * 8);
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const int s = mt * 32 + q * 8 + r8;
+                    const bool v = s < K;
+                    jq[q] = v ? p.edges[ebase + s] : i;
+                    codeq[q] = v ? p.codes[ebase + s] : 0u;
+                    radq[q] = v ? p.radial[ebase + s] : 0.f;
+                }
+                const float *Arow = p.A + ab + (size_t)i * H + c8 * 8;
+                float4 a0, a1, w0, w1;                 // per-chunk operands shared by the four passes
+                auto gather_chunk = [&](int kc) {
+                    a0 = *reinterpret_cast<const float4 *>(Arow + kc * 64);
+                    a1 = *reinterpret_cast<const float4 *>(Arow + kc * 64 + 4);
+                    w0 = *reinterpret_cast<const float4 *>(p.w_r + kc * 64 + c8 * 8);
+                    w1 = *reinterpret_cast<const float4 *>(p.w_r + kc * 64 + c8 * 8 + 4);
                 };
-                // one raw buffer, refilled in place: the gathers of k-step kk+1 fly under the SiLU + 8 MFMAs of kk
-                RawK raw;
-                gather(0, raw);
-#pragma unroll 1
-                for (int kk = 0; kk < 16; ++kk) {
-                    float v[8] = {raw.a0.x, raw.a0.y, raw.a0.z, raw.a0.w, raw.a1.x, raw.a1.y, raw.a1.z, raw.a1.w};
-                    acc8(v, raw.bm); acc8(v, raw.t0); acc8(v, raw.t1); acc8(v, raw.t2); acc8(v, raw.t3); acc8(v, raw.t4);
-                    if (kk + 1 < 16) gather(kk + 1, raw);
-                    const float4 w0 = *reinterpret_cast<const float4 *>(s_wr + h * 128 + kk * 8);
-                    const float4 w1 = *reinterpret_cast<const float4 *>(s_wr + h * 128 + kk * 8 + 4);
-                    v[0] = fmaf(w0.x, rad, v[0]); v[1] = fmaf(w0.y, rad, v[1]); v[2] = fmaf(w0.z, rad, v[2]);
-                    v[3] = fmaf(w0.w, rad, v[3]); v[4] = fmaf(w1.x, rad, v[4]); v[5] = fmaf(w1.y, rad, v[5]);
-                    v[6] = fmaf(w1.z, rad, v[6]); v[7] = fmaf(w1.w, rad, v[7]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = valid ? silu(v[e]) : 0.f;
-                    Frag af;
-                    af.u = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
-#pragma unroll
-                    for (int nt = 0; nt < 8; ++nt) {
-                        Frag bf;
-                        bf.u = Wf[(kk * 8 + nt) * 64 + lane];
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.b, bf.b, acc[nt], 0, 0, 0);
+                auto gather = [&](int kc, int q, RawP<GPREC> &r) {
+                    const uint32_t ch = kc * 64 + c8 * 8;
+                    const uint32_t code = codeq[q];
+                    if constexpr (GPREC == 1) {
+                        const float *Brow = p.Bm + ab + ((uint32_t)jq[q] * H + ch);
+                        r.b0 = *reinterpret_cast<const float4 *>(Brow);
+                        r.b1 = *reinterpret_cast<const float4 *>(Brow + 4);
+                    } else {
+                        r.bm = *reinterpret_cast<const uint4 *>(p.Bmb + ab + ((uint32_t)jq[q] * H + ch));
                     }
+                    const uint32_t i0 = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * H;
+                    const uint32_t i1 = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * H;
+                    const uint32_t i2 = (1056u + ((code >> 20) & 127u)) * H;
+                    r.t0 = *reinterpret_cast<const uint4 *>(p.T2b + (i0 + ch));
+                    r.t1 = *reinterpret_cast<const uint4 *>(p.T2b + (i1 + ch));
+                    r.t2 = *reinterpret_cast<const uint4 *>(p.T2b + (i2 + ch));
+                };
+                auto compute_store = [&](int q, const RawP<GPREC> &r) {
+                    const float rad = radq[q];
+                    float v[8] = {fmaf(w0.x, rad, a0.x), fmaf(w0.y, rad, a0.y), fmaf(w0.z, rad, a0.z), fmaf(w0.w, rad, a0.w),
+                                  fmaf(w1.x, rad, a1.x), fmaf(w1.y, rad, a1.y), fmaf(w1.z, rad, a1.z), fmaf(w1.w, rad, a1.w)};
+                    // three table rows summed as packed fp16 (v_pk_add_f16), then widened once
+                    H8 t, t1, t2;
+                    t.u = r.t0; t1.u = r.t1; t2.u = r.t2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t.h[e] = __hadd2(__hadd2(t.h[e], t1.h[e]), t2.h[e]);
+                    if constexpr (GPREC == 1) {
+                        acc8f(v, r.b0, r.b1);
+                    } else {
+                        H8 bm;
+                        bm.u = r.bm;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[2 * e] += __low2float(bm.h[e]); v[2 * e + 1] += __high2float(bm.h[e]); }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[2 * e] += __low2float(t.h[e]); v[2 * e + 1] += __high2float(t.h[e]); }
+                    Frag f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f.b[e] = (__bf16)silu_fast(v[e]);   // rows >= K hold finite filler, gated to 0 below
+                    const int row = q * 8 + r8;
+                    *reinterpret_cast<uint4 *>(stage + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = f.u;
+                };
+                // every pass owns one raw buffer that is refilled in place for the NEXT chunk right after it is
+                // consumed: a whole chunk of gathers (16 x 1 KiB per wave) flies under the 32 MFMAs of this chunk
+                RawP<GPREC> r0, r1, r2, r3;
+                gather_chunk(0);
+                gather(0, 0, r0); gather(0, 1, r1); gather(0, 2, r2); gather(0, 3, r3);
+#pragma unroll 1
+                for (int kc = 0; kc < 4; ++kc) {
+                    const int kn = kc < 3 ? kc + 1 : 3;
+                    compute_store(0, r0); if (kc < 3) gather(kn, 0, r0);
+                    compute_store(1, r1); if (kc < 3) gather(kn, 1, r1);
+                    compute_store(2, r2); if (kc < 3) gather(kn, 2, r2);
+                    compute_store(3, r3); if (kc < 3) gather(kn, 3, r3);
+                    if (kc < 3) gather_chunk(kn);
+                    wave_lds_fence();
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) {
+                        Frag af;
+                        af.u = *reinterpret_cast<const uint4 *>(stage + l31 * 128 + (((kq * 2 + h) ^ ((l31 >> 1) & 7)) << 4));
+#pragma unroll
+                        for (int nt = 0; nt < 8; ++nt) {
+                            Frag bf;
+                            bf.u = Wf[((kc * 4 + kq) * 8 + nt) * 64 + lane];
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.b, bf.b, acc[nt], 0, 0, 0);
+                        }
+                    }
+                    wave_lds_fence();
                 }
             } else {
-                const uint16_t *Mrow = p.mbuf + (((size_t)b * p.L + (i - p.R)) * KPAD + (valid ? s : 0)) * H + h * 128;
+                const int s = mt * 32 + l31;
+                const bool valid = s < K;
+                const uint16_t *Mrow = p.mbuf + (((size_t)b * p.L + (i - p.R)) * KPAD + (valid ? s : 0)) * H + h * 8;
                 uint4 cur[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const uint4 *>(Mrow + q * 8);
+                for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const uint4 *>(Mrow + q * 16);
 #pragma unroll 1
                 for (int g = 0; g < 4; ++g) {
                     uint4 a4[4];
@@ -320,7 +361,7 @@ __global__ __launch_bounds__(512) void k_edge_bf16(EdgeKArgs p)
                     for (int q = 0; q < 4; ++q) a4[q] = valid ? cur[q] : make_uint4(0, 0, 0, 0);
                     if (g < 3) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const uint4 *>(Mrow + ((g + 1) * 4 + q) * 8);
+                        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const uint4 *>(Mrow + ((g + 1) * 4 + q) * 16);
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -342,10 +383,10 @@ __global__ __launch_bounds__(512) void k_edge_bf16(EdgeKArgs p)
             for (int r = 0; r < 16; ++r) part[r] = 0.f;
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
-                const float bias = s_b[nt * 32 + l31], vv = s_v[nt * 32 + l31];
+                const float bias = bias_v[nt * 32 + l31], vv = dot_v[nt * 32 + l31];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float m = silu(acc[nt][r] + bias);
+                    const float m = silu_fast(acc[nt][r] + bias);
                     acc[nt][r] = m;
                     part[r] = fmaf(m, vv, part[r]);
                 }
@@ -357,24 +398,24 @@ __global__ __launch_bounds__(512) void k_edge_bf16(EdgeKArgs p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    part[r] = row < K ? 1.0f / (1.0f + __expf(-(part[r] + p.att_b))) : 0.f;   // attention gate
+                    part[r] = row < K ? sigmoid_fast(part[r] + p.att_b) : 0.f;   // attention gate; masked rows -> 0
                 }
                 const bool store_m = p.last && i >= p.R;
-                uint16_t *Mout = store_m ? p.mbuf + (((size_t)b * p.L + (i - p.R)) * KPAD) * H : nullptr;
+                if (store_m) {
+                    uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * KPAD) * H;
+#pragma unroll
+                    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            Mout[(size_t)row * H + nt * 32 + l31] = f2bf(acc[nt][r] * part[r]);
+                        }
+                }
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
                     float cs = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float mg = acc[nt][r] * part[r];
-                        cs += mg;
-                        if (store_m) {
-                            // stored in operand order: element (row, channel) at [row][channel]; the consumer
-                            // (MODE 1) reads channel = h*128 + kk*8 + e, so store by natural channel index
-                            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            Mout[(size_t)row * H + nt * 32 + l31] = f2bf(mg);
-                        }
-                    }
+                    for (int r = 0; r < 16; ++r) cs = fmaf(acc[nt][r], part[r], cs);
                     colsum[nt] += cs;
                 }
             } else {
@@ -427,7 +468,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.edges = a.edges; k.codes = a.codes; k.radial = a.radial; k.ca4 = a.ca4;
     k.B = a.B; k.N = a.N; k.R = a.R; k.K = a.K; k.L = a.N - a.R;
     const LayerDev *w = a.lw;
-    k.w_r = w->w_r; k.T = w->T; k.W2t = w->W2t; k.b2 = w->b2; k.att_w = w->att_w; k.Tb = w->Tb;
+    k.w_r = w->w_r; k.T = w->T; k.W2t = w->W2t; k.b2 = w->b2; k.att_w = w->att_w; k.T2b = w->T2b;
     k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
     k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf;
@@ -454,54 +495,39 @@ static int persistent_grid(long long wave_tasks)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    long long wgs = (wave_tasks + 7) / 8;
+    long long wgs = (wave_tasks + EDGE_WAVES - 1) / EDGE_WAVES;
     long long g = wgs < cus ? wgs : cus;
     g = (g + 7) / 8 * 8;   // multiple of the XCD count
     return (int)g;
 }
 
-template <int GPREC> static hipError_t launch_edge_bf16_t(const EdgeArgs &a, hipStream_t s)
+template <int MODE, int GPREC> static hipError_t launch_bf16_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_bf16<0, GPREC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_bf16<MODE, GPREC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_EDGE_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const EdgeKArgs k = to_kargs(a);
-    const int grid = persistent_grid((long long)a.B * a.N);
-    hipLaunchKernelGGL((k_edge_bf16<0, GPREC>), dim3(grid), dim3(512), LDS_EDGE_BYTES, s, k);
+    hipLaunchKernelGGL((k_edge_bf16<MODE, GPREC>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
     return hipGetLastError();
 }
 
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    // DFM_GATHER_PREC (debug): bit0 = fp32 Bm gathers, bit1 = fp32 T-row gathers.  Default 1: measured on the
-    // golden vectors, fp32 Bm gathers cut the worst rot_score deviation 1.0e-2 -> 6.6e-3 for 3 % throughput.
-    static const int gprec = [] { const char *e = getenv("DFM_GATHER_PREC"); return e ? atoi(e) & 3 : 1; }();
-    switch (gprec) {
-        case 1: return launch_edge_bf16_t<1>(a, s);
-        case 2: return launch_edge_bf16_t<2>(a, s);
-        case 3: return launch_edge_bf16_t<3>(a, s);
-        default: return launch_edge_bf16_t<0>(a, s);
-    }
+    // DFM_GATHER_PREC (debug): 1 = gather Bm (= Wb h_j) as fp32, 0 = as fp16 (default; the T tables are fp16 too:
+    // 11-bit mantissa, 8x finer than bf16 at the same bytes - only the MFMA operands themselves are bf16).
+    static const int gprec = [] { const char *e = getenv("DFM_GATHER_PREC"); return e ? atoi(e) & 1 : 0; }();
+    const EdgeKArgs k = to_kargs(a);
+    return gprec ? launch_bf16_t<0, 1>(k, (long long)a.B * a.N, s) : launch_bf16_t<0, 0>(k, (long long)a.B * a.N, s);
 }
 
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_bf16<1, 0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_EDGE_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
     EdgeKArgs k = to_kargs(a);
     k.Wf = reinterpret_cast<const uint4 *>(a.lw->Wc1f);
-    const int grid = persistent_grid((long long)a.B * (a.N - a.R));
-    hipLaunchKernelGGL((k_edge_bf16<1, 0>), dim3(grid), dim3(512), LDS_EDGE_BYTES, s, k);
-    return hipGetLastError();
+    return launch_bf16_t<1, 0>(k, (long long)a.B * (a.N - a.R), s);
 }
 
 }  // namespace dfm

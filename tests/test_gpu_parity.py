@@ -268,7 +268,7 @@ def test_reference_shaped_python_api(blob):
     assert torch.equal(rec_pos, batch["rec_pos"]) and {"energy", "num_clashes", "tr_score", "rot_score"} <= set(output)
     # rigid-body consistency: final pose == original ligand moved by (rot_update, tr_update) about its CA centroid
     from oracle import oracle as ora
-    moved = ora.modify_coords(cx["lig_pos"], rot_update.numpy(), tr_update.numpy())
+    moved = ora.modify_coords(batch["lig_pos"].numpy(), rot_update.numpy(), tr_update.numpy())
     assert np.abs(moved - lig_pos.numpy()).max() < 2e-3
     dt = torch.tensor(0.025615394115447998)
     s = torch.tensor([[0.25, -0.5, 0.125]])
