@@ -54,7 +54,8 @@ def main():
     ap.add_argument("--R", type=int, default=300)
     ap.add_argument("--L", type=int, default=300)
     ap.add_argument("--num-steps", type=int, default=40, help="diffusion steps per trajectory")
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "f16", "fp32"], default="bf16",
+                    help="bf16 / f16: 16-bit MFMA operands for the per-edge contractions (fp32 accumulate); fp32: exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -80,10 +81,12 @@ def main():
     model = engine.Model(blob)
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
     bf16 = args.precision == "bf16"
+    f16 = args.precision == "f16"
+    mfma16 = bf16 or f16
     B = args.batch
 
     def one_step(it, profile=False):
-        r = gx.sample(B=B, num_steps=args.num_steps, seed=1000 * (rank + 1) + it, bf16=bf16, profile=profile)
+        r = gx.sample(B=B, num_steps=args.num_steps, seed=1000 * (rank + 1) + it, bf16=bf16, f16=f16, profile=profile)
         rec = D.make_records(0, np.arange(rank * B, (rank + 1) * B), r)
         allrec = D.gather_records(rec)            # the only collective: ranked energies (RCCL all_gather)
         return r, allrec
@@ -116,7 +119,7 @@ def main():
         avg_launch_s = edge_ms / max(edge_launches, 1) * 1e-3
         flop_per_launch = B * N * FLOP_PER_NODE_LAYER
         achieved = flop_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-        peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if mfma16 else PEAK_F32_TFLOPS
         out = {
             "metric": "docking trajectories/sec (N_res~300+300, 40 steps)",
             "value": total_traj / elapsed,
@@ -128,13 +131,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if bf16 else "f32",
+            "dtype": args.precision if mfma16 else "f32",
             "data": "synthetic",
             "config": {"workload": f"C3: synthetic {args.R}+{args.L}-residue complex, batch={B} trajectories/GPU, "
                                    f"{args.num_steps} steps ({args.num_steps + 1} score evaluations + energy head)",
                        "trajectories_per_gpu": B, "num_steps": args.num_steps, "parallelism": f"traj-shard x{world}",
                        "weights": "random-init (seeded generator; trained checkpoint not in the reference)"},
-            "roofline": {"bound": "mfma", "kernel": "k_edge_bf16<0>" if bf16 else "k_edge_f32", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": ("k_edge_bf16<0,%d>" % int(f16)) if mfma16 else "k_edge_f32", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
                          "flop_per_launch": flop_per_launch, "traffic": None},

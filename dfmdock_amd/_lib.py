@@ -22,6 +22,7 @@ DFM_F_CLASH_FORCE = 1 << 3
 DFM_F_ODE = 1 << 4
 DFM_F_PROFILE = 1 << 5
 DFM_F_STEP_ENERGY = 1 << 6
+DFM_F_F16 = 1 << 7
 
 EXPORTS = [
     "dfm_last_error", "dfm_device_count", "dfm_set_device", "dfm_default_hparams", "dfm_param_count",

@@ -200,15 +200,15 @@ extern "C" int dfm_diffusion_coef(const dfm_hparams *hp, int which, double t, do
 }
 
 // ------------------------------------------------------------------------------------------------
-static std::vector<uint16_t> pack_frags(const float *W /*[256 out][256 in]*/)
-{   // bf16 B-operand fragments of v_mfma_f32_32x32x16_bf16: [kk][nt][lane][e] = W[nt*32 + lane%32][chan(kk, lane/32, e)]
+static std::vector<uint16_t> pack_frags(const float *W /*[256 out][256 in]*/, bool f16 = false)
+{   // 16-bit B-operand fragments of v_mfma_f32_32x32x16_bf16: [kk][nt][lane][e] = W[nt*32 + lane%32][chan(kk, lane/32, e)]
     std::vector<uint16_t> f((size_t)16 * 8 * 64 * 8);
     for (int kk = 0; kk < 16; ++kk)
         for (int nt = 0; nt < 8; ++nt)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
                     const int n = nt * 32 + (lane & 31), k = frag_channel(kk, lane >> 5, e);
-                    f[(((size_t)kk * 8 + nt) * 64 + lane) * 8 + e] = f2bf(W[(size_t)n * H + k]);
+                    f[(((size_t)kk * 8 + nt) * 64 + lane) * 8 + e] = f16 ? f2h(W[(size_t)n * H + k]) : f2bf(W[(size_t)n * H + k]);
                 }
     return f;
 }
@@ -289,7 +289,7 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
         up(&D.Wab, Wab.data(), Wab.size()); up(&D.bias_ab, bias_ab.data(), bias_ab.size());
         up(&D.w_r, w_r.data(), w_r.size()); up(&D.T, T.data(), T.size()); up16(&D.T2b, T2b);
         const std::vector<float> W2t = transpose256(Lw.e2_w);
-        up(&D.W2t, W2t.data(), W2t.size()); up16(&D.W2f, pack_frags(Lw.e2_w));
+        up(&D.W2t, W2t.data(), W2t.size()); up16(&D.W2f, pack_frags(Lw.e2_w)); up16(&D.W2f16, pack_frags(Lw.e2_w, true));
         up(&D.b2, Lw.e2_b, H); up(&D.att_w, Lw.att_w, H); D.att_b = Lw.att_b[0];
         up(&D.W3, Lw.n1_w, (size_t)H * 2 * H); up(&D.b3, Lw.n1_b, H);
         up(&D.gn_w, Lw.gn_w, H); up(&D.gn_b, Lw.gn_b, H); up(&D.gn_ms, Lw.gn_ms, H);
@@ -302,7 +302,7 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
         }
         if (Lw.c1_w) {
             const std::vector<float> Wc1t = transpose256(Lw.c1_w);
-            up(&D.Wc1t, Wc1t.data(), Wc1t.size()); up16(&D.Wc1f, pack_frags(Lw.c1_w));
+            up(&D.Wc1t, Wc1t.data(), Wc1t.size()); up16(&D.Wc1f, pack_frags(Lw.c1_w)); up16(&D.Wc1f16, pack_frags(Lw.c1_w, true));
             up(&D.bc1, Lw.c1_b, H); up(&D.wc2, Lw.c2_w, H);
         }
     }
@@ -421,7 +421,7 @@ __global__ void k_fill(float *dst, float v, int n)
 }
 
 struct FwdOpts {
-    bool bf16 = false, want_energy = false, profile = false;
+    bool bf16 = false, f16 = false, want_energy = false, profile = false;   // bf16: 16-bit MFMA engine; f16: with fp16 operands
     const int32_t *edges_dev = nullptr;   // [B][N][K] already on device (or nullptr = sample natively)
     int64_t edges_pitch = 0;              // elements between trajectories in edges_dev
     uint64_t seed = 0;
@@ -462,6 +462,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         else { e.A = W.A; e.Bm = W.Bm; e.Bmb = W.Bmb; e.ab_bstride = (int64_t)N * H; }
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
         e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = last; e.fout = W.fvec; e.mbuf = W.mbuf;
+        e.f16 = o.f16 ? 1 : 0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (o.profile) {
             if (cx->ev_used + 2 > cx->ev.size()) {
@@ -552,7 +553,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
 {
     if (!cx || !lig_pos || !t || !out || !out->tr_score || !out->rot_score) return fail(DFM_E_INVALID, "NULL argument");
     if (B < 1) return fail(DFM_E_INVALID, "B must be >= 1");
-    const bool bf16 = flags & DFM_F_BF16, want_energy = flags & DFM_F_ENERGY;
+    const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_BF16) || f16, want_energy = flags & DFM_F_ENERGY;
     int rc = ensure_workspace(cx, B, bf16);
     if (rc) return rc;
     Workspace &W = cx->ws;
@@ -571,7 +572,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     }
     if (out->h_first) HIPCHK(hipMalloc(reinterpret_cast<void **>(&h_first_dev), (size_t)B * N * H * 4));
     FwdOpts o;
-    o.bf16 = bf16; o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
+    o.bf16 = bf16; o.f16 = f16; o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
     o.edges_pitch = (int64_t)N * K; o.seed = seed; o.h_first_out = h_first_dev;
     HIPCHK(hipEventRecord(cx->ev_total[0], s));
     rc = enqueue_forward(cx, B, o);
@@ -612,7 +613,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
 {
     if (!cx || !out) return fail(DFM_E_INVALID, "NULL argument");
     if (B < 1 || num_steps < 2) return fail(DFM_E_INVALID, "need B >= 1 and num_steps >= 2");
-    const bool bf16 = flags & DFM_F_BF16;
+    const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_BF16) || f16;
     int rc = ensure_workspace(cx, B, bf16);
     if (rc) return rc;
     Workspace &W = cx->ws;
@@ -660,7 +661,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
         HIPCHK(hipMemcpyAsync(ip_d, W.lig_cur, (size_t)B * L * 9 * 4, hipMemcpyDeviceToDevice, s));
     }
     FwdOpts o;
-    o.bf16 = bf16; o.profile = flags & DFM_F_PROFILE; o.seed = seed; o.edges_pitch = (int64_t)(S + 1) * N * K;
+    o.bf16 = bf16; o.f16 = f16; o.profile = flags & DFM_F_PROFILE; o.seed = seed; o.edges_pitch = (int64_t)(S + 1) * N * K;
     const bool step_energy = (flags & DFM_F_STEP_ENERGY) != 0;
     for (int i = 0; i < num_steps; ++i) {
         const bool is_last = (i == num_steps - 1);

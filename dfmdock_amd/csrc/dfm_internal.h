@@ -39,6 +39,7 @@ struct LayerDev {
     uint16_t *T2b;    // [1122][256]  merged tables (see NTAB2), fp16
     float *W2t;       // [256 in][256 out] edge_mlp.2.weight transposed (fp32 kernel)
     uint16_t *W2f;    // [16][8][64][8] bf16 MFMA B-fragments of edge_mlp.2.weight
+    uint16_t *W2f16;  // same, fp16
     float *b2;        // [256]
     float *att_w;     // [256]
     float att_b;
@@ -50,6 +51,7 @@ struct LayerDev {
     uint16_t *Wab_hi, *Wab_lo, *W3_hi, *W3_lo, *W4_hi, *W4_lo;   // bf16 hi/lo splits for launch_gemm_split
     float *Wc1t;      // [256 in][256 out] coord_mlp.0.weight transposed (last layer)
     uint16_t *Wc1f;   // bf16 fragments of coord_mlp.0.weight
+    uint16_t *Wc1f16; // fp16 fragments
     float *bc1;       // [256]
     float *wc2;       // [256]
 };
@@ -113,7 +115,8 @@ struct EdgeArgs {
     float *agg;            // [B][N][256]
     int last;              // last layer: also the coordinate update for ligand nodes
     float *fout;           // [B][L][3]   (last)
-    uint16_t *mbuf;        // [B][L][64][256] bf16 gated messages (bf16 path, last)
+    uint16_t *mbuf;        // [B][L][64][256] 16-bit gated messages (MFMA path, last)
+    int f16;               // MFMA operand type: 0 bf16, 1 fp16
 };
 hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s);

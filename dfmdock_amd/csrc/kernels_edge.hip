@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
 }
 
 // =================================================================================================
-// bf16 MFMA kernel (v2).
+// 16-bit MFMA kernel (bf16 or fp16 operands).
 //
 // Workgroup = 8 waves, persistent, all 160 KiB of LDS: 128 KiB hold the bf16 B-fragments of the 256x256
 // weight matrix for the whole launch, 32 KiB are eight wave-private 4 KiB staging tiles.  A wave owns one
@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
 // 32-lane butterfly), row mask, 60-row segment sum in registers -> agg; no atomics.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-union Frag { uint4 u; bf16x8 b; };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+union Frag { uint4 u; bf16x8 b; f16x8 f; };
 union H8 { uint4 u; __half2 h[4]; };   // eight fp16 values of one gathered 16-byte chunk
 
 constexpr int LDS_WF_BYTES = 16 * 8 * 64 * 16;     // 131072: bf16 B-fragments of one 256x256 matrix
@@ -205,15 +206,37 @@ __device__ inline void acc8f(float (&v)[8], const float4 &a, const float4 &b)
     v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
 }
 
+// sum over the 32 lanes sharing lane>>5, result in every lane: 4 DPP adds inside each 16-lane row
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) + one ds_swizzle (xor 16) across the two rows
+__device__ inline float half_sum_dpp(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // xor 0x10, and 0x1f
+    return v;
+}
+
 // make every earlier LDS access of this wave visible/ordered before later ones (wave-private staging tile)
 __device__ inline void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int GPREC> struct RawP;            // gathered operands of one producer pass (8 channels of one row)
-template <> struct RawP<0> { uint4 bm, t0, t1, t2; };
-template <> struct RawP<1> { float4 b0, b1; uint4 t0, t1, t2; };
+struct RawP { uint4 bm, t0, t1, t2; };        // gathered fp16 operands of one producer pass (8 channels of one row)
 
-template <int MODE, int GPREC>   // MODE 0: edge messages (+ store of gated messages on the last layer), 1: coordinate MLP
-                                 // GPREC 0: Bm gathered as fp16, 1: Bm gathered as fp32
+// one MFMA step on bf16 (F16 = 0) or fp16 (F16 = 1) operands, fp32 accumulate - same rate on gfx950
+template <int F16> __device__ inline f32x16 mfma16(const Frag &a, const Frag &b, f32x16 c)
+{
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.f, b.f, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b, b.b, c, 0, 0, 0);
+}
+template <int F16> __device__ inline uint16_t to16(float x)
+{
+    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)fminf(fmaxf(x, -65504.f), 65504.f));
+    else return __builtin_bit_cast(uint16_t, (__bf16)x);
+}
+
+template <int MODE, int F16>     // MODE 0: edge messages (+ store of gated messages on the last layer), 1: coordinate MLP
+                                 // F16 0: bf16 MFMA operands, 1: fp16 MFMA operands (3 more mantissa bits, same rate)
 __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -253,11 +276,13 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
         float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // MODE 1: sum_s cdiff * w
 
         for (int mt = 0; mt < ntile; ++mt) {
-            f32x16 acc[8];
+            f32x16 acc[8];   // accumulators start at the bias of this contraction (saves the epilogue add)
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
+            for (int nt = 0; nt < 8; ++nt) {
+                const float bias = bias_v[nt * 32 + l31];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[nt][r] = bias;
+            }
 
             if (MODE == 0) {
                 // per-pass row data: pass q handles rows mt*32 + q*8 + r8 (rows >= K: self edge, code 0 - finite filler)
@@ -278,16 +303,10 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     w0 = *reinterpret_cast<const float4 *>(p.w_r + kc * 64 + c8 * 8);
                     w1 = *reinterpret_cast<const float4 *>(p.w_r + kc * 64 + c8 * 8 + 4);
                 };
-                auto gather = [&](int kc, int q, RawP<GPREC> &r) {
+                auto gather = [&](int kc, int q, RawP &r) {
                     const uint32_t ch = kc * 64 + c8 * 8;
                     const uint32_t code = codeq[q];
-                    if constexpr (GPREC == 1) {
-                        const float *Brow = p.Bm + ab + ((uint32_t)jq[q] * H + ch);
-                        r.b0 = *reinterpret_cast<const float4 *>(Brow);
-                        r.b1 = *reinterpret_cast<const float4 *>(Brow + 4);
-                    } else {
-                        r.bm = *reinterpret_cast<const uint4 *>(p.Bmb + ab + ((uint32_t)jq[q] * H + ch));
-                    }
+                    r.bm = *reinterpret_cast<const uint4 *>(p.Bmb + ab + ((uint32_t)jq[q] * H + ch));
                     const uint32_t i0 = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * H;
                     const uint32_t i1 = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * H;
                     const uint32_t i2 = (1056u + ((code >> 20) & 127u)) * H;
@@ -295,7 +314,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     r.t1 = *reinterpret_cast<const uint4 *>(p.T2b + (i1 + ch));
                     r.t2 = *reinterpret_cast<const uint4 *>(p.T2b + (i2 + ch));
                 };
-                auto compute_store = [&](int q, const RawP<GPREC> &r) {
+                auto compute_store = [&](int q, const RawP &r) {
                     const float rad = radq[q];
                     float v[8] = {fmaf(w0.x, rad, a0.x), fmaf(w0.y, rad, a0.y), fmaf(w0.z, rad, a0.z), fmaf(w0.w, rad, a0.w),
                                   fmaf(w1.x, rad, a1.x), fmaf(w1.y, rad, a1.y), fmaf(w1.z, rad, a1.z), fmaf(w1.w, rad, a1.w)};
@@ -304,25 +323,24 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     t.u = r.t0; t1.u = r.t1; t2.u = r.t2;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) t.h[e] = __hadd2(__hadd2(t.h[e], t1.h[e]), t2.h[e]);
-                    if constexpr (GPREC == 1) {
-                        acc8f(v, r.b0, r.b1);
-                    } else {
-                        H8 bm;
-                        bm.u = r.bm;
+                    H8 bm;
+                    bm.u = r.bm;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[2 * e] += __low2float(bm.h[e]); v[2 * e + 1] += __high2float(bm.h[e]); }
-                    }
+                    for (int e = 0; e < 4; ++e) { v[2 * e] += __low2float(bm.h[e]); v[2 * e + 1] += __high2float(bm.h[e]); }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[2 * e] += __low2float(t.h[e]); v[2 * e + 1] += __high2float(t.h[e]); }
-                    Frag f;
+                    Frag f;   // rows >= K hold finite filler, gated to 0 below
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f.b[e] = (__bf16)silu_fast(v[e]);   // rows >= K hold finite filler, gated to 0 below
+                    for (int e = 0; e < 8; ++e) {
+                        if constexpr (F16) f.f[e] = (_Float16)fminf(silu_fast(v[e]), 65504.f);
+                        else f.b[e] = (__bf16)silu_fast(v[e]);
+                    }
                     const int row = q * 8 + r8;
                     *reinterpret_cast<uint4 *>(stage + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = f.u;
                 };
                 // every pass owns one raw buffer that is refilled in place for the NEXT chunk right after it is
                 // consumed: a whole chunk of gathers (16 x 1 KiB per wave) flies under the 32 MFMAs of this chunk
-                RawP<GPREC> r0, r1, r2, r3;
+                RawP r0, r1, r2, r3;
                 gather_chunk(0);
                 gather(0, 0, r0); gather(0, 1, r1); gather(0, 2, r2); gather(0, 3, r3);
 #pragma unroll 1
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                         for (int nt = 0; nt < 8; ++nt) {
                             Frag bf;
                             bf.u = Wf[((kc * 4 + kq) * 8 + nt) * 64 + lane];
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.b, bf.b, acc[nt], 0, 0, 0);
+                            acc[nt] = mfma16<F16>(af, bf, acc[nt]);
                         }
                     }
                     wave_lds_fence();
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                         for (int nt = 0; nt < 8; ++nt) {
                             Frag bf;
                             bf.u = Wf[((g * 4 + q) * 8 + nt) * 64 + lane];
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.b, bf.b, acc[nt], 0, 0, 0);
+                            acc[nt] = mfma16<F16>(af, bf, acc[nt]);
                         }
                     }
                 }
@@ -383,16 +401,16 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
             for (int r = 0; r < 16; ++r) part[r] = 0.f;
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
-                const float bias = bias_v[nt * 32 + l31], vv = dot_v[nt * 32 + l31];
+                const float vv = dot_v[nt * 32 + l31];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float m = silu_fast(acc[nt][r] + bias);
+                    const float m = silu_fast(acc[nt][r]);
                     acc[nt][r] = m;
                     part[r] = fmaf(m, vv, part[r]);
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[r] = half_sum(part[r]);   // all 32 lanes of the half hold the row sum
+            for (int r = 0; r < 16; ++r) part[r] = half_sum_dpp(part[r]);   // all 32 lanes of the half hold the row sum
 
             if (MODE == 0) {
 #pragma unroll
@@ -408,7 +426,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            Mout[(size_t)row * H + nt * 32 + l31] = f2bf(acc[nt][r] * part[r]);
+                            Mout[(size_t)row * H + nt * 32 + l31] = to16<F16>(acc[nt][r] * part[r]);
                         }
                 }
 #pragma unroll
@@ -501,33 +519,35 @@ static int persistent_grid(long long wave_tasks)
     return (int)g;
 }
 
-template <int MODE, int GPREC> static hipError_t launch_bf16_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
+template <int MODE, int F16> static hipError_t launch_mfma_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_bf16<MODE, GPREC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_bf16<MODE, F16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_EDGE_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_edge_bf16<MODE, GPREC>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
+    hipLaunchKernelGGL((k_edge_bf16<MODE, F16>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
     return hipGetLastError();
 }
 
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    // DFM_GATHER_PREC (debug): 1 = gather Bm (= Wb h_j) as fp32, 0 = as fp16 (default; the T tables are fp16 too:
-    // 11-bit mantissa, 8x finer than bf16 at the same bytes - only the MFMA operands themselves are bf16).
-    static const int gprec = [] { const char *e = getenv("DFM_GATHER_PREC"); return e ? atoi(e) & 1 : 0; }();
-    const EdgeKArgs k = to_kargs(a);
-    return gprec ? launch_bf16_t<0, 1>(k, (long long)a.B * a.N, s) : launch_bf16_t<0, 0>(k, (long long)a.B * a.N, s);
+    EdgeKArgs k = to_kargs(a);
+    if (a.f16) {
+        k.Wf = reinterpret_cast<const uint4 *>(a.lw->W2f16);
+        return launch_mfma_t<0, 1>(k, (long long)a.B * a.N, s);
+    }
+    return launch_mfma_t<0, 0>(k, (long long)a.B * a.N, s);
 }
 
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
 {
     EdgeKArgs k = to_kargs(a);
-    k.Wf = reinterpret_cast<const uint4 *>(a.lw->Wc1f);
-    return launch_bf16_t<1, 0>(k, (long long)a.B * (a.N - a.R), s);
+    k.Wf = reinterpret_cast<const uint4 *>(a.f16 ? a.lw->Wc1f16 : a.lw->Wc1f);
+    const long long tasks = (long long)a.B * (a.N - a.R);
+    return a.f16 ? launch_mfma_t<1, 1>(k, tasks, s) : launch_mfma_t<1, 0>(k, tasks, s);
 }
 
 }  // namespace dfm

@@ -95,7 +95,7 @@ class Complex:
             pass
 
     # ------------------------------------------------------------------
-    def score(self, lig_pos, t, edges=None, seed=0, bf16=False, energy=True, debug=False, profile=False):
+    def score(self, lig_pos, t, edges=None, seed=0, bf16=False, energy=True, debug=False, profile=False, f16=False):
         """B score evaluations.  lig_pos [B,L,3,3] (or [L,3,3]), t [B] (or scalar)."""
         lig_pos = _f32(lig_pos)
         if lig_pos.ndim == 3:
@@ -121,7 +121,8 @@ class Complex:
                 e = e[None]
             if e.shape != (B, N, K):
                 raise ValueError(f"edges must be [B,N,K] = {(B, N, K)}, got {e.shape}")
-        flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_ENERGY if energy else 0) | (L.DFM_F_PROFILE if profile else 0)
+        flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_ENERGY if energy else 0) | (L.DFM_F_PROFILE if profile else 0) | \
+                (L.DFM_F_F16 if f16 else 0)
         rc = L.lib().dfm_score(self._h, B, _p(lig_pos), _p(t), _p(e, L.I32P), int(seed), flags, C.byref(out))
         L.check(rc, "dfm_score")
         if debug:
@@ -131,7 +132,7 @@ class Complex:
         return o
 
     def sample(self, B=1, num_steps=40, eps=1e-3, tr_noise_scale=0.5, rot_noise_scale=0.5, noise_annealing=False,
-               use_clash_force=False, ode=False, seed=0, bf16=False, inject=None, trace=False, profile=False):
+               use_clash_force=False, ode=False, seed=0, bf16=False, inject=None, trace=False, profile=False, f16=False):
         """B independent Euler-Maruyama trajectories (inference_base.py:390-468 batched)."""
         Lg, N, K, S = self.L, self.N, self.K, int(num_steps)
         o = dict(lig_pos=np.zeros((B, Lg, 3, 3), np.float32), rot_update=np.zeros((B, 3), np.float32),
@@ -160,7 +161,7 @@ class Complex:
                 inj.edges = _p(a, L.I32P)
         flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_NOISE_ANNEALING if noise_annealing else 0) | \
                 (L.DFM_F_CLASH_FORCE if use_clash_force else 0) | (L.DFM_F_ODE if ode else 0) | \
-                (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if trace else 0)
+                (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if trace else 0) | (L.DFM_F_F16 if f16 else 0)
         rc = L.lib().dfm_sample(self._h, int(B), S, float(eps), float(tr_noise_scale), float(rot_noise_scale), flags,
                                 int(seed), C.byref(inj) if inj is not None else None, C.byref(out))
         L.check(rc, "dfm_sample")

@@ -129,7 +129,7 @@ class Score_Model:
         if t.size != 1:
             raise ValueError("batch['t'] must hold one time value (the reference runs batch_size=1)")
         self._calls += 1
-        r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, bf16=self.precision == "bf16", energy=True)
+        r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, bf16=self.precision == "bf16", f16=self.precision == "f16", energy=True)
         return {"tr_score": torch.from_numpy(r["tr_score"]), "rot_score": torch.from_numpy(r["rot_score"]),
                 "energy": torch.tensor(float(r["energy"][0]), dtype=torch.float32), "f": torch.from_numpy(r["f"][0]),
                 "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64)}
@@ -150,7 +150,8 @@ def Euler_Maruyama_sampler(model: Score_Model, batch, num_steps=40, device="cpu"
     model._calls += 1
     r = cx.sample(B=1, num_steps=num_steps, eps=eps, tr_noise_scale=tr_noise_scale, rot_noise_scale=rot_noise_scale,
                   noise_annealing=noise_annealing, use_clash_force=use_clash_force,
-                  seed=(model.seed + model._calls) if seed is None else seed, bf16=model.precision == "bf16")
+                  seed=(model.seed + model._calls) if seed is None else seed, bf16=model.precision == "bf16",
+                  f16=model.precision == "f16")
     output = {"energy": torch.tensor(float(r["energy"][0])), "num_clashes": torch.tensor(int(r["num_clashes"][0])),
               "tr_score": torch.from_numpy(r["final_scores"][:, 0:3].copy()),
               "rot_score": torch.from_numpy(r["final_scores"][:, 3:6].copy())}
@@ -170,7 +171,8 @@ def sample_trajectories(model: Score_Model, batch, num_samples=120, num_steps=40
         b = min(max_batch, num_samples - done)
         outs.append(cx.sample(B=b, num_steps=num_steps, eps=eps, tr_noise_scale=tr_noise_scale,
                               rot_noise_scale=rot_noise_scale, noise_annealing=noise_annealing,
-                              use_clash_force=use_clash_force, seed=seed + done, bf16=model.precision == "bf16"))
+                              use_clash_force=use_clash_force, seed=seed + done, bf16=model.precision == "bf16",
+                              f16=model.precision == "f16"))
         done += b
     res = {k: np.concatenate([o[k] for o in outs], 0) for k in ("lig_pos", "rot_update", "tr_update", "energy", "num_clashes")}
     res["best"] = int(np.argmin(res["energy"]))     # `if outputs["energy"] < min_energy` keeps the first minimum

@@ -66,13 +66,14 @@ typedef struct {
 
 /* flags for dfm_score / dfm_sample */
 enum {
-    DFM_F_BF16 = 1u << 0,            /* per-edge contractions on bf16 MFMA (default: exact fp32) */
+    DFM_F_BF16 = 1u << 0,            /* per-edge contractions on bf16 MFMA (default without flag: exact fp32) */
     DFM_F_ENERGY = 1u << 1,          /* dfm_score: also evaluate the energy head                 */
     DFM_F_NOISE_ANNEALING = 1u << 2, /* inference_base.py:428-430                                */
     DFM_F_CLASH_FORCE = 1u << 3,     /* inference_base.py:458-461                                */
     DFM_F_ODE = 1u << 4,             /* so3_diffuser.py:367-368                                  */
     DFM_F_PROFILE = 1u << 5,         /* time the dominant kernel with HIP events (dfm_get_profile) */
-    DFM_F_STEP_ENERGY = 1u << 6      /* dfm_sample: evaluate the energy head on every step (traces) */
+    DFM_F_STEP_ENERGY = 1u << 6,     /* dfm_sample: evaluate the energy head on every step (traces) */
+    DFM_F_F16 = 1u << 7              /* like DFM_F_BF16 but with fp16 MFMA operands (11-bit mantissa, same rate) */
 };
 
 /* Output of dfm_score.  Required: tr_score, rot_score.  Any other pointer may be NULL. */
