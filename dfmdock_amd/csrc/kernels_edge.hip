@@ -11,6 +11,7 @@
 //   k_edge_bf16 : 256x256 contraction on v_mfma_f32_32x32x16_bf16, fp32 accumulate; A-fragments are
 //                 built in registers straight from the gathers, the weight matrix lives in LDS for the
 //                 whole (persistent) workgroup.
+#include <cstdio>
 #include <cstdlib>
 
 #include <hip/hip_fp16.h>
@@ -42,6 +43,7 @@ struct EdgeKArgs {
     int last;
     float *fout;
     uint16_t *mbuf;
+    long long *tl;   // DFM_TIMELINE debug: per-phase s_memtime stamps of wave 0 / workgroup 0 (nullptr normally)
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -193,7 +195,17 @@ constexpr int LDS_STAGE_BYTES = 32 * 64 * 2;       // 4096 per wave: 32 rows x 6
 constexpr int EDGE_WAVES = 8;                      // waves per workgroup (two per SIMD, 256 registers each)
 constexpr int LDS_EDGE_BYTES = LDS_WF_BYTES + 8 * LDS_STAGE_BYTES;   // 163840 = the whole CU
 
+typedef float f2 __attribute__((ext_vector_type(2)));   // packed fp32 pair -> v_pk_{mul,add,fma}_f32 (2 results / instr)
 __device__ inline float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// SiLU of two values: 3 packed ops + 2 v_exp_f32 + 2 v_rcp_f32
+__device__ inline f2 silu2(f2 x)
+{
+    const f2 y = x * (f2){-1.44269504088896f, -1.44269504088896f};
+    f2 e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+    e = e + (f2){1.0f, 1.0f};
+    const f2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    return x * r;
+}
 __device__ inline float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ inline void acc8(float (&v)[8], const uint4 &q)
@@ -235,7 +247,7 @@ template <int F16> __device__ inline uint16_t to16(float x)
     else return __builtin_bit_cast(uint16_t, (__bf16)x);
 }
 
-template <int MODE, int F16>     // MODE 0: edge messages (+ store of gated messages on the last layer), 1: coordinate MLP
+template <int MODE, int F16, int TL = 0>   // MODE 0: edge messages (+ store of gated messages on the last layer), 1: coordinate MLP
                                  // F16 0: bf16 MFMA operands, 1: fp16 MFMA operands (3 more mantissa bits, same rate)
 __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 {
@@ -261,10 +273,17 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
     const float *bias_v = MODE == 0 ? p.b2 : p.bc1;       // bias of this contraction
     const float *dot_v = MODE == 0 ? p.att_w : p.wc2;     // att_w / wc2
 
-    for (long long tt = (long long)slot * EDGE_WAVES + wave; tt < ntask; tt += (long long)wg_per_xcd * EDGE_WAVES) {
-        const int u = xcd + 8 * (int)(tt / NTc);
+    int tl_tile = 0;
+    auto stamp = [&](int k) {
+        if constexpr (TL) {
+            if (blockIdx.x == 8 && wave == 0 && tl_tile < 64 && lane == 0) p.tl[tl_tile * 16 + k] = clock64();
+        }
+    };
+    for (unsigned tt = (unsigned)slot * EDGE_WAVES + wave; tt < (unsigned)ntask; tt += (unsigned)wg_per_xcd * EDGE_WAVES) {
+        const unsigned tq = tt / (unsigned)NTc, tr = tt - tq * (unsigned)NTc;
+        const int u = xcd + 8 * (int)tq;
         const int b = __builtin_amdgcn_readfirstlane(u / nsplit);                    // wave-uniform -> SGPRs
-        const int idx = __builtin_amdgcn_readfirstlane((u % nsplit) * NTc + (int)(tt % NTc));
+        const int idx = __builtin_amdgcn_readfirstlane((u % nsplit) * NTc + (int)tr);
         if (idx >= NT) continue;
         const int i = (MODE == 0 ? 0 : p.R) + idx;
         const size_t node = (size_t)b * p.N + i;
@@ -276,13 +295,13 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
         float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // MODE 1: sum_s cdiff * w
 
         for (int mt = 0; mt < ntile; ++mt) {
-            f32x16 acc[8];   // accumulators start at the bias of this contraction (saves the epilogue add)
+            stamp(0);
+            f32x16 acc[8];
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const float bias = bias_v[nt * 32 + l31];
+            for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][r] = bias;
-            }
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            float bv[8], dv[8];   // bias / dot vector of the epilogue, fetched under the last MFMA phase
 
             if (MODE == 0) {
                 // per-pass row data: pass q handles rows mt*32 + q*8 + r8 (rows >= K: self edge, code 0 - finite filler)
@@ -315,25 +334,25 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     r.t2 = *reinterpret_cast<const uint4 *>(p.T2b + (i2 + ch));
                 };
                 auto compute_store = [&](int q, const RawP &r) {
-                    const float rad = radq[q];
-                    float v[8] = {fmaf(w0.x, rad, a0.x), fmaf(w0.y, rad, a0.y), fmaf(w0.z, rad, a0.z), fmaf(w0.w, rad, a0.w),
-                                  fmaf(w1.x, rad, a1.x), fmaf(w1.y, rad, a1.y), fmaf(w1.z, rad, a1.z), fmaf(w1.w, rad, a1.w)};
-                    // three table rows summed as packed fp16 (v_pk_add_f16), then widened once
-                    H8 t, t1, t2;
-                    t.u = r.t0; t1.u = r.t1; t2.u = r.t2;
+                    const f2 rad2 = {radq[q], radq[q]};
+                    f2 v[4] = {(f2){w0.x, w0.y} * rad2 + (f2){a0.x, a0.y}, (f2){w0.z, w0.w} * rad2 + (f2){a0.z, a0.w},
+                               (f2){w1.x, w1.y} * rad2 + (f2){a1.x, a1.y}, (f2){w1.z, w1.w} * rad2 + (f2){a1.z, a1.w}};
+                    // table rows (and, with bf16 operands, Bm too) summed as packed fp16, then widened once
+                    H8 t, t1, t2, bm;
+                    t.u = r.t0; t1.u = r.t1; t2.u = r.t2; bm.u = r.bm;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t.h[e] = __hadd2(__hadd2(t.h[e], t1.h[e]), t2.h[e]);
-                    H8 bm;
-                    bm.u = r.bm;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[2 * e] += __low2float(bm.h[e]); v[2 * e + 1] += __high2float(bm.h[e]); }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[2 * e] += __low2float(t.h[e]); v[2 * e + 1] += __high2float(t.h[e]); }
+                    for (int e = 0; e < 4; ++e) {
+                        t.h[e] = __hadd2(__hadd2(t.h[e], t1.h[e]), t2.h[e]);
+                        if constexpr (!F16) t.h[e] = __hadd2(t.h[e], bm.h[e]);
+                        else v[e] = v[e] + (f2){__low2float(bm.h[e]), __high2float(bm.h[e])};
+                        v[e] = v[e] + (f2){__low2float(t.h[e]), __high2float(t.h[e])};
+                    }
                     Frag f;   // rows >= K hold finite filler, gated to 0 below
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        if constexpr (F16) f.f[e] = (_Float16)fminf(silu_fast(v[e]), 65504.f);
-                        else f.b[e] = (__bf16)silu_fast(v[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const f2 m = silu2(v[e]);
+                        if constexpr (F16) { f.f[2 * e] = (_Float16)fminf(m.x, 65504.f); f.f[2 * e + 1] = (_Float16)fminf(m.y, 65504.f); }
+                        else { f.b[2 * e] = (__bf16)m.x; f.b[2 * e + 1] = (__bf16)m.y; }
                     }
                     const int row = q * 8 + r8;
                     *reinterpret_cast<uint4 *>(stage + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = f.u;
@@ -343,15 +362,10 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 RawP r0, r1, r2, r3;
                 gather_chunk(0);
                 gather(0, 0, r0); gather(0, 1, r1); gather(0, 2, r2); gather(0, 3, r3);
-#pragma unroll 1
-                for (int kc = 0; kc < 4; ++kc) {
-                    const int kn = kc < 3 ? kc + 1 : 3;
-                    compute_store(0, r0); if (kc < 3) gather(kn, 0, r0);
-                    compute_store(1, r1); if (kc < 3) gather(kn, 1, r1);
-                    compute_store(2, r2); if (kc < 3) gather(kn, 2, r2);
-                    compute_store(3, r3); if (kc < 3) gather(kn, 3, r3);
-                    if (kc < 3) gather_chunk(kn);
+                stamp(1);
+                auto mfma_chunk = [&](int kc) {
                     wave_lds_fence();
+                    stamp(3 + 2 * kc);
 #pragma unroll
                     for (int kq = 0; kq < 4; ++kq) {
                         Frag af;
@@ -364,7 +378,22 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                         }
                     }
                     wave_lds_fence();
+                    stamp(4 + 2 * kc);
+                };
+#pragma unroll 1
+                for (int kc = 0; kc < 3; ++kc) {
+                    compute_store(0, r0); gather(kc + 1, 0, r0);
+                    if (kc == 0) stamp(2);
+                    compute_store(1, r1); gather(kc + 1, 1, r1);
+                    compute_store(2, r2); gather(kc + 1, 2, r2);
+                    compute_store(3, r3); gather(kc + 1, 3, r3);
+                    gather_chunk(kc + 1);
+                    mfma_chunk(kc);
                 }
+                compute_store(0, r0); compute_store(1, r1); compute_store(2, r2); compute_store(3, r3);
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) { bv[nt] = bias_v[nt * 32 + l31]; dv[nt] = dot_v[nt * 32 + l31]; }
+                mfma_chunk(3);
             } else {
                 const int s = mt * 32 + l31;
                 const bool valid = s < K;
@@ -393,21 +422,28 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                         }
                     }
                 }
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) { bv[nt] = bias_v[nt * 32 + l31]; dv[nt] = dot_v[nt * 32 + l31]; }
             }
 
             // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) -------------
             float part[16];
+            {
+                f2 part2[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[r] = 0.f;
+                for (int q = 0; q < 8; ++q) part2[q] = (f2){0.f, 0.f};
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const float vv = dot_v[nt * 32 + l31];
+                for (int nt = 0; nt < 8; ++nt) {
+                    const f2 vv = {dv[nt], dv[nt]}, bb = {bv[nt], bv[nt]};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float m = silu_fast(acc[nt][r]);
-                    acc[nt][r] = m;
-                    part[r] = fmaf(m, vv, part[r]);
+                    for (int q = 0; q < 8; ++q) {
+                        const f2 m = silu2((f2){acc[nt][2 * q], acc[nt][2 * q + 1]} + bb);
+                        acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
+                        part2[q] = m * vv + part2[q];
+                    }
                 }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { part[2 * q] = part2[q].x; part[2 * q + 1] = part2[q].y; }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) part[r] = half_sum_dpp(part[r]);   // all 32 lanes of the half hold the row sum
@@ -431,10 +467,10 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 }
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
-                    float cs = 0.f;
+                    f2 cs = {0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) cs = fmaf(acc[nt][r], part[r], cs);
-                    colsum[nt] += cs;
+                    for (int q = 0; q < 8; ++q) cs = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){part[2 * q], part[2 * q + 1]} + cs;
+                    colsum[nt] += cs.x + cs.y;
                 }
             } else {
                 // coord_mlp: w = clamp(sum_c silu(.) * wc2, +-2); x_i += mean_s (x_i - x_j)/(|x_i - x_j| + 1) * w
@@ -454,6 +490,8 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     }
                 }
             }
+            stamp(11);
+            tl_tile += 1;
         }   // mt
 
         if (MODE == 0) {
@@ -489,7 +527,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.w_r = w->w_r; k.T = w->T; k.W2t = w->W2t; k.b2 = w->b2; k.att_w = w->att_w; k.T2b = w->T2b;
     k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
-    k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf;
+    k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.tl = nullptr;
     return k;
 }
 
@@ -519,6 +557,225 @@ static int persistent_grid(long long wave_tasks)
     return (int)g;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Edge-message kernel, software-pipelined ACROSS tiles (k_edge_bf16<0,.> restarts cold on every tile:
+// metadata load -> dependent gathers -> first SiLU, ~2 L2 latencies exposed per 32 rows).  Here the wave
+// walks one flat sequence of tiles (node, m-tile): during the last K-chunk of tile t it loads the row
+// metadata of tile t+1 into the registers the gathers no longer need, and it issues tile t+1's first
+// chunk of gathers right before tile t's epilogue, so both latencies hide under VALU/MFMA work.
+template <int F16, int NW>   // NW waves per workgroup: 8 (two per SIMD, 256 registers) or 4 (one per SIMD, 512 registers)
+__global__ __launch_bounds__(NW * 64) void k_edge_msg(EdgeKArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *Wf = reinterpret_cast<uint4 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char *stage = smem + LDS_WF_BYTES + wave * LDS_STAGE_BYTES;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    for (int q = tid; q < LDS_WF_BYTES / 16; q += NW * 64) Wf[q] = p.Wf[q];
+    __syncthreads();   // the only workgroup barrier: everything below is wave-private
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int NT = p.N;
+    const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;
+    const int NTc = (NT + nsplit - 1) / nsplit;
+    const int U = p.B * nsplit;
+    const int nb = U > xcd ? (U - xcd + 7) >> 3 : 0;
+    const long long ntask = (long long)nb * NTc;
+    const long long tstride = (long long)wg_per_xcd * NW;
+    const int K = p.K, ntile = (K + 31) >> 5;
+
+    struct Tile { int b, i, mt; };
+    long long tt = (long long)slot * NW + wave - tstride;
+    // next node task of this wave (wave-uniform); false when the list is exhausted
+    auto next_node = [&](Tile &t) -> bool {
+        for (;;) {
+            tt += tstride;
+            if (tt >= ntask) return false;
+            const int u = xcd + 8 * (int)(tt / NTc);
+            const int idx = (u % nsplit) * NTc + (int)(tt % NTc);
+            if (idx >= NT) continue;
+            t.b = __builtin_amdgcn_readfirstlane(u / nsplit);
+            t.i = __builtin_amdgcn_readfirstlane(idx);
+            t.mt = 0;
+            return true;
+        }
+    };
+    auto advance = [&](Tile &t) -> bool {
+        if (t.mt + 1 < ntile) { t.mt += 1; return true; }
+        return next_node(t);
+    };
+
+    Tile cur;
+    if (!next_node(cur)) return;
+
+    int jq[4]; uint32_t codeq[4]; float radq[4], radn[4];
+    auto load_meta = [&](const Tile &t, float (&rad)[4]) {
+        const size_t ebase = ((size_t)t.b * p.N + t.i) * K;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = t.mt * 32 + q * 8 + r8;
+            const bool v = s < K;
+            jq[q] = v ? p.edges[ebase + s] : t.i;
+            codeq[q] = v ? p.codes[ebase + s] : 0u;
+            rad[q] = v ? p.radial[ebase + s] : 0.f;
+        }
+    };
+    float4 a0, a1, w0, w1;
+    auto gather_chunk = [&](const Tile &t, int kc) {
+        const float *Arow = p.A + (size_t)t.b * p.ab_bstride + (size_t)t.i * H + kc * 64 + c8 * 8;
+        a0 = *reinterpret_cast<const float4 *>(Arow);
+        a1 = *reinterpret_cast<const float4 *>(Arow + 4);
+        w0 = *reinterpret_cast<const float4 *>(p.w_r + kc * 64 + c8 * 8);
+        w1 = *reinterpret_cast<const float4 *>(p.w_r + kc * 64 + c8 * 8 + 4);
+    };
+    auto gather = [&](const Tile &t, int kc, int q, RawP &r) {
+        const uint32_t ch = kc * 64 + c8 * 8;
+        const uint32_t code = codeq[q];
+        r.bm = *reinterpret_cast<const uint4 *>(p.Bmb + (size_t)t.b * p.ab_bstride + ((uint32_t)jq[q] * H + ch));
+        const uint32_t i0 = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * H;
+        const uint32_t i1 = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * H;
+        const uint32_t i2 = (1056u + ((code >> 20) & 127u)) * H;
+        r.t0 = *reinterpret_cast<const uint4 *>(p.T2b + (i0 + ch));
+        r.t1 = *reinterpret_cast<const uint4 *>(p.T2b + (i1 + ch));
+        r.t2 = *reinterpret_cast<const uint4 *>(p.T2b + (i2 + ch));
+    };
+    auto compute_store = [&](int q, const RawP &r) {
+        const f2 rad2 = {radq[q], radq[q]};
+        f2 v[4] = {(f2){w0.x, w0.y} * rad2 + (f2){a0.x, a0.y}, (f2){w0.z, w0.w} * rad2 + (f2){a0.z, a0.w},
+                   (f2){w1.x, w1.y} * rad2 + (f2){a1.x, a1.y}, (f2){w1.z, w1.w} * rad2 + (f2){a1.z, a1.w}};
+        H8 t, t1, t2, bm;
+        t.u = r.t0; t1.u = r.t1; t2.u = r.t2; bm.u = r.bm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t.h[e] = __hadd2(__hadd2(t.h[e], t1.h[e]), t2.h[e]);
+            if constexpr (!F16) t.h[e] = __hadd2(t.h[e], bm.h[e]);
+            else v[e] = v[e] + (f2){__low2float(bm.h[e]), __high2float(bm.h[e])};
+            v[e] = v[e] + (f2){__low2float(t.h[e]), __high2float(t.h[e])};
+        }
+        Frag f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f2 m = silu2(v[e]);
+            if constexpr (F16) { f.f[2 * e] = (_Float16)fminf(m.x, 65504.f); f.f[2 * e + 1] = (_Float16)fminf(m.y, 65504.f); }
+            else { f.b[2 * e] = (__bf16)m.x; f.b[2 * e + 1] = (__bf16)m.y; }
+        }
+        const int row = q * 8 + r8;
+        *reinterpret_cast<uint4 *>(stage + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = f.u;
+    };
+
+    RawP r0, r1, r2, r3;
+    load_meta(cur, radq);
+    gather_chunk(cur, 0);
+    gather(cur, 0, 0, r0); gather(cur, 0, 1, r1); gather(cur, 0, 2, r2); gather(cur, 0, 3, r3);
+    float colsum[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) colsum[nt] = 0.f;
+
+    for (;;) {
+        f32x16 acc[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            const float bias = p.b2[nt * 32 + l31];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = bias;
+        }
+        auto mfma_chunk = [&](int kc) {
+            wave_lds_fence();
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                Frag af;
+                af.u = *reinterpret_cast<const uint4 *>(stage + l31 * 128 + (((kq * 2 + h) ^ ((l31 >> 1) & 7)) << 4));
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    Frag bf;
+                    bf.u = Wf[((kc * 4 + kq) * 8 + nt) * 64 + lane];
+                    acc[nt] = mfma16<F16>(af, bf, acc[nt]);
+                }
+            }
+            wave_lds_fence();
+        };
+#pragma unroll 1
+        for (int kc = 0; kc < 3; ++kc) {
+            compute_store(0, r0); gather(cur, kc + 1, 0, r0);
+            compute_store(1, r1); gather(cur, kc + 1, 1, r1);
+            compute_store(2, r2); gather(cur, kc + 1, 2, r2);
+            compute_store(3, r3); gather(cur, kc + 1, 3, r3);
+            gather_chunk(cur, kc + 1);
+            mfma_chunk(kc);
+        }
+        // last chunk: jq / codeq are dead (all gathers of this tile are issued) -> fetch the next tile's metadata
+        Tile nxt = cur;
+        const bool has_next = advance(nxt);
+        if (has_next) load_meta(nxt, radn);
+        compute_store(0, r0); compute_store(1, r1); compute_store(2, r2); compute_store(3, r3);
+        mfma_chunk(3);
+        if (has_next) {   // half of the next tile's first chunk flies under this tile's epilogue (register budget)
+            gather_chunk(nxt, 0);
+            gather(nxt, 0, 0, r0); gather(nxt, 0, 1, r1);
+            if constexpr (NW == 4) { gather(nxt, 0, 2, r2); gather(nxt, 0, 3, r3); }
+        }
+
+        // ---- epilogue: lane owns columns nt*32 + l31, rows rowof(r) ------------------------------------
+        float part[16];
+        {
+            f2 part2[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) part2[q] = (f2){0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const float vs = p.att_w[nt * 32 + l31];
+                const f2 vv = {vs, vs};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f2 m = silu2((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
+                    acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
+                    part2[q] = m * vv + part2[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { part[2 * q] = part2[q].x; part[2 * q + 1] = part2[q].y; }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = cur.mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float g = half_sum_dpp(part[r]);
+            part[r] = row < K ? sigmoid_fast(g + p.att_b) : 0.f;   // attention gate; masked rows -> 0
+        }
+        if (p.last && cur.i >= p.R) {
+            uint16_t *Mout = p.mbuf + (((size_t)cur.b * p.L + (cur.i - p.R)) * KPAD) * H;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = cur.mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    Mout[(size_t)row * H + nt * 32 + l31] = to16<F16>(acc[nt][r] * part[r]);
+                }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            f2 cs = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){part[2 * q], part[2 * q + 1]} + cs;
+            colsum[nt] += cs.x + cs.y;
+        }
+        if (cur.mt == ntile - 1) {   // node complete: fixed-degree segment sum -> agg
+            const size_t node = (size_t)cur.b * p.N + cur.i;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const float t = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
+                if (h == 0) p.agg[node * H + nt * 32 + l31] = t;
+                colsum[nt] = 0.f;
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) radq[q] = radn[q];
+        if constexpr (NW != 4) { gather(cur, 0, 2, r2); gather(cur, 0, 3, r3); }
+    }
+}
+
 template <int MODE, int F16> static hipError_t launch_mfma_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
 {
     static bool attr_set = false;
@@ -532,14 +789,62 @@ template <int MODE, int F16> static hipError_t launch_mfma_t(const EdgeKArgs &k,
     return hipGetLastError();
 }
 
+static int persistent_grid_nw(long long wave_tasks, int nw)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    long long wgs = (wave_tasks + nw - 1) / nw;
+    long long g = wgs < cus ? wgs : cus;
+    return (int)((g + 7) / 8 * 8);
+}
+
+template <int F16, int NW> static hipError_t launch_msg_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_msg<F16, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_EDGE_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_edge_msg<F16, NW>), dim3(persistent_grid_nw(wave_tasks, NW)), dim3(NW * 64), LDS_EDGE_BYTES, s, k);
+    return hipGetLastError();
+}
+
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
+    // DFM_EDGE_PIPE (A/B timing): 0 = un-pipelined kernel, 8 / 4 = cross-tile pipelined kernel with 8 / 4 waves
+    static const int pipe = [] { const char *e = getenv("DFM_EDGE_PIPE"); return e ? atoi(e) : 0; }();
     EdgeKArgs k = to_kargs(a);
-    if (a.f16) {
-        k.Wf = reinterpret_cast<const uint4 *>(a.lw->W2f16);
-        return launch_mfma_t<0, 1>(k, (long long)a.B * a.N, s);
+    if (a.f16) k.Wf = reinterpret_cast<const uint4 *>(a.lw->W2f16);
+    const long long tasks = (long long)a.B * a.N;
+    static long long *tl_dev = nullptr;
+    static const int want_tl = [] { const char *e = getenv("DFM_TIMELINE"); return e ? atoi(e) : 0; }();
+    if (want_tl) {   // debug: one instrumented launch per call, stamps dumped to stderr
+        if (!tl_dev && hipMalloc(reinterpret_cast<void **>(&tl_dev), 64 * 16 * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(tl_dev, 0, 64 * 16 * 8, s);
+        k.tl = tl_dev;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_bf16<0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_EDGE_BYTES); attr = true; }
+        hipLaunchKernelGGL((k_edge_bf16<0, 0, 1>), dim3(persistent_grid(tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
+        static int dumped = 0;
+        if (dumped < 2) {
+            long long host[64 * 16];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(host, tl_dev, sizeof(host), hipMemcpyDeviceToHost);
+            for (int t = 4; t < 12; ++t) {
+                fprintf(stderr, "TL tile %2d:", t);
+                for (int q = 1; q < 12; ++q) fprintf(stderr, " %6lld", host[t * 16 + q] - host[t * 16 + q - 1]);
+                fprintf(stderr, "  | next-start gap %6lld\n", host[(t + 1) * 16] - host[t * 16 + 11]);
+            }
+            ++dumped;
+        }
+        return hipGetLastError();
     }
-    return launch_mfma_t<0, 0>(k, (long long)a.B * a.N, s);
+    if (pipe == 8) return a.f16 ? launch_msg_t<1, 8>(k, tasks, s) : launch_msg_t<0, 8>(k, tasks, s);
+    if (pipe == 4) return a.f16 ? launch_msg_t<1, 4>(k, tasks, s) : launch_msg_t<0, 4>(k, tasks, s);
+    return a.f16 ? launch_mfma_t<0, 1>(k, tasks, s) : launch_mfma_t<0, 0>(k, tasks, s);
 }
 
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
