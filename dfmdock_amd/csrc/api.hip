@@ -486,7 +486,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         g.A0 = h; g.A1 = W.agg; g.lda = H; g.K = 2 * H; g.pro = 1; g.W = Lw.W3; g.ldw = 2 * H; g.bias = Lw.b3;
         g.M = M; g.Nout = H; g.C = W.u; g.ldc = H;
         if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W3_hi, Lw.W3_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
-        HIPCHK(launch_gn_stats(W.u, B, N, Lw.gn_ms, W.gn_shift, W.gn_den, s));
+        HIPCHK(launch_gn_stats(W.u, B, N, Lw.gn_ms, W.gn_shift, W.gn_den, o.bf16 ? Lw.gn_w : nullptr, o.bf16 ? Lw.gn_b : nullptr, s));
         std::memset(&g, 0, sizeof(g));
         g.A0 = W.u; g.lda = H; g.K = H; g.pro = 2; g.gn_shift = W.gn_shift; g.gn_den = W.gn_den; g.gn_w = Lw.gn_w;
         g.gn_b = Lw.gn_b; g.rows_per_graph = N; g.W = Lw.W4; g.ldw = H; g.bias = Lw.b4; g.M = M; g.Nout = H;

@@ -122,8 +122,9 @@ hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s);
 
+// fold_w / fold_b non-null: write the folded affine (den := w/den, shift := b - w*shift/den) for launch_gemm_split
 hipError_t launch_gn_stats(const float *u, int B, int N, const float *mean_scale, float *shift, float *den,
-                           hipStream_t s);
+                           const float *fold_w, const float *fold_b, hipStream_t s);
 
 struct HeadArgs {
     const float *fvec;       // [B][L][3]

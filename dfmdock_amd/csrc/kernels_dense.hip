@@ -139,7 +139,8 @@ hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s)
 //   A W^T ~= Ahi Whi^T + Ahi Wlo^T + Alo Whi^T      (lo*lo dropped: ~2^-17 relative)
 // on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~1e-5 relative error at 3/16 of the f32-MFMA cost.
 // Weights are pre-split on the host ([Nout][K] hi and lo); activations are split while they are staged.
-// Same prologues / epilogues as k_gemm_f32.  Needs K % 32 == 0.
+// Same prologues / epilogues as k_gemm_f32, except that prologue 2 takes the folded GraphNorm affine
+// (gn_den := w/den, gn_shift := b - w*shift/den per graph and channel, see k_gn_stats fold=1).  Needs K % 32 == 0.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 union FragB { uint4 u; bf16x8 b; };
 constexpr int SK = 32, SLD = 40;   // K per stage; LDS row stride in bf16 (80 B: conflict-free ds_read_b128)
@@ -187,12 +188,17 @@ __global__ __launch_bounds__(256) void k_gemm_split(GemmSplitArgs sa)
                 const float4 v = *reinterpret_cast<const float4 *>(src + q * 4);
                 x[q * 4] = v.x; x[q * 4 + 1] = v.y; x[q * 4 + 2] = v.z; x[q * 4 + 3] = v.w;
             }
-            if (a.pro == 2) {   // GraphNorm + SiLU (egnn.py:72-76)
+            if (a.pro == 2) {   // GraphNorm + SiLU (egnn.py:72-76) as y = x * sc + sh with per-(graph, channel) sc, sh
+                const float *sc = a.gn_den + (size_t)g * H + k, *sh = a.gn_shift + (size_t)g * H + k;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int kk = k + e;
-                    const float o = x[e] - a.gn_shift[(size_t)g * H + kk];
-                    x[e] = silu_exact(a.gn_w[kk] * o / a.gn_den[(size_t)g * H + kk] + a.gn_b[kk]);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 c4 = *reinterpret_cast<const float4 *>(sc + q * 4), h4 = *reinterpret_cast<const float4 *>(sh + q * 4);
+                    const float y0 = fmaf(x[q * 4], c4.x, h4.x), y1 = fmaf(x[q * 4 + 1], c4.y, h4.y),
+                                y2 = fmaf(x[q * 4 + 2], c4.z, h4.z), y3 = fmaf(x[q * 4 + 3], c4.w, h4.w);
+                    x[q * 4] = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0));
+                    x[q * 4 + 1] = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1));
+                    x[q * 4 + 2] = y2 * __builtin_amdgcn_rcpf(1.0f + __expf(-y2));
+                    x[q * 4 + 3] = y3 * __builtin_amdgcn_rcpf(1.0f + __expf(-y3));
                 }
             }
         } else {
@@ -291,7 +297,8 @@ hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint1
 // Two exact passes in float64 (no E[x^2]-E[x]^2 cancellation), deterministic (no atomics).
 // grid (B, 4): each workgroup owns 64 channels of one trajectory; 256 threads = 4 row lanes x 64 channels.
 __global__ __launch_bounds__(256) void k_gn_stats(const float *__restrict__ u, int N, const float *__restrict__ mean_scale,
-                                                  float *__restrict__ shift, float *__restrict__ den)
+                                                  float *__restrict__ shift, float *__restrict__ den,
+                                                  const float *__restrict__ fold_w, const float *__restrict__ fold_b)
 {
     __shared__ double red[4][64];
     __shared__ float sh_shift[64];
@@ -319,14 +326,22 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float *__restrict__ u, i
     if (rl == 0) {
         const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         const float var = (float)(t / N);
-        shift[(size_t)b * H + c] = sft;
-        den[(size_t)b * H + c] = sqrtf(var + 1e-5f);
+        const float dn = sqrtf(var + 1e-5f);
+        if (fold_w) {   // y = w*(x - shift)/den + b  ==  x*sc + sh
+            const float sc = fold_w[c] / dn;
+            den[(size_t)b * H + c] = sc;
+            shift[(size_t)b * H + c] = fold_b[c] - sc * sft;
+        } else {
+            shift[(size_t)b * H + c] = sft;
+            den[(size_t)b * H + c] = dn;
+        }
     }
 }
 
-hipError_t launch_gn_stats(const float *u, int B, int N, const float *mean_scale, float *shift, float *den, hipStream_t s)
+hipError_t launch_gn_stats(const float *u, int B, int N, const float *mean_scale, float *shift, float *den,
+                           const float *fold_w, const float *fold_b, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gn_stats, dim3(B, 4), dim3(256), 0, s, u, N, mean_scale, shift, den);
+    hipLaunchKernelGGL(k_gn_stats, dim3(B, 4), dim3(256), 0, s, u, N, mean_scale, shift, den, fold_w, fold_b);
     return hipGetLastError();
 }
 
