@@ -45,6 +45,21 @@ def cpu_baseline(blob, cx, num_steps, n_forwards=8):
                       f"({dt:.1f} s), extrapolated"}
 
 
+def measured_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC run (profiles/r01_traffic.json);
+    PMC counters cannot be read from inside this process, so the number is attached only for the exact configuration
+    it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        t = json.load(open(path))
+    except OSError:
+        return None
+    c = t["config"]
+    if (c["R"], c["L"], c["batch"], c["precision"]) == (args.R, args.L, args.batch, args.precision):
+        return t["traffic_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +155,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": ("k_edge_bf16<0,%d>" % int(f16)) if mfma16 else "k_edge_f32", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
-                         "flop_per_launch": flop_per_launch, "traffic": None},
+                         "flop_per_launch": flop_per_launch, "traffic": measured_traffic(args),
+                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)"},
             "best_energy": float(D.rank_by_energy(allrec)[0][0, 2]),
         }
         if not args.no_cpu_baseline:
