@@ -56,6 +56,10 @@ def install_stubs():
     tgl = types.ModuleType("torch_geometric.loader")
     tgn.GraphNorm = GraphNorm
     tgl.DataLoader = object
+    tgd = types.ModuleType("torch_geometric.data")
+    tgd.HeteroData = type("HeteroData", (), {})
+    tg.data = tgd
+    sys.modules["torch_geometric.data"] = tgd
     tgnn.norm = tgn
     tg.nn = tgnn
     tg.loader = tgl
@@ -430,12 +434,44 @@ def gen_rollout(model, cx, name, num_steps, seed):
     save(name, **arrs)
 
 
+def gen_io_kats(cx7):
+    """f-1: reference DB5-set driver pieces that are pure functions: get_full_coords (inference_mlsb.py:68-85),
+    save_PDB text (utils/pdb.py:59-84), random_rotation (ppi_dataset.py:212-219) for a recorded rotation."""
+    import tempfile
+    import inference_mlsb as im
+    from utils.pdb import save_PDB
+    import datasets.ppi_dataset as pds
+    coords = torch.from_numpy(cx7["rec_pos"][:12].copy())
+    full = im.get_full_coords(coords)
+    seq = "MELKNSISDYTG"
+    with tempfile.NamedTemporaryFile("r", suffix=".pdb") as f:
+        save_PDB(out_pdb=f.name, coords=full, seq=seq, delim=6)
+        text = open(f.name).read()
+    rec = {}
+    orig = pds.Rotation
+
+    class R:
+        @staticmethod
+        def random():
+            r = orig.random()
+            rec["q"] = r.as_quat().copy()     # scalar-last
+            rec["m"] = r.as_matrix().copy()
+            return r
+    pds.Rotation = R
+    np.random.seed(5)
+    rp, lp = pds.random_rotation(torch.from_numpy(cx7["rec_pos"].copy()), torch.from_numpy(cx7["lig_pos"].copy()))
+    pds.Rotation = orig
+    save("io_kats.npz", coords=coords.numpy(), full=full.numpy(), seq=seq, pdb_text=text, rot_quat=rec["q"], rot_mat=rec["m"],
+         rot_rec=rp.numpy(), rot_lig=lp.numpy())
+
+
 def main():
     net = build_net(0)
     model = Model(net).eval()
     gen_scalar_kats(model)
     gen_geometry(make_complex(40, 30, seed=3))
     cx7 = gen_forward_cases(net)
+    gen_io_kats(cx7)
     cxs = make_complex(24, 16, seed=5)
     gen_rollout(model, cxs, "rollout_syn_24_16.npz", num_steps=40, seed=123)
     gen_rollout(model, make_complex(64, 48, seed=7), "rollout_syn_64_48.npz", num_steps=40, seed=321)

@@ -294,3 +294,89 @@ def test_reference_shaped_python_api(blob):
         m.so3_diffuser.sigma(1.2)
     res = sample_trajectories(m, batch, num_samples=10, num_steps=4, max_batch=4)
     assert res["lig_pos"].shape == (10, 127, 3, 3) and res["energy"][res["best"]] == res["energy"].min()
+
+
+@pytest.mark.parametrize("flag", ["noise_annealing", "ode"])
+def test_sampler_variants_vs_oracle(flag, model, blob):
+    """f-4: noise annealing (inference_base.py:428-430) and the ODE step (so3_diffuser.py:367-368) against the
+    oracle with every random draw injected."""
+    from oracle import oracle as ora
+    g = load_golden("rollout_syn_24_16.npz")
+    gx, cx = gpu_complex(model, "rollout_syn_24_16")
+    steps = 6
+    inj = dict(R0=g["R0"].astype(np.float32), tr_draw=g["tr_draw"], z_rot=g["z_rot"][:steps], z_tr=g["z_tr"][:steps],
+               edges=g["edges"][:steps + 1])
+    kw = {flag: True}
+    o = ora.Oracle(blob, cx).sample(num_steps=steps, inject=dict(inj, R0=g["R0"]), trace=True, **kw)
+    r = gx.sample(B=1, num_steps=steps, inject=inj, trace=True, **kw)
+    ca, ref = r["trace_pose"][0][:, :, 1, :], o["trace_pose"][:, :, 1, :]
+    rmsd = np.sqrt(((ca - ref) ** 2).sum(-1).mean(-1))
+    assert rmsd[:5].max() < 0.05 and rmsd.max() < 0.5, rmsd
+    np.testing.assert_allclose(r["tr_update"][0], o["tr_update"][0], atol=0.05 + 2 * rmsd.max())
+    assert abs(float(r["energy"][0]) - float(o["energy"])) < 5e-3 + abs(float(o["energy"])) * 0.05
+
+
+def test_clash_force_vs_oracle():
+    """a-17 / f-4: get_clash_force (inference_base.py:366-384).  Weights with vanishing score scales and zero
+    noise leave the closed-form repulsion as the only thing that moves the ligand, from a pose dropped onto
+    the receptor; the GPU trajectory must follow the oracle's."""
+    from dfmdock_amd import engine
+    from dfmdock_amd.weights import make_random_weights, pack_blob
+    from oracle import oracle as ora
+    w = make_random_weights(0)
+    w["tr_scale.4.weight"][:] = -4.0      # softplus(very negative) ~ 0: no score-driven motion
+    w["rot_scale.4.weight"][:] = -4.0
+    blob2 = pack_blob(w)
+    g = load_golden("rollout_7CEI.npz")
+    cx = complex_for("rollout_7CEI")
+    m2 = engine.Model(blob2)
+    gx = engine.Complex(m2, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    steps = 4
+    inj = dict(R0=np.eye(3, dtype=np.float32).reshape(1, 9), tr_draw=np.zeros((1, 3), np.float32), z_rot=g["z_rot"][:steps],
+               z_tr=g["z_tr"][:steps], edges=g["edges"][:steps + 1])
+    kw = dict(tr_noise_scale=0.0, rot_noise_scale=0.0, use_clash_force=True)
+    o = ora.Oracle(blob2, cx).sample(num_steps=steps, inject=dict(inj, R0=np.eye(3)), trace=True, **kw)
+    r = gx.sample(B=1, num_steps=steps, inject=inj, trace=True, **kw)
+    plain = gx.sample(B=1, num_steps=steps, inject=inj, trace=True, tr_noise_scale=0.0, rot_noise_scale=0.0)
+    moved = np.abs(plain["trace_pose"][0] - r["trace_pose"][0]).max(axis=(1, 2, 3))
+    assert moved[0] > 1e-2, moved                              # the repulsion is active from the first step
+    np.testing.assert_allclose(r["trace_pose"][0], o["trace_pose"], atol=2e-3)
+    np.testing.assert_allclose(r["tr_update"][0], o["tr_update"][0], atol=2e-3)
+    assert int(r["num_clashes"][0]) == int(o["num_clashes"])
+    gx.close(); m2.close()
+
+
+def test_set_driver_and_pair_driver(model, tmp_path):
+    """f-1 / a-15: the DB5-style sweep (CSV schema of inference_base.py:495-499, loader rotation, trajectory PDBs)
+    and the single-pair run (arg-min energy, all-atom pose, output.pdb) on synthetic complexes."""
+    import csv
+    from dfmdock_amd import driver, pdbio
+    from dfmdock_amd.synthetic import make_complex
+    cxs = []
+    for k, (R, L) in enumerate([(30, 22), (41, 17)]):
+        c = make_complex(R, L, seed=20 + k)
+        c.update(id=f"SYN{k}", rec_seq="A" * R, lig_seq="G" * L)
+        cxs.append(c)
+    out_csv = tmp_path / "csv" / "test.csv"
+    rows, ranked = driver.run_set(model, cxs, num_samples=5, num_steps=4, seed=3, out_csv=str(out_csv),
+                                  traj_dir=str(tmp_path / "trj"), max_batch=3)
+    assert len(rows) == 10 and set(ranked) == {0, 1}
+    got = list(csv.DictReader(open(out_csv)))
+    assert list(got[0].keys()) == driver.CSV_FIELDS and len(got) == 10
+    assert all(0.0 <= float(r["DockQ"]) <= 1.0 and float(r["l_rmsd"]) > 0 for r in got)
+    assert (np.diff(ranked[0][:, 2]) >= 0).all()
+    trj = (tmp_path / "trj" / "SYN0_p0.pdb").read_text()
+    assert trj.count("MODEL") == 4 and " CB  ALA A" in trj and " CB  GLY" not in trj
+    # pair driver: fake all-atom chains = backbone atoms
+    def chain(pos, resn, ch):
+        atoms = [{"hetero": False, "name": nm, "res_name": resn, "chain": ch, "res_id": r + 1, "ins": " ",
+                  "coord": tuple(pos[r, a]), "element": nm[0]} for r in range(pos.shape[0]) for a, nm in enumerate(("N", "CA", "C"))]
+        return pdbio.backbone_from_atoms(atoms)
+    c = cxs[0]
+    rec, lig = chain(c["rec_pos"], "ALA", "A"), chain(c["lig_pos"], "GLY", "B")
+    res = driver.dock_pair(model, rec, lig, c["rec_x"], c["lig_x"], num_samples=7, num_steps=4, seed=1,
+                           out_pdb=str(tmp_path / "output.pdb"), max_batch=4)
+    back = pdbio.read_pdb(str(tmp_path / "output.pdb"))
+    assert len(back) == 3 * (30 + 22)
+    lig_ca = np.array([a["coord"] for a in back if a["chain"] == "B" and a["name"] == "CA"])
+    np.testing.assert_allclose(lig_ca, res["lig_aa_coords"].reshape(-1, 3, 3)[:, 1], atol=6e-4)
