@@ -82,14 +82,20 @@ def main():
     from dfmdock_amd.weights import make_random_weights, pack_blob
 
     rank, local_rank, world = D.dist_env()
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = local_rank % ndev            # one process per GPU; the modulo only matters for single-GPU dry runs
+    backend = os.environ.get("DFM_DIST_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" for dry runs on one GPU
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=backend)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    engine.set_device(local_rank)
-    torch.cuda.set_device(local_rank)
+    engine.set_device(dev)
+    torch.cuda.set_device(dev)
 
     blob = pack_blob(make_random_weights(0))
     cx = make_complex(args.R, args.L, seed=1)
@@ -124,7 +130,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
