@@ -13,6 +13,7 @@
 //                 whole (persistent) workgroup.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include <hip/hip_fp16.h>
 
@@ -776,6 +777,237 @@ __global__ __launch_bounds__(NW * 64) void k_edge_msg(EdgeKArgs p)
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// "Weights in registers" edge-message kernel.
+//
+// The per-wave 32x256 tile of k_edge_bf16 needs 128 accumulator registers and the whole weight matrix in
+// LDS, which leaves two waves per SIMD starved of registers (no read-ahead, exposed LDS latency).  Here the
+// roles are turned around:
+//   * wave w of the 8-wave workgroup owns 32 OUTPUT channels for every node; its slice of the weight
+//     matrix (16 k-steps x 16 B/lane = 64 VGPRs) is loaded once and stays in registers for the launch;
+//   * the workgroup processes one node (64 rows: 60 edges + 4 masked) at a time.  Every wave produces 8 rows
+//     x 256 channels of the first activation (gather layout, whole 128-B lines) into a double-buffered,
+//     XOR-swizzled LDS tile [64][256] that all eight waves then consume;
+//   * the product is computed TRANSPOSED, D[channel][edge] = W[channel][k] * a1[edge][k]^T (weights as the
+//     MFMA A operand, the staged tile as B), so a lane holds 16 contiguous channels of ONE edge: the
+//     attention dot product is in-lane (+ one 8-way exchange through LDS), accumulators shrink to 32
+//     registers, and the 60-row segment sum is 16 DPP row reductions per wave;
+//   * one s_barrier per node: MFMAs of node n are issued interleaved with the producer VALU work of node
+//     n+1 (other half of the double buffer); gathers run one node ahead, row metadata two nodes ahead.
+constexpr int WR_WAVES = 8;
+constexpr int WR_TILE_BYTES = 64 * 256 * 2;                       // one staged node
+constexpr int WR_LDS_BYTES = 2 * WR_TILE_BYTES + 2 * 8 * 64 * 4;  // + double-buffered gate partials
+
+template <int F16>
+__global__ __launch_bounds__(WR_WAVES * 64) void k_edge_wr(EdgeKArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *gate_part = reinterpret_cast<float *>(smem + 2 * WR_TILE_BYTES);   // [2][8 waves][64 edges]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int prow = wave * 8 + r8;                  // the ONE row of the node this lane produces (all four passes)
+    const int K = p.K;
+
+    // resident weight slice: A-operand fragments, row rho <-> channel 32w + 16*((rho>>2)&1) + 4*(rho>>3) + (rho&3)
+    uint4 Wreg[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) Wreg[kk] = p.Wf[(kk * 8 + wave) * 64 + lane];
+    const int ch0 = wave * 32 + h * 16;              // this lane's 16 contiguous output channels
+
+    // node tasks of this workgroup (XCD-aware order, see k_edge_bf16)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int NT = p.N;
+    const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;
+    const int NTc = (NT + nsplit - 1) / nsplit;
+    const int U = p.B * nsplit;
+    const int nb = U > xcd ? (U - xcd + 7) >> 3 : 0;
+    const unsigned ntask = (unsigned)nb * (unsigned)NTc;
+    struct Node { int b, i; bool ok; };
+    auto node_at = [&](unsigned it) -> Node {        // it-th node of this workgroup; ok = false past the end / padding
+        const unsigned tt = (unsigned)slot + it * (unsigned)wg_per_xcd;
+        Node n{0, 0, false};
+        if (tt >= ntask) return n;
+        const unsigned tq = tt / (unsigned)NTc, tr = tt - tq * (unsigned)NTc;
+        const int u = xcd + 8 * (int)tq;
+        const int idx = (u % nsplit) * NTc + (int)tr;
+        n.b = u / nsplit; n.i = idx; n.ok = idx < NT;
+        return n;
+    };
+    const unsigned niter = ntask > (unsigned)slot ? (ntask - slot + wg_per_xcd - 1) / wg_per_xcd : 0;
+    if (niter == 0) return;
+
+    struct Meta { int j; uint32_t code; float rad; };
+    auto load_meta = [&](const Node &n) -> Meta {
+        Meta m{n.i, 0u, 0.f};
+        if (n.ok && prow < K) {
+            const size_t e = ((size_t)n.b * p.N + n.i) * K + prow;
+            m.j = p.edges[e]; m.code = p.codes[e]; m.rad = p.radial[e];
+        }
+        return m;
+    };
+    auto gather = [&](const Node &n, const Meta &m, int q, RawP &r) {
+        const uint32_t ch = q * 64 + c8 * 8;
+        const size_t ab = (size_t)n.b * p.ab_bstride;
+        r.bm = *reinterpret_cast<const uint4 *>(p.Bmb + ab + ((uint32_t)m.j * H + ch));
+        const uint32_t code = m.code;
+        const uint32_t i0 = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * H;
+        const uint32_t i1 = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * H;
+        const uint32_t i2 = (1056u + ((code >> 20) & 127u)) * H;
+        r.t0 = *reinterpret_cast<const uint4 *>(p.T2b + (i0 + ch));
+        r.t1 = *reinterpret_cast<const uint4 *>(p.T2b + (i1 + ch));
+        r.t2 = *reinterpret_cast<const uint4 *>(p.T2b + (i2 + ch));
+    };
+    // one producer pass: 8 channels of this lane's row -> SiLU -> 16-bit -> staged tile
+    auto compute_store = [&](const Node &n, float rad, int q, const RawP &r, char *tile) {
+        const float *Arow = p.A + (size_t)n.b * p.ab_bstride + (size_t)n.i * H + q * 64 + c8 * 8;
+        const float4 a0 = *reinterpret_cast<const float4 *>(Arow), a1 = *reinterpret_cast<const float4 *>(Arow + 4);
+        const float4 w0 = *reinterpret_cast<const float4 *>(p.w_r + q * 64 + c8 * 8);
+        const float4 w1 = *reinterpret_cast<const float4 *>(p.w_r + q * 64 + c8 * 8 + 4);
+        const f2 rad2 = {rad, rad};
+        f2 v[4] = {(f2){w0.x, w0.y} * rad2 + (f2){a0.x, a0.y}, (f2){w0.z, w0.w} * rad2 + (f2){a0.z, a0.w},
+                   (f2){w1.x, w1.y} * rad2 + (f2){a1.x, a1.y}, (f2){w1.z, w1.w} * rad2 + (f2){a1.z, a1.w}};
+        H8 t, t1, t2, bm;
+        t.u = r.t0; t1.u = r.t1; t2.u = r.t2; bm.u = r.bm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t.h[e] = __hadd2(__hadd2(t.h[e], t1.h[e]), t2.h[e]);
+            if constexpr (!F16) t.h[e] = __hadd2(t.h[e], bm.h[e]);
+            else v[e] = v[e] + (f2){__low2float(bm.h[e]), __high2float(bm.h[e])};
+            v[e] = v[e] + (f2){__low2float(t.h[e]), __high2float(t.h[e])};
+        }
+        Frag f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f2 m = silu2(v[e]);
+            if constexpr (F16) { f.f[2 * e] = (_Float16)fminf(m.x, 65504.f); f.f[2 * e + 1] = (_Float16)fminf(m.y, 65504.f); }
+            else { f.b[2 * e] = (__bf16)m.x; f.b[2 * e + 1] = (__bf16)m.y; }
+        }
+        *reinterpret_cast<uint4 *>(tile + prow * 512 + (((q * 8 + c8) ^ (prow & 15)) << 4)) = f.u;
+    };
+
+    // ---- prologue: stage node 0, start the pipeline --------------------------------------------------
+    Node n0 = node_at(0), n1 = node_at(1), n2 = node_at(2);
+    Meta m0 = load_meta(n0), m1 = load_meta(n1), m2 = load_meta(n2);
+    RawP r0, r1, r2, r3;
+    gather(n0, m0, 0, r0); gather(n0, m0, 1, r1); gather(n0, m0, 2, r2); gather(n0, m0, 3, r3);
+    compute_store(n0, m0.rad, 0, r0, smem); gather(n1, m1, 0, r0);
+    compute_store(n0, m0.rad, 1, r1, smem); gather(n1, m1, 1, r1);
+    compute_store(n0, m0.rad, 2, r2, smem); gather(n1, m1, 2, r2);
+    compute_store(n0, m0.rad, 3, r3, smem); gather(n1, m1, 3, r3);
+    __syncthreads();
+
+    Node cur = n0, nx1 = n1, nx2 = n2;         // node being contracted, node being produced, node being gathered
+    Meta mx1 = m1, mx2 = m2;
+    for (unsigned it = 0; it < niter; ++it) {
+        char *tile_c = smem + (it & 1) * WR_TILE_BYTES, *tile_n = smem + ((it + 1) & 1) * WR_TILE_BYTES;
+        float *gp = gate_part + (it & 1) * 512;
+        const Node nx3 = node_at(it + 3);
+        const Meta mx3 = load_meta(nx3);            // metadata runs two nodes ahead of its gathers' consumers
+
+        // ---- contraction of `cur` (32 MFMAs) interleaved with the producer passes of `nx1` -----------------
+        f32x16 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        auto mfma_quarter = [&](int q4) {
+#pragma unroll
+            for (int kk = q4 * 4; kk < q4 * 4 + 4; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int row = mt * 32 + l31;
+                    Frag bf, af;
+                    bf.u = *reinterpret_cast<const uint4 *>(tile_c + row * 512 + (((kk * 2 + h) ^ (row & 15)) << 4));
+                    af.u = Wreg[kk];
+                    acc[mt] = mfma16<F16>(af, bf, acc[mt]);
+                }
+        };
+        // (padding tasks can sit in the middle of the list, so every stage is predicated on its own node)
+        if (nx1.ok) compute_store(nx1, mx1.rad, 0, r0, tile_n);
+        gather(nx2, mx2, 0, r0); mfma_quarter(0);
+        if (nx1.ok) compute_store(nx1, mx1.rad, 1, r1, tile_n);
+        gather(nx2, mx2, 1, r1); mfma_quarter(1);
+        if (nx1.ok) compute_store(nx1, mx1.rad, 2, r2, tile_n);
+        gather(nx2, mx2, 2, r2); mfma_quarter(2);
+        if (nx1.ok) compute_store(nx1, mx1.rad, 3, r3, tile_n);
+        gather(nx2, mx2, 3, r3); mfma_quarter(3);
+
+        // ---- epilogue part 1: bias, SiLU, partial attention logits of this wave's 32 channels --------------
+        float4 bq[4], dq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bq[q] = *reinterpret_cast<const float4 *>(p.b2 + ch0 + q * 4);
+            dq[q] = *reinterpret_cast<const float4 *>(p.att_w + ch0 + q * 4);
+        }
+        float pg[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f2 s2 = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f2 ma = silu2((f2){acc[mt][4 * q], acc[mt][4 * q + 1]} + (f2){bq[q].x, bq[q].y});
+                const f2 mb = silu2((f2){acc[mt][4 * q + 2], acc[mt][4 * q + 3]} + (f2){bq[q].z, bq[q].w});
+                acc[mt][4 * q] = ma.x; acc[mt][4 * q + 1] = ma.y; acc[mt][4 * q + 2] = mb.x; acc[mt][4 * q + 3] = mb.y;
+                s2 = ma * (f2){dq[q].x, dq[q].y} + s2;
+                s2 = mb * (f2){dq[q].z, dq[q].w} + s2;
+            }
+            pg[mt] = s2.x + s2.y;
+            pg[mt] += __shfl_xor(pg[mt], 32, 64);
+            if (h == 0) gp[wave * 64 + mt * 32 + l31] = pg[mt];
+        }
+        __syncthreads();   // tile_n complete, gate partials complete, every wave done reading tile_c
+
+        // ---- epilogue part 2: gate, fixed-degree segment sum -----------------------------------------------
+        if (cur.ok) {
+            f2 s2[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s2[q] = (f2){0.f, 0.f};
+            const bool store_m = p.last && cur.i >= p.R;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int edge = mt * 32 + l31;
+                float g = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < 8; ++w2) g += gp[w2 * 64 + edge];
+                g = edge < K ? sigmoid_fast(g + p.att_b) : 0.f;
+                const f2 g2 = {g, g};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f2 mg = (f2){acc[mt][2 * q], acc[mt][2 * q + 1]} * g2;
+                    acc[mt][2 * q] = mg.x; acc[mt][2 * q + 1] = mg.y;
+                    s2[q] = s2[q] + mg;
+                }
+                if (store_m) {
+                    Frag o0, o1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if constexpr (F16) {
+                            o0.f[e] = (_Float16)fminf(fmaxf(acc[mt][e], -65504.f), 65504.f);
+                            o1.f[e] = (_Float16)fminf(fmaxf(acc[mt][8 + e], -65504.f), 65504.f);
+                        } else { o0.b[e] = (__bf16)acc[mt][e]; o1.b[e] = (__bf16)acc[mt][8 + e]; }
+                    }
+                    uint16_t *Mo = p.mbuf + ((((size_t)cur.b * p.L + (cur.i - p.R)) * KPAD) + edge) * H + ch0;
+                    *reinterpret_cast<uint4 *>(Mo) = o0.u;
+                    *reinterpret_cast<uint4 *>(Mo + 8) = o1.u;
+                }
+            }
+            float sum[16];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { sum[2 * q] = half_sum_dpp(s2[q].x); sum[2 * q + 1] = half_sum_dpp(s2[q].y); }
+            if (l31 == 0) {
+                float *ao = p.agg + ((size_t)cur.b * p.N + cur.i) * H + ch0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(ao + q * 4) = make_float4(sum[4 * q], sum[4 * q + 1], sum[4 * q + 2], sum[4 * q + 3]);
+            }
+        }
+        cur = nx1; nx1 = nx2; nx2 = nx3;
+        mx1 = mx2; mx2 = mx3;
+    }
+}
+
 template <int MODE, int F16> static hipError_t launch_mfma_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
 {
     static bool attr_set = false;
@@ -812,38 +1044,45 @@ template <int F16, int NW> static hipError_t launch_msg_t(const EdgeKArgs &k, lo
     return hipGetLastError();
 }
 
+template <int F16> static hipError_t launch_wr_t(const EdgeKArgs &k, long long nodes, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_wr<F16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    long long g = nodes < cus ? nodes : cus;
+    g = (g + 7) / 8 * 8;
+    hipLaunchKernelGGL((k_edge_wr<F16>), dim3((unsigned)g), dim3(WR_WAVES * 64), WR_LDS_BYTES, s, k);
+    return hipGetLastError();
+}
+
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    // DFM_EDGE_PIPE (A/B timing): 0 = un-pipelined kernel, 8 / 4 = cross-tile pipelined kernel with 8 / 4 waves
-    static const int pipe = [] { const char *e = getenv("DFM_EDGE_PIPE"); return e ? atoi(e) : 0; }();
+    // DFM_EDGE_KERNEL (A/B timing): "wr" = weights-in-registers kernel, "tile" = per-wave 32x256 tile kernel,
+    // "pipe8"/"pipe4" = cross-tile pipelined tile kernel
+    static const int which = [] {
+        const char *e = getenv("DFM_EDGE_KERNEL");
+        if (!e) return 0;
+        if (!strcmp(e, "wr")) return 1;
+        if (!strcmp(e, "pipe8")) return 8;
+        if (!strcmp(e, "pipe4")) return 4;
+        return 0;
+    }();
     EdgeKArgs k = to_kargs(a);
-    if (a.f16) k.Wf = reinterpret_cast<const uint4 *>(a.lw->W2f16);
     const long long tasks = (long long)a.B * a.N;
-    static long long *tl_dev = nullptr;
-    static const int want_tl = [] { const char *e = getenv("DFM_TIMELINE"); return e ? atoi(e) : 0; }();
-    if (want_tl) {   // debug: one instrumented launch per call, stamps dumped to stderr
-        if (!tl_dev && hipMalloc(reinterpret_cast<void **>(&tl_dev), 64 * 16 * 8) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemsetAsync(tl_dev, 0, 64 * 16 * 8, s);
-        k.tl = tl_dev;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_bf16<0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_EDGE_BYTES); attr = true; }
-        hipLaunchKernelGGL((k_edge_bf16<0, 0, 1>), dim3(persistent_grid(tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
-        static int dumped = 0;
-        if (dumped < 2) {
-            long long host[64 * 16];
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(host, tl_dev, sizeof(host), hipMemcpyDeviceToHost);
-            for (int t = 4; t < 12; ++t) {
-                fprintf(stderr, "TL tile %2d:", t);
-                for (int q = 1; q < 12; ++q) fprintf(stderr, " %6lld", host[t * 16 + q] - host[t * 16 + q - 1]);
-                fprintf(stderr, "  | next-start gap %6lld\n", host[(t + 1) * 16] - host[t * 16 + 11]);
-            }
-            ++dumped;
-        }
-        return hipGetLastError();
+    if (which == 1) {
+        k.Wf = reinterpret_cast<const uint4 *>(a.f16 ? a.lw->W2t16 : a.lw->W2tb);
+        return a.f16 ? launch_wr_t<1>(k, tasks, s) : launch_wr_t<0>(k, tasks, s);
     }
-    if (pipe == 8) return a.f16 ? launch_msg_t<1, 8>(k, tasks, s) : launch_msg_t<0, 8>(k, tasks, s);
-    if (pipe == 4) return a.f16 ? launch_msg_t<1, 4>(k, tasks, s) : launch_msg_t<0, 4>(k, tasks, s);
+    if (a.f16) k.Wf = reinterpret_cast<const uint4 *>(a.lw->W2f16);
+    if (which == 8) return a.f16 ? launch_msg_t<1, 8>(k, tasks, s) : launch_msg_t<0, 8>(k, tasks, s);
+    if (which == 4) return a.f16 ? launch_msg_t<1, 4>(k, tasks, s) : launch_msg_t<0, 4>(k, tasks, s);
     return a.f16 ? launch_mfma_t<0, 1>(k, tasks, s) : launch_mfma_t<0, 0>(k, tasks, s);
 }
 
