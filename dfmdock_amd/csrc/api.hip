@@ -228,13 +228,17 @@ static std::vector<uint16_t> pack_frags_wr(const float *W /*[256 out][256 in]*/,
                 }
     return f;
 }
-static void split_bf16(const float *W, size_t n, std::vector<uint16_t> &hi, std::vector<uint16_t> &lo)
+// split-bf16 operands of k_gemm_split, tiled in K-stage order: [K/32][Nout][32] (W is [Nout][K] row-major)
+static void split_bf16(const float *W, int Nout, int K, std::vector<uint16_t> &hi, std::vector<uint16_t> &lo)
 {
-    hi.resize(n); lo.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        hi[i] = f2bf(W[i]);
-        lo[i] = f2bf(W[i] - bf2f(hi[i]));
-    }
+    hi.resize((size_t)Nout * K); lo.resize((size_t)Nout * K);
+    for (int o = 0; o < Nout; ++o)
+        for (int k = 0; k < K; ++k) {
+            const float w = W[(size_t)o * K + k];
+            const size_t d = ((size_t)(k / 32) * Nout + o) * 32 + (k % 32);
+            hi[d] = f2bf(w);
+            lo[d] = f2bf(w - bf2f(hi[d]));
+        }
 }
 static std::vector<float> transpose256(const float *W)
 {
@@ -313,9 +317,9 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
         up(&D.W4, Lw.n2_w, (size_t)H * H); up(&D.b4, Lw.n2_b, H);
         {
             std::vector<uint16_t> hi, lo;
-            split_bf16(Wab.data(), Wab.size(), hi, lo); up16(&D.Wab_hi, hi); up16(&D.Wab_lo, lo);
-            split_bf16(Lw.n1_w, (size_t)H * 2 * H, hi, lo); up16(&D.W3_hi, hi); up16(&D.W3_lo, lo);
-            split_bf16(Lw.n2_w, (size_t)H * H, hi, lo); up16(&D.W4_hi, hi); up16(&D.W4_lo, lo);
+            split_bf16(Wab.data(), 2 * H, H, hi, lo); up16(&D.Wab_hi, hi); up16(&D.Wab_lo, lo);
+            split_bf16(Lw.n1_w, H, 2 * H, hi, lo); up16(&D.W3_hi, hi); up16(&D.W3_lo, lo);
+            split_bf16(Lw.n2_w, H, H, hi, lo); up16(&D.W4_hi, hi); up16(&D.W4_lo, lo);
         }
         if (Lw.c1_w) {
             const std::vector<float> Wc1t = transpose256(Lw.c1_w);
@@ -516,7 +520,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             const LayerDev &Ln = m->layers[l + 1];
             std::memset(&g, 0, sizeof(g));
             g.A0 = h; g.lda = H; g.K = H; g.W = Ln.Wab; g.ldw = H; g.bias = Ln.bias_ab; g.M = M; g.Nout = 2 * H;
-            g.epi = 2; g.C = W.A; g.ldc = H; g.C2 = W.Bm; g.C2b = W.Bmb;
+            g.epi = 2; g.C = W.A; g.ldc = H; g.C2 = o.bf16 ? nullptr : W.Bm; g.C2b = W.Bmb;   // 16-bit engines gather the fp16 copy only
             if (o.bf16) HIPCHK(launch_gemm_split(g, Ln.Wab_hi, Ln.Wab_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         }
     }

@@ -9,6 +9,7 @@
 //
 // Tile: 128 x 128 per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles),
 // K staged 16 at a time through LDS as [k][row] so that fragment reads are conflict-free ds_read_b32.
+#include <cstdlib>
 #include "dfm_device.h"
 #include "dfm_internal.h"
 
@@ -138,16 +139,23 @@ hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s)
 // Split-bf16 variant for the bf16 engine: x = hi + lo (two bf16 values, 16 mantissa bits), and
 //   A W^T ~= Ahi Whi^T + Ahi Wlo^T + Alo Whi^T      (lo*lo dropped: ~2^-17 relative)
 // on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~1e-5 relative error at 3/16 of the f32-MFMA cost.
-// Weights are pre-split on the host ([Nout][K] hi and lo); activations are split while they are staged.
+//
+// The node-level layers are tall and skinny (M = B*N rows, K and Nout in {256, 512}) and HBM-bound, so one
+// workgroup owns a block of rows x 256 output columns: every activation is read, normalised/activated and split
+// exactly once per 256 outputs.  Weights are pre-split and pre-tiled on the host in stage order ([K/32][Nout][32]
+// bf16, hi and lo), so a K-stage of weights is one contiguous, L2-resident 16 KiB block.  Per K-stage of 32: the
+// next stage's global loads are issued into registers, then the MFMAs run from the LDS tiles (80-byte row stride:
+// conflict-free ds_read_b128).
 // Same prologues / epilogues as k_gemm_f32, except that prologue 2 takes the folded GraphNorm affine
-// (gn_den := w/den, gn_shift := b - w*shift/den per graph and channel, see k_gn_stats fold=1).  Needs K % 32 == 0.
+// (gn_den := w/den, gn_shift := b - w*shift/den per graph and channel, see k_gn_stats fold=1).
+// Needs K % 32 == 0, Nout % 256 == 0.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 union FragB { uint4 u; bf16x8 b; };
-constexpr int SK = 32, SLD = 40;   // K per stage; LDS row stride in bf16 (80 B: conflict-free ds_read_b128)
+constexpr int SN = 256, SK = 32, SLD = 40;   // output columns per workgroup; K per stage; LDS row stride in bf16
 
 struct GemmSplitArgs {
     GemmArgs g;
-    const uint16_t *Whi, *Wlo;   // [Nout][ldw] bf16
+    const uint16_t *Whi, *Wlo;   // [K/32][Nout][32] bf16 (split_bf16 in api.hip)
 };
 
 __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
@@ -157,137 +165,174 @@ __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
     return v.u;
 }
 
-__global__ __launch_bounds__(256) void k_gemm_split(GemmSplitArgs sa)
+// MT = 64-row groups per workgroup.  MT 2: 128 x 256 tile, waves 2 x 2 of 64 x 128 (60 KiB LDS, 2 workgroups / CU);
+// MT 1: 64 x 256 tile, waves 1 x 4 of 64 x 64 (50 KiB LDS, 3 workgroups / CU: more independent phases in flight).
+template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm_split(GemmSplitArgs sa)
 {
+    constexpr int SM = 64 * MT, WN = 4 / MT, NJ = 8 / WN;      // rows; waves along N; 32-column tiles per wave
     const GemmArgs &a = sa.g;
-    __shared__ __attribute__((aligned(16))) uint16_t Ah[BM * SLD], Al[BM * SLD], Wh[BN * SLD], Wl[BN * SLD];
+    __shared__ __attribute__((aligned(16))) uint16_t lds[(2 * SM + 2 * SN) * SLD];
+    uint16_t *Ah = lds, *Al = lds + SM * SLD, *Wh = lds + 2 * SM * SLD, *Wl = lds + (2 * SM + SN) * SLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
-    f32x16 acc[2][2];
+    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31;
+    const int row0 = blockIdx.x * SM, col0 = blockIdx.y * SN;
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int lr = tid >> 1, lk = (tid & 1) * 16;    // staging: thread owns 16 consecutive k of one row
+    // staging: thread owns 8 consecutive k (kg) of row ar (and ar + 64 when MT = 2); four lanes cover one row's 128-byte line
+    const int ar = tid >> 2, kg = (tid & 3) * 8;
     const int halfK = a.K >> 1;
-    const int grow = row0 + lr, gcol = col0 + lr;
-    const int g = a.pro == 2 && grow < a.M ? grow / a.rows_per_graph : 0;
+    const bool rv0 = row0 + ar < a.M, rv1 = MT == 2 && row0 + ar + 64 < a.M;
+    const size_t gr0 = (size_t)(rv0 ? row0 + ar : 0), gr1 = (size_t)(rv1 ? row0 + ar + 64 : 0);
+    const int g0 = a.pro == 2 ? (int)(gr0 / a.rows_per_graph) : 0, g1 = a.pro == 2 ? (int)(gr1 / a.rows_per_graph) : 0;
 
-    for (int k0 = 0; k0 < a.K; k0 += SK) {
-        float x[16];
-        if (grow < a.M) {
-            const int k = k0 + lk;
-            const float *src = (a.pro == 1 && k >= halfK) ? a.A1 + (size_t)grow * a.lda + (k - halfK)
-                                                          : a.A0 + (size_t)grow * a.lda + k;
+    // registers of the stage being fetched: activations (rows x 8 k) and 4 x 16 B of hi / lo weights
+    float4 xa0, xa1, xa2, xa3;
+    uint4 wh0, wh1, wh2, wh3, wl0, wl1, wl2, wl3;
+#define GEMM_SPLIT_FETCH(K0)                                                                                          \
+    {                                                                                                                 \
+        const int k_ = (K0) + kg;                                                                                     \
+        const float *base_ = (a.pro == 1 && k_ >= halfK) ? a.A1 + (k_ - halfK) : a.A0 + k_;                           \
+        const float *s0_ = base_ + gr0 * a.lda;                                                                       \
+        xa0 = *reinterpret_cast<const float4 *>(s0_); xa1 = *reinterpret_cast<const float4 *>(s0_ + 4);              \
+        if constexpr (MT == 2) {                                                                                      \
+            const float *s1_ = base_ + gr1 * a.lda;                                                                   \
+            xa2 = *reinterpret_cast<const float4 *>(s1_); xa3 = *reinterpret_cast<const float4 *>(s1_ + 4);          \
+        }                                                                                                             \
+        const size_t wbase_ = ((size_t)((K0) / SK) * a.Nout + col0) * SK;                                             \
+        const uint4 *ph_ = reinterpret_cast<const uint4 *>(sa.Whi + wbase_) + tid;                                    \
+        const uint4 *pl_ = reinterpret_cast<const uint4 *>(sa.Wlo + wbase_) + tid;                                    \
+        wh0 = ph_[0]; wh1 = ph_[256]; wh2 = ph_[512]; wh3 = ph_[768];                                                 \
+        wl0 = pl_[0]; wl1 = pl_[256]; wl2 = pl_[512]; wl3 = pl_[768];                                                 \
+    }
+    auto stage_row = [&](const float4 &v0, const float4 &v1, bool valid, int g, int k, int row) {
+        float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (a.pro == 2) {   // GraphNorm + SiLU (egnn.py:72-76) as y = x * sc + sh with per-(graph, channel) sc, sh
+            const float *sc = a.gn_den + (size_t)g * H + k, *sh = a.gn_shift + (size_t)g * H + k;
+            const float4 c0 = *reinterpret_cast<const float4 *>(sc), c1 = *reinterpret_cast<const float4 *>(sc + 4);
+            const float4 h0 = *reinterpret_cast<const float4 *>(sh), h1 = *reinterpret_cast<const float4 *>(sh + 4);
+            const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const float hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4 *>(src + q * 4);
-                x[q * 4] = v.x; x[q * 4 + 1] = v.y; x[q * 4 + 2] = v.z; x[q * 4 + 3] = v.w;
+            for (int e = 0; e < 8; ++e) {
+                const float y = fmaf(x[e], cc[e], hh[e]);
+                x[e] = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
             }
-            if (a.pro == 2) {   // GraphNorm + SiLU (egnn.py:72-76) as y = x * sc + sh with per-(graph, channel) sc, sh
-                const float *sc = a.gn_den + (size_t)g * H + k, *sh = a.gn_shift + (size_t)g * H + k;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 c4 = *reinterpret_cast<const float4 *>(sc + q * 4), h4 = *reinterpret_cast<const float4 *>(sh + q * 4);
-                    const float y0 = fmaf(x[q * 4], c4.x, h4.x), y1 = fmaf(x[q * 4 + 1], c4.y, h4.y),
-                                y2 = fmaf(x[q * 4 + 2], c4.z, h4.z), y3 = fmaf(x[q * 4 + 3], c4.w, h4.w);
-                    x[q * 4] = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0));
-                    x[q * 4 + 1] = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1));
-                    x[q * 4 + 2] = y2 * __builtin_amdgcn_rcpf(1.0f + __expf(-y2));
-                    x[q * 4 + 3] = y3 * __builtin_amdgcn_rcpf(1.0f + __expf(-y3));
-                }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x[e] = 0.f;
         }
-        uint32_t hi[8], lo[8];
+        uint32_t hi[4], lo[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const __bf16 h0 = (__bf16)x[2 * e], h1 = (__bf16)x[2 * e + 1];
+        for (int e = 0; e < 4; ++e) {
+            const float x0 = valid ? x[2 * e] : 0.f, x1 = valid ? x[2 * e + 1] : 0.f;
+            const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
             hi[e] = pack2(h0, h1);
-            lo[e] = pack2((__bf16)(x[2 * e] - (float)h0), (__bf16)(x[2 * e + 1] - (float)h1));
+            lo[e] = pack2((__bf16)(x0 - (float)h0), (__bf16)(x1 - (float)h1));
         }
-        uint4 whi0 = make_uint4(0, 0, 0, 0), whi1 = whi0, wlo0 = whi0, wlo1 = whi0;
-        if (gcol < a.Nout) {
-            const uint16_t *ph = sa.Whi + (size_t)gcol * a.ldw + k0 + lk, *pl = sa.Wlo + (size_t)gcol * a.ldw + k0 + lk;
-            whi0 = *reinterpret_cast<const uint4 *>(ph); whi1 = *reinterpret_cast<const uint4 *>(ph + 8);
-            wlo0 = *reinterpret_cast<const uint4 *>(pl); wlo1 = *reinterpret_cast<const uint4 *>(pl + 8);
-        }
-        __syncthreads();   // previous stage fully consumed
-        *reinterpret_cast<uint4 *>(&Ah[lr * SLD + lk]) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        *reinterpret_cast<uint4 *>(&Ah[lr * SLD + lk + 8]) = make_uint4(hi[4], hi[5], hi[6], hi[7]);
-        *reinterpret_cast<uint4 *>(&Al[lr * SLD + lk]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-        *reinterpret_cast<uint4 *>(&Al[lr * SLD + lk + 8]) = make_uint4(lo[4], lo[5], lo[6], lo[7]);
-        *reinterpret_cast<uint4 *>(&Wh[lr * SLD + lk]) = whi0;
-        *reinterpret_cast<uint4 *>(&Wh[lr * SLD + lk + 8]) = whi1;
-        *reinterpret_cast<uint4 *>(&Wl[lr * SLD + lk]) = wlo0;
-        *reinterpret_cast<uint4 *>(&Wl[lr * SLD + lk + 8]) = wlo1;
+        *reinterpret_cast<uint4 *>(&Ah[row * SLD + kg]) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4 *>(&Al[row * SLD + kg]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    };
+
+    const int wu = (tid >> 2) * SLD + (tid & 3) * 8;   // this thread's 16-byte unit of a weight stage block (+64 columns per q)
+    GEMM_SPLIT_FETCH(0)
+    for (int k0 = 0; k0 < a.K; k0 += SK) {
+        if (k0) __syncthreads();   // previous stage fully consumed
+        stage_row(xa0, xa1, rv0, g0, k0 + kg, ar);
+        if constexpr (MT == 2) stage_row(xa2, xa3, rv1, g1, k0 + kg, ar + 64);
+        *reinterpret_cast<uint4 *>(&Wh[wu]) = wh0; *reinterpret_cast<uint4 *>(&Wh[wu + 64 * SLD]) = wh1;
+        *reinterpret_cast<uint4 *>(&Wh[wu + 128 * SLD]) = wh2; *reinterpret_cast<uint4 *>(&Wh[wu + 192 * SLD]) = wh3;
+        *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 64 * SLD]) = wl1;
+        *reinterpret_cast<uint4 *>(&Wl[wu + 128 * SLD]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 192 * SLD]) = wl3;
         __syncthreads();
+        if (k0 + SK < a.K) GEMM_SPLIT_FETCH(k0 + SK)         // flies under the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < SK; ks += 16) {
             const int ko = ks + (lane >> 5) * 8;
-            FragB ah[2], al[2], wh[2], wl[2];
+            FragB ah[2], al[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int r = wm * 64 + i * 32 + (lane & 31);
+                const int r = wm * 64 + i * 32 + l31;
                 ah[i].u = *reinterpret_cast<const uint4 *>(&Ah[r * SLD + ko]);
                 al[i].u = *reinterpret_cast<const uint4 *>(&Al[r * SLD + ko]);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = wn * 64 + j * 32 + (lane & 31);
-                wh[j].u = *reinterpret_cast<const uint4 *>(&Wh[c * SLD + ko]);
-                wl[j].u = *reinterpret_cast<const uint4 *>(&Wl[c * SLD + ko]);
-            }
+            for (int j = 0; j < NJ; ++j) {
+                const int c = (wn * NJ + j) * 32 + l31;
+                FragB wh, wl;
+                wh.u = *reinterpret_cast<const uint4 *>(&Wh[c * SLD + ko]);
+                wl.u = *reinterpret_cast<const uint4 *>(&Wl[c * SLD + ko]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].b, wh[j].b, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wl[j].b, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wh[j].b, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].b, wh.b, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wl.b, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wh.b, acc[i][j], 0, 0, 0);
                 }
+            }
         }
     }
+    // epilogue: the C layout (lane = column, registers = rows) would need scalar stores, and the kernel is then bound
+    // by store issue.  Each wave instead transposes its outputs through a private LDS region (the operand tiles are
+    // dead by now) in 32 x 64 passes and stores 16-byte vectors, 256 B per row.
+    __syncthreads();
+    constexpr int ELD = 68;                               // floats per staged row (64 + 4 padding)
+    float *est = reinterpret_cast<float *>(lds) + wave * (32 * ELD);   // 8704 B per wave
+    const int er = lane >> 4, ec = (lane & 15) * 4;       // read-back: 4 rows x 16 float4 per instruction
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = col0 + wn * 64 + j * 32 + (lane & 31);
-            if (col >= a.Nout) continue;
-            const float bias = a.bias ? a.bias[col] : 0.f;
+        for (int jp = 0; jp < NJ / 2; ++jp) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= a.M) continue;
-                const float v = acc[i][j][r] + bias;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = jp * 2 + jj;
+                const float bias = a.bias ? a.bias[col0 + (wn * NJ + j) * 32 + l31] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    est[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * ELD + jj * 32 + l31] = acc[i][j][r] + bias;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int lr = q * 4 + er;
+                const float4 v = *reinterpret_cast<const float4 *>(est + lr * ELD + ec);
+                const size_t row = (size_t)row0 + wm * 64 + i * 32 + lr;
+                const int col = col0 + (wn * NJ + jp * 2) * 32 + ec;
+                if (row >= (size_t)a.M) continue;
                 if (a.epi == 1) {
-                    a.C[(size_t)row * a.ldc + col] = a.R[(size_t)row * a.ldc + col] + v;
+                    const float4 rr = *reinterpret_cast<const float4 *>(a.R + row * a.ldc + col);
+                    *reinterpret_cast<float4 *>(a.C + row * a.ldc + col) = make_float4(rr.x + v.x, rr.y + v.y, rr.z + v.z, rr.w + v.w);
                 } else if (a.epi == 2) {
-                    if (col < H) a.C[(size_t)row * H + col] = v;
+                    if (col0 < H) *reinterpret_cast<float4 *>(a.C + row * H + col) = v;
                     else {
-                        a.C2[(size_t)row * H + (col - H)] = v;
-                        if (a.C2b) a.C2b[(size_t)row * H + (col - H)] = f2h(v);
+                        if (a.C2) *reinterpret_cast<float4 *>(a.C2 + row * H + (col - H)) = v;
+                        if (a.C2b) {
+                            uint2 o;
+                            o.x = (uint32_t)f2h(v.x) | ((uint32_t)f2h(v.y) << 16);
+                            o.y = (uint32_t)f2h(v.z) | ((uint32_t)f2h(v.w) << 16);
+                            *reinterpret_cast<uint2 *>(a.C2b + row * H + (col - H)) = o;
+                        }
                     }
                 } else {
-                    a.C[(size_t)row * a.ldc + col] = v;
+                    *reinterpret_cast<float4 *>(a.C + row * a.ldc + col) = v;
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
 }
+#undef GEMM_SPLIT_FETCH
 
 hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s)
 {
-    if (a.K % SK != 0 || (a.pro == 1 && (a.K / 2) % 16 != 0)) return hipErrorInvalidValue;
+    if (a.K % SK != 0 || a.Nout % SN != 0 || (a.pro == 1 && (a.K / 2) % SK != 0) || a.lda % 4 != 0 || a.ldc % 4 != 0)
+        return hipErrorInvalidValue;
     GemmSplitArgs sa;
     sa.g = a; sa.Whi = Whi; sa.Wlo = Wlo;
-    const dim3 grid((a.M + BM - 1) / BM, (a.Nout + BN - 1) / BN);
-    hipLaunchKernelGGL(k_gemm_split, grid, dim3(256), 0, s, sa);
+    static int mt = 0;
+    if (!mt) { const char *e = getenv("DFM_GEMM_MT"); mt = e && atoi(e) == 2 ? 2 : 1; }
+    if (mt == 2) hipLaunchKernelGGL(k_gemm_split<2>, dim3((a.M + 127) / 128, a.Nout / SN), dim3(256), 0, s, sa);
+    else hipLaunchKernelGGL(k_gemm_split<1>, dim3((a.M + 63) / 64, a.Nout / SN), dim3(256), 0, s, sa);
     return hipGetLastError();
 }
 

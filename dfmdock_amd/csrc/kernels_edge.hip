@@ -360,9 +360,9 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 };
                 // every pass owns one raw buffer that is refilled in place for the NEXT chunk right after it is
                 // consumed: a whole chunk of gathers (16 x 1 KiB per wave) flies under the 32 MFMAs of this chunk
-                RawP r0, r1, r2, r3;
+                RawP r0, r1;
                 gather_chunk(0);
-                gather(0, 0, r0); gather(0, 1, r1); gather(0, 2, r2); gather(0, 3, r3);
+                gather(0, 0, r0); gather(0, 1, r1);
                 stamp(1);
                 auto mfma_chunk = [&](int kc) {
                     wave_lds_fence();
@@ -381,19 +381,23 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     wave_lds_fence();
                     stamp(4 + 2 * kc);
                 };
+                // two raw buffers in a ring: the gathers of pass q+2 fly under the arithmetic of passes q, q+1 (and the
+                // MFMA phase when they cross a chunk boundary)
 #pragma unroll 1
                 for (int kc = 0; kc < 3; ++kc) {
-                    compute_store(0, r0); gather(kc + 1, 0, r0);
+                    compute_store(0, r0); gather(kc, 2, r0);
                     if (kc == 0) stamp(2);
-                    compute_store(1, r1); gather(kc + 1, 1, r1);
-                    compute_store(2, r2); gather(kc + 1, 2, r2);
-                    compute_store(3, r3); gather(kc + 1, 3, r3);
+                    compute_store(1, r1); gather(kc, 3, r1);
+                    compute_store(2, r0); gather(kc + 1, 0, r0);
+                    compute_store(3, r1); gather(kc + 1, 1, r1);
                     gather_chunk(kc + 1);
                     mfma_chunk(kc);
                 }
-                compute_store(0, r0); compute_store(1, r1); compute_store(2, r2); compute_store(3, r3);
+                compute_store(0, r0); gather(3, 2, r0);
+                compute_store(1, r1); gather(3, 3, r1);
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) { bv[nt] = bias_v[nt * 32 + l31]; dv[nt] = dot_v[nt * 32 + l31]; }
+                compute_store(2, r0); compute_store(3, r1);
                 mfma_chunk(3);
             } else {
                 const int s = mt * 32 + l31;
