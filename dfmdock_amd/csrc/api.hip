@@ -228,14 +228,14 @@ static std::vector<uint16_t> pack_frags_wr(const float *W /*[256 out][256 in]*/,
                 }
     return f;
 }
-// split-bf16 operands of k_gemm_split, tiled in K-stage order: [K/32][Nout][32] (W is [Nout][K] row-major)
+// split-bf16 operands of k_gemm_split, tiled in K-stage order: [K/32][4 k-groups][Nout][8] (W is [Nout][K] row-major)
 static void split_bf16(const float *W, int Nout, int K, std::vector<uint16_t> &hi, std::vector<uint16_t> &lo)
 {
     hi.resize((size_t)Nout * K); lo.resize((size_t)Nout * K);
     for (int o = 0; o < Nout; ++o)
         for (int k = 0; k < K; ++k) {
             const float w = W[(size_t)o * K + k];
-            const size_t d = ((size_t)(k / 32) * Nout + o) * 32 + (k % 32);
+            const size_t d = (((size_t)(k / 32) * 4 + (k % 32) / 8) * Nout + o) * 8 + (k % 8);
             hi[d] = f2bf(w);
             lo[d] = f2bf(w - bf2f(hi[d]));
         }

@@ -142,8 +142,8 @@ hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s)
 //
 // The node-level layers are tall and skinny (M = B*N rows, K and Nout in {256, 512}) and HBM-bound, so one
 // workgroup owns a block of rows x 256 output columns: every activation is read, normalised/activated and split
-// exactly once per 256 outputs.  Weights are pre-split and pre-tiled on the host in stage order ([K/32][Nout][32]
-// bf16, hi and lo), so a K-stage of weights is one contiguous, L2-resident 16 KiB block.  Per K-stage of 32: the
+// exactly once per 256 outputs.  Weights are pre-split and pre-tiled on the host in stage order ([K/32][4 k-groups][Nout][8]
+// bf16, hi and lo): coalesced 16-byte loads, L2-resident, and consecutive lanes write consecutive LDS rows.  Per K-stage of 32: the
 // next stage's global loads are issued into registers, then the MFMAs run from the LDS tiles (80-byte row stride:
 // conflict-free ds_read_b128).
 // Same prologues / epilogues as k_gemm_f32, except that prologue 2 takes the folded GraphNorm affine
@@ -155,7 +155,7 @@ constexpr int SN = 256, SK = 32, SLD = 40;   // output columns per workgroup; K 
 
 struct GemmSplitArgs {
     GemmArgs g;
-    const uint16_t *Whi, *Wlo;   // [K/32][Nout][32] bf16 (split_bf16 in api.hip)
+    const uint16_t *Whi, *Wlo;   // [K/32][4][Nout][8] bf16 (split_bf16 in api.hip)
 };
 
 __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
@@ -204,11 +204,13 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
             const float *s1_ = base_ + gr1 * a.lda;                                                                   \
             xa2 = *reinterpret_cast<const float4 *>(s1_); xa3 = *reinterpret_cast<const float4 *>(s1_ + 4);          \
         }                                                                                                             \
-        const size_t wbase_ = ((size_t)((K0) / SK) * a.Nout + col0) * SK;                                             \
-        const uint4 *ph_ = reinterpret_cast<const uint4 *>(sa.Whi + wbase_) + tid;                                    \
-        const uint4 *pl_ = reinterpret_cast<const uint4 *>(sa.Wlo + wbase_) + tid;                                    \
-        wh0 = ph_[0]; wh1 = ph_[256]; wh2 = ph_[512]; wh3 = ph_[768];                                                 \
-        wl0 = pl_[0]; wl1 = pl_[256]; wl2 = pl_[512]; wl3 = pl_[768];                                                 \
+        const size_t wbase_ = ((size_t)((K0) / SK) * 4 * a.Nout + col0 + tid) * 8;                                    \
+        const size_t wq_ = (size_t)a.Nout * 8;                                                                        \
+        const uint16_t *ph_ = sa.Whi + wbase_, *pl_ = sa.Wlo + wbase_;                                                \
+        wh0 = *reinterpret_cast<const uint4 *>(ph_); wh1 = *reinterpret_cast<const uint4 *>(ph_ + wq_);               \
+        wh2 = *reinterpret_cast<const uint4 *>(ph_ + 2 * wq_); wh3 = *reinterpret_cast<const uint4 *>(ph_ + 3 * wq_); \
+        wl0 = *reinterpret_cast<const uint4 *>(pl_); wl1 = *reinterpret_cast<const uint4 *>(pl_ + wq_);               \
+        wl2 = *reinterpret_cast<const uint4 *>(pl_ + 2 * wq_); wl3 = *reinterpret_cast<const uint4 *>(pl_ + 3 * wq_); \
     }
     auto stage_row = [&](const float4 &v0, const float4 &v1, bool valid, int g, int k, int row) {
         float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -236,16 +238,16 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
         *reinterpret_cast<uint4 *>(&Al[row * SLD + kg]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     };
 
-    const int wu = (tid >> 2) * SLD + (tid & 3) * 8;   // this thread's 16-byte unit of a weight stage block (+64 columns per q)
+    const int wu = tid * SLD;   // weights: thread = output column, q = 8-k group (consecutive lanes -> consecutive LDS rows: conflict-free)
     GEMM_SPLIT_FETCH(0)
     for (int k0 = 0; k0 < a.K; k0 += SK) {
         if (k0) __syncthreads();   // previous stage fully consumed
         stage_row(xa0, xa1, rv0, g0, k0 + kg, ar);
         if constexpr (MT == 2) stage_row(xa2, xa3, rv1, g1, k0 + kg, ar + 64);
-        *reinterpret_cast<uint4 *>(&Wh[wu]) = wh0; *reinterpret_cast<uint4 *>(&Wh[wu + 64 * SLD]) = wh1;
-        *reinterpret_cast<uint4 *>(&Wh[wu + 128 * SLD]) = wh2; *reinterpret_cast<uint4 *>(&Wh[wu + 192 * SLD]) = wh3;
-        *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 64 * SLD]) = wl1;
-        *reinterpret_cast<uint4 *>(&Wl[wu + 128 * SLD]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 192 * SLD]) = wl3;
+        *reinterpret_cast<uint4 *>(&Wh[wu]) = wh0; *reinterpret_cast<uint4 *>(&Wh[wu + 8]) = wh1;
+        *reinterpret_cast<uint4 *>(&Wh[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&Wh[wu + 24]) = wh3;
+        *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
+        *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
         __syncthreads();
         if (k0 + SK < a.K) GEMM_SPLIT_FETCH(k0 + SK)         // flies under the MFMAs below
 #pragma unroll
@@ -277,8 +279,8 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     // by store issue.  Each wave instead transposes its outputs through a private LDS region (the operand tiles are
     // dead by now) in 32 x 64 passes and stores 16-byte vectors, 256 B per row.
     __syncthreads();
-    constexpr int ELD = 68;                               // floats per staged row (64 + 4 padding)
-    float *est = reinterpret_cast<float *>(lds) + wave * (32 * ELD);   // 8704 B per wave
+    constexpr int ELD = 72;                               // floats per staged row (64 + 8: the half-waves, 4 rows apart, hit disjoint banks)
+    float *est = reinterpret_cast<float *>(lds) + wave * (32 * ELD);   // 9216 B per wave
     const int er = lane >> 4, ec = (lane & 15) * 4;       // read-back: 4 rows x 16 float4 per instruction
 #pragma unroll
     for (int i = 0; i < 2; ++i)
