@@ -342,44 +342,54 @@ hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint1
 // GraphNorm statistics per trajectory and channel (torch_geometric 2.6.0 graph_norm.py, batch=None):
 //   mean = mean_n u ;  shift = mean * mean_scale ;  var = mean_n (u - shift)^2 ;  den = sqrt(var + 1e-5)
 // Two exact passes in float64 (no E[x^2]-E[x]^2 cancellation), deterministic (no atomics).
-// grid (B, 4): each workgroup owns 64 channels of one trajectory; 256 threads = 4 row lanes x 64 channels.
+// grid (B, 4): each workgroup owns 64 channels of one trajectory; 256 threads = 16 row lanes x 16 float4 channel quads
+// (a wave instruction reads four 256-byte row segments; the second pass re-reads the 150 KB slab from L2).
 __global__ __launch_bounds__(256) void k_gn_stats(const float *__restrict__ u, int N, const float *__restrict__ mean_scale,
                                                   float *__restrict__ shift, float *__restrict__ den,
                                                   const float *__restrict__ fold_w, const float *__restrict__ fold_b)
 {
-    __shared__ double red[4][64];
+    __shared__ double red[16][64];
     __shared__ float sh_shift[64];
-    const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-    const float *U = u + (size_t)b * N * H;
-    double s = 0;
-    for (int n = rl; n < N; n += 4) s += U[(size_t)n * H + c];
-    red[rl][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rl == 0) {
-        const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        const float mean = (float)(t / N);
-        sh_shift[threadIdx.x] = mean * mean_scale[c];
+    const int b = blockIdx.x, cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c0 = blockIdx.y * 64;
+    const float *U = u + (size_t)b * N * H + c0 + cq * 4;
+    auto reduce_rows = [&](const double (&s)[4]) {     // fixed-order sum over the 16 row lanes -> red[0][channel]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[rl][cq * 4 + e] = s[e];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            double t = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+            red[0][threadIdx.x] = t;
+        }
+        __syncthreads();
+    };
+    double s[4] = {0, 0, 0, 0};
+    for (int n = rl; n < N; n += 16) {
+        const float4 v = *reinterpret_cast<const float4 *>(U + (size_t)n * H);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
     }
+    reduce_rows(s);
+    if (threadIdx.x < 64) sh_shift[threadIdx.x] = (float)(red[0][threadIdx.x] / N) * mean_scale[c0 + threadIdx.x];
     __syncthreads();
-    const float sft = sh_shift[threadIdx.x & 63];
-    double v = 0;
-    for (int n = rl; n < N; n += 4) {
-        const float o = U[(size_t)n * H + c] - sft;
-        v += (double)o * o;
+    const float4 sft = *reinterpret_cast<const float4 *>(&sh_shift[cq * 4]);
+    double v2[4] = {0, 0, 0, 0};
+    for (int n = rl; n < N; n += 16) {
+        const float4 v = *reinterpret_cast<const float4 *>(U + (size_t)n * H);
+        const float o0 = v.x - sft.x, o1 = v.y - sft.y, o2 = v.z - sft.z, o3 = v.w - sft.w;
+        v2[0] += (double)o0 * o0; v2[1] += (double)o1 * o1; v2[2] += (double)o2 * o2; v2[3] += (double)o3 * o3;
     }
-    __syncthreads();
-    red[rl][threadIdx.x & 63] = v;
-    __syncthreads();
-    if (rl == 0) {
-        const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        const float var = (float)(t / N);
-        const float dn = sqrtf(var + 1e-5f);
+    reduce_rows(v2);
+    if (threadIdx.x < 64) {
+        const int c = c0 + threadIdx.x;
+        const float var = (float)(red[0][threadIdx.x] / N);
+        const float dn = sqrtf(var + 1e-5f), sf = sh_shift[threadIdx.x];
         if (fold_w) {   // y = w*(x - shift)/den + b  ==  x*sc + sh
             const float sc = fold_w[c] / dn;
             den[(size_t)b * H + c] = sc;
-            shift[(size_t)b * H + c] = fold_b[c] - sc * sft;
+            shift[(size_t)b * H + c] = fold_b[c] - sc * sf;
         } else {
-            shift[(size_t)b * H + c] = sft;
+            shift[(size_t)b * H + c] = sf;
             den[(size_t)b * H + c] = dn;
         }
     }

@@ -72,16 +72,18 @@ hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, i
 // key: ascending distance, lowest index first on ties, slot 0 = the node itself.  The sampled slots
 // are an exponential race: key_j = Exp(1)_j * d_j^3, the 40 smallest keys = successive sampling
 // without replacement with p ~ d^-3 (the scheme torch.multinomial uses), Exp(1) from Philox4x32-10.
-__device__ inline unsigned long long wave_min_u64(unsigned long long v)
+// wave-wide unsigned minimum, result wave-uniform: 4 DPP steps inside each 16-lane row, ds_swizzle across the row
+// pair, then the two 32-lane halves meet in scalar registers
+__device__ inline uint32_t wave_min_u32(uint32_t v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)v, m, 64);
-        const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
-        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-        v = o < v ? o : v;
-    }
-    return v;
+    auto step = [](uint32_t x, uint32_t y) { return x < y ? x : y; };
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v = step(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));   // row_mirror
+    v = step(v, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));                           // lane ^ 16
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+    return a < b ? a : b;
 }
 
 template <int NPL>
@@ -138,26 +140,20 @@ __global__ __launch_bounds__(256) void k_knn_sample(const float4 *__restrict__ c
                 }
             }
         }
-        // lane-local arg-min
-        unsigned long long best = ~0ull;
+        // arg-min of (value, j) over the wave, ties to the smallest j.  Values are non-negative floats, so their bit
+        // patterns order like unsigned integers: min value first (32-bit), then the smallest j that holds it.
+        uint32_t mv = 0xFFFFFFFFu;
 #pragma unroll
-        for (int q = 0; q < NPL / 4; ++q)
+        for (int r = 0; r < NPL; ++r) { const uint32_t k = __float_as_uint(val[r]); mv = k < mv ? k : mv; }
+        const uint32_t wm = wave_min_u32(mv);
+        int rb = NPL;                          // this lane's first slot holding the minimum (slots ascend with j inside a lane)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = q * 4 + e;
-                const unsigned j = 4u * (lane + 64 * q) + e;
-                const unsigned long long k = ((unsigned long long)__float_as_uint(val[r]) << 32) | j;
-                best = k < best ? k : best;
-            }
-        best = wave_min_u64(best);
-        const int win = (int)(unsigned)best;
+        for (int r = NPL - 1; r >= 0; --r) rb = __float_as_uint(val[r]) == wm ? r : rb;
+        const uint32_t jb = rb < NPL ? 4u * (uint32_t)lane + 256u * (uint32_t)(rb >> 2) + (uint32_t)(rb & 3) : 0xFFFFFFFFu;
+        const int win = (int)wave_min_u32(jb);
+        rb = (int)jb == win ? rb : NPL;        // only the owner removes its slot
 #pragma unroll
-        for (int q = 0; q < NPL / 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = 4 * (lane + 64 * q) + e;
-                if (j == win) val[q * 4 + e] = __builtin_inff();
-            }
+        for (int r = 0; r < NPL; ++r) val[r] = r == rb ? __builtin_inff() : val[r];
         if (lane == s) my_edge = win;
     }
     if (lane < K) edges[((size_t)b * N + i) * K + lane] = my_edge;
@@ -172,6 +168,7 @@ hipError_t launch_knn_sample(const float4 *ca4, int B, int N, int knn, int nsamp
 #define LAUNCH(NPL) hipLaunchKernelGGL(k_knn_sample<NPL>, grid, block, 0, s, ca4, B, N, knn, nsamp, lo, hi, stream_id, edges)
     if (N <= 256) LAUNCH(4);
     else if (N <= 512) LAUNCH(8);
+    else if (N <= 768) LAUNCH(12);
     else if (N <= 1024) LAUNCH(16);
     else if (N <= 2048) LAUNCH(32);
     else LAUNCH(64);
