@@ -38,6 +38,11 @@ class HParams:
     r3_max_sigma: float = 30.0
     so3_min_sigma: float = 0.1
     so3_max_sigma: float = 1.5
+    # model family: 0 = Score_Net (score_net_mlsb.py, the network inference_single.py loads),
+    #               1 = EGNN_Net behind DFMDock.forward (egnn_net.py:408-505, DFMDock.py:68-75): no coordinate update,
+    #                   pair-force / energy / confidence heads on [h_r, h_l, D]; configs/model/DFMDock.yaml
+    family: int = 0
+    agg_mean: bool = True      # EGNN_Net `agg`: 'mean' (True) or 'sum' pooling of pair energies / forces
 
     def as_dict(self):
         return asdict(self)
@@ -66,7 +71,7 @@ def param_specs(hp: HParams = HParams()):
             (p + "node_mlp.3.weight", (H, H)),
             (p + "node_mlp.3.bias", (H,)),
         ]
-        if l == hp.depth - 1:
+        if l == hp.depth - 1 and hp.family == 0:
             s += [
                 (p + "coord_mlp.0.weight", (H, H)),
                 (p + "coord_mlp.0.bias", (H,)),
@@ -76,11 +81,22 @@ def param_specs(hp: HParams = HParams()):
             (p + "att_mlp.0.weight", (1, H)),
             (p + "att_mlp.0.bias", (1,)),
         ]
+    if hp.family == 1:      # egnn_net.py:329-360: four pair heads on cat[h_r, h_l, D]
+        for head, nout in (("to_energy", 1), ("to_force", 1), ("to_dist", 64), ("to_confidence", 1)):
+            s += [
+                (head + ".0.weight", (H, 2 * H + 1)),
+                (head + ".1.weight", (H,)),
+                (head + ".1.bias", (H,)),
+                (head + ".3.weight", (nout, H)),
+            ]
+    else:
+        s += [
+            ("to_energy.0.weight", (H, 2 * H)),
+            ("to_energy.1.weight", (H,)),
+            ("to_energy.1.bias", (H,)),
+            ("to_energy.3.weight", (1, H)),
+        ]
     s += [
-        ("to_energy.0.weight", (H, 2 * H)),
-        ("to_energy.1.weight", (H,)),
-        ("to_energy.1.bias", (H,)),
-        ("to_energy.3.weight", (1, H)),
         ("to_ires.0.weight", (2 * H, H)),
         ("to_ires.0.bias", (2 * H,)),
         ("to_ires.2.weight", (2 * H, 2 * H)),
@@ -116,8 +132,8 @@ def make_random_weights(seed: int = 0, hp: HParams = HParams()) -> "OrderedDict[
             w = rng.standard_normal(shape)
         elif leaf == "mean_scale":
             w = 1.0 + 0.1 * rng.standard_normal(shape)
-        elif ("node_mlp.1." in name or "to_energy.1." in name
-              or "tr_scale.1." in name or "rot_scale.1." in name):
+        elif ("node_mlp.1." in name or "to_energy.1." in name or "to_force.1." in name or "to_dist.1." in name
+              or "to_confidence.1." in name or "tr_scale.1." in name or "rot_scale.1." in name):
             # GraphNorm / LayerNorm affine
             w = (1.0 + 0.1 * rng.standard_normal(shape)) if leaf == "weight" \
                 else 0.1 * rng.standard_normal(shape)
@@ -137,6 +153,9 @@ def make_random_weights(seed: int = 0, hp: HParams = HParams()) -> "OrderedDict[
             if name.endswith("edge_mlp.0.weight"):
                 # column 2H multiplies radial = |x_i-x_j|^2 (up to ~1e4 A^2)
                 w[:, 2 * H] = rng.standard_normal(shape[0]) * 2e-3
+            elif hp.family == 1 and name.endswith(".0.weight") and name.startswith("to_") and shape[-1] == 2 * H + 1:
+                # column 2H multiplies the CA distance D (up to ~1e2 A)
+                w[:, 2 * H] = rng.standard_normal(shape[0]) * 2e-2
         out[name] = np.ascontiguousarray(w, dtype=np.float32)
     return out
 
@@ -246,5 +265,10 @@ def load_lightning_checkpoint(path):
             v = _cfg_get(model_cfg, f)
             if isinstance(v, (int, float)):
                 kw[f] = type(getattr(hp, f))(v)
+        if "to_force.0.weight" in out:      # EGNN_Net checkpoint (DFMDock.yaml: mask 20 A, agg)
+            kw["family"] = 1
+            kw["mask_dist"] = 20.0
+            agg = _cfg_get(model_cfg, "agg")
+            kw["agg_mean"] = (agg != "sum")
         hp = HParams(**{**hp.as_dict(), **kw})
     return out, hp

@@ -33,6 +33,8 @@ typedef struct {
     const float *single_embed, *spatial_embed, *positional_embed;
     layer_w layer[16];
     const float *en0_w, *en_ln_w, *en_ln_b, *en3_w;
+    const float *fo0_w, *fo_ln_w, *fo_ln_b, *fo3_w;    /* family 1: to_force       */
+    const float *cf0_w, *cf_ln_w, *cf_ln_b, *cf3_w;    /* family 1: to_confidence  */
     const float *ir0_w, *ir0_b, *ir2_w, *ir2_b, *ir4_w, *ir4_b;
     const float *t_W, *t_lin;
     const float *trs0_w, *trs_ln_w, *trs_ln_b, *trs4_w;
@@ -55,14 +57,25 @@ static void map_weights(const ora_hparams *hp, const float *blob, net_w *w)
         TAKE(L->n1_w, (int64_t)H * 2 * H); TAKE(L->n1_b, H);
         TAKE(L->gn_w, H); TAKE(L->gn_b, H); TAKE(L->gn_ms, H);
         TAKE(L->n2_w, (int64_t)H * H); TAKE(L->n2_b, H);
-        if (l == hp->depth - 1) {
+        if (l == hp->depth - 1 && hp->family == 0) {
             TAKE(L->c1_w, (int64_t)H * H); TAKE(L->c1_b, H); TAKE(L->c2_w, H);
         } else {
             L->c1_w = L->c1_b = L->c2_w = NULL;
         }
         TAKE(L->att_w, H); TAKE(L->att_b, 1);
     }
-    TAKE(w->en0_w, (int64_t)H * 2 * H); TAKE(w->en_ln_w, H); TAKE(w->en_ln_b, H); TAKE(w->en3_w, H);
+    if (hp->family == 1) {   /* egnn_net.py:329-360: to_energy, to_force, to_dist, to_confidence on cat[h_r, h_l, D] */
+        const float *skip;
+        TAKE(w->en0_w, (int64_t)H * (2 * H + 1)); TAKE(w->en_ln_w, H); TAKE(w->en_ln_b, H); TAKE(w->en3_w, H);
+        TAKE(w->fo0_w, (int64_t)H * (2 * H + 1)); TAKE(w->fo_ln_w, H); TAKE(w->fo_ln_b, H); TAKE(w->fo3_w, H);
+        TAKE(skip, (int64_t)H * (2 * H + 1)); TAKE(skip, H); TAKE(skip, H); TAKE(skip, (int64_t)64 * H);   /* to_dist */
+        TAKE(w->cf0_w, (int64_t)H * (2 * H + 1)); TAKE(w->cf_ln_w, H); TAKE(w->cf_ln_b, H); TAKE(w->cf3_w, H);
+        (void)skip;
+    } else {
+        TAKE(w->en0_w, (int64_t)H * 2 * H); TAKE(w->en_ln_w, H); TAKE(w->en_ln_b, H); TAKE(w->en3_w, H);
+        w->fo0_w = w->fo_ln_w = w->fo_ln_b = w->fo3_w = NULL;
+        w->cf0_w = w->cf_ln_w = w->cf_ln_b = w->cf3_w = NULL;
+    }
     TAKE(w->ir0_w, (int64_t)2 * H * H); TAKE(w->ir0_b, 2 * H);
     TAKE(w->ir2_w, (int64_t)4 * H * H); TAKE(w->ir2_b, 2 * H);
     TAKE(w->ir4_w, 2 * H); TAKE(w->ir4_b, 1);
@@ -524,9 +537,18 @@ int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const floa
     net_w w;
     map_weights(hp, blob, &w);
 
-    /* :353-359 centre on the ligand CA centroid, concatenate */
+    /* :353-359 centre on the ligand CA centroid, concatenate.  Family 1: DFMDock.move_to_lig_center
+     * (DFMDock.py:254-257) subtracts the mean over all L x 3 backbone atoms before the net is called. */
     float center[3];
-    ca_mean(lig_pos, L, center);
+    if (hp->family == 1) {
+        for (int d = 0; d < 3; ++d) {
+            double sacc = 0;
+            for (int i = 0; i < L * 3; ++i) sacc += lig_pos[i * 3 + d];
+            center[d] = (float)(sacc / (L * 3));
+        }
+    } else {
+        ca_mean(lig_pos, L, center);
+    }
     float *pos = (float *)malloc(sizeof(float) * N * 9);
     for (int i = 0; i < R * 3; ++i)
         for (int d = 0; d < 3; ++d) pos[i * 3 + d] = rec_pos[i * 3 + d] - center[d];
@@ -602,7 +624,7 @@ int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const floa
     float *cagg = (float *)calloc((size_t)N * 3, sizeof(float));
     for (int l = 0; l < hp->depth; ++l) {
         const layer_w *Lw = &w.layer[l];
-        const int last = (l == hp->depth - 1);
+        const int last = (l == hp->depth - 1) && hp->family == 0;   /* EGNN_Net: update_coords=False everywhere */
 #pragma omp parallel
         {
             float *in = (float *)malloc(sizeof(float) * (int64_t)K * Kin1);
@@ -684,9 +706,76 @@ int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const floa
         free(a1); free(a2);
     }
 
-    /* :362, :386-390 energy over receptor x ligand pairs with CA distance < cut_off; :72 clashes */
     int64_t clashes = 0;
     double esum = 0, msum = 0;
+    out->confidence = 0.f;
+    float *fpair = NULL;   /* family 1: f [L,3] from the pair-force head */
+    if (hp->family == 1) {
+        /* egnn_net.py:430-470.  Linear(cat[h_r, h_l, D]) = W[:, :H] h_r + W[:, H:2H] h_l + W[:, 2H] D (no bias)
+         * -> LayerNorm -> SiLU -> Linear(H -> 1).  energy: masked (D < cut_off) mean (clamp(min=1)) or sum;
+         * confidence: mean over all pairs; force f_l = agg_r unit_vec(r,l) * to_force(.) ; clashes D <= 3 */
+        const int Kp = 2 * H + 1;
+        const float *W0[3] = {w.fo0_w, w.en0_w, w.cf0_w};
+        const float *LW[3] = {w.fo_ln_w, w.en_ln_w, w.cf_ln_w}, *LB[3] = {w.fo_ln_b, w.en_ln_b, w.cf_ln_b};
+        const float *W3[3] = {w.fo3_w, w.en3_w, w.cf3_w};
+        const int nh = want_energy ? 3 : 1;
+        float *Ar[3], *Bl[3];
+        for (int q = 0; q < nh; ++q) {
+            Ar[q] = (float *)malloc(sizeof(float) * (int64_t)R * H);
+            Bl[q] = (float *)malloc(sizeof(float) * (int64_t)L * H);
+            linear(h, R, H, H, W0[q], Kp, NULL, H, Ar[q], H, 1);
+            linear(h + (int64_t)R * H, L, H, H, W0[q] + H, Kp, NULL, H, Bl[q], H, 1);
+        }
+        fpair = (float *)calloc((size_t)L * 3, sizeof(float));
+        double csum = 0;
+        double *facc = (double *)calloc((size_t)L * 3, sizeof(double));
+#pragma omp parallel
+        {
+            float *v = (float *)malloc(sizeof(float) * H);
+            double *fl = (double *)calloc((size_t)L * 3, sizeof(double));
+#pragma omp for schedule(static) reduction(+ : esum, msum, csum, clashes)
+            for (int r = 0; r < R; ++r) {
+                for (int q = 0; q < L; ++q) {
+                    const int j = R + q;
+                    const float dx = ca[r * 3] - ca[j * 3], dy = ca[r * 3 + 1] - ca[j * 3 + 1],
+                                dz = ca[r * 3 + 2] - ca[j * 3 + 2];
+                    const float D = sqrtf((dx * dx + dy * dy) + dz * dz);
+                    if (D <= 3.0f) clashes += 1;
+                    float sval[3] = {0, 0, 0};
+                    for (int hd = 0; hd < nh; ++hd) {
+                        for (int c = 0; c < H; ++c)
+                            v[c] = (Ar[hd][(int64_t)r * H + c] + Bl[hd][(int64_t)q * H + c]) + W0[hd][(int64_t)c * Kp + 2 * H] * D;
+                        layernorm(v, H, LW[hd], LB[hd]);
+                        float o = 0;
+                        for (int c = 0; c < H; ++c) o += siluf(v[c]) * W3[hd][c];
+                        sval[hd] = o;
+                    }
+                    const float nrm = D > 1e-12f ? D : 1e-12f;     /* F.normalize(vec, dim=-1), eps 1e-12 */
+                    fl[q * 3] += (double)(dx / nrm * sval[0]);
+                    fl[q * 3 + 1] += (double)(dy / nrm * sval[0]);
+                    fl[q * 3 + 2] += (double)(dz / nrm * sval[0]);
+                    if (want_energy) {
+                        if (D < hp->cut_off) { msum += 1.0; esum += sval[1]; }
+                        csum += sval[2];
+                    }
+                }
+            }
+#pragma omp critical
+            for (int q = 0; q < L * 3; ++q) facc[q] += fl[q];
+            free(v); free(fl);
+        }
+        for (int q = 0; q < L * 3; ++q) fpair[q] = (float)(hp->agg_mean ? facc[q] / R : facc[q]);
+        free(facc);
+        for (int q = 0; q < nh; ++q) { free(Ar[q]); free(Bl[q]); }
+        if (want_energy) {
+            out->energy = hp->agg_mean ? (float)((float)esum / (msum < 1.0 ? 1.0f : (float)msum)) : (float)esum;
+            out->confidence = (float)(csum / ((double)R * L));
+        } else {
+            out->energy = 0.f;
+        }
+        out->num_clashes = clashes;
+    } else
+    /* :362, :386-390 energy over receptor x ligand pairs with CA distance < cut_off; :72 clashes */
     {
         /* Linear(cat[h_r,h_l]) = W[:, :H] h_r + W[:, H:] h_l (no bias) */
         float *Ar = (float *)malloc(sizeof(float) * (int64_t)R * H);
@@ -719,15 +808,18 @@ int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const floa
         }
         free(Ar); free(Bl);
     }
-    out->energy = (float)((float)esum / ((float)msum + 1e-6f));
-    out->num_clashes = clashes;
+    if (hp->family == 0) {
+        out->energy = (float)((float)esum / ((float)msum + 1e-6f));
+        out->num_clashes = clashes;
+    }
 
     /* :396-404 force, translation and torque pooling */
     double trp[3] = {0, 0, 0}, rtp[3] = {0, 0, 0};
     for (int q = 0; q < L; ++q) {
         const int i = R + q;
         const float r[3] = {ca[i * 3], ca[i * 3 + 1], ca[i * 3 + 2]};
-        const float f[3] = {coord[i * 3] - r[0], coord[i * 3 + 1] - r[1], coord[i * 3 + 2] - r[2]};
+        const float f[3] = {fpair ? fpair[q * 3] : coord[i * 3] - r[0], fpair ? fpair[q * 3 + 1] : coord[i * 3 + 1] - r[1],
+                            fpair ? fpair[q * 3 + 2] : coord[i * 3 + 2] - r[2]};
         if (dbg && dbg->f) { dbg->f[q * 3] = f[0]; dbg->f[q * 3 + 1] = f[1]; dbg->f[q * 3 + 2] = f[2]; }
         for (int d = 0; d < 3; ++d) trp[d] += f[d];
         rtp[0] += r[1] * f[2] - r[2] * f[1];
@@ -735,7 +827,9 @@ int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const floa
         rtp[2] += r[0] * f[1] - r[1] * f[0];
     }
     float tr_pred[3], rot_pred[3];
-    for (int d = 0; d < 3; ++d) { tr_pred[d] = (float)(trp[d] / L); rot_pred[d] = (float)(rtp[d] / L); }
+    const double pool = (hp->family == 1 && !hp->agg_mean) ? 1.0 : (double)L;     /* egnn_net.py:459-470 */
+    for (int d = 0; d < 3; ++d) { tr_pred[d] = (float)(trp[d] / pool); rot_pred[d] = (float)(rtp[d] / pool); }
+    free(fpair);
 
     /* :407 t_embed: GaussianFourierProjection (:162-172) -> Linear(no bias) -> Sigmoid */
     float *four = (float *)malloc(sizeof(float) * Hi), *temb = (float *)malloc(sizeof(float) * Hi);

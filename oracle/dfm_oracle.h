@@ -25,12 +25,15 @@ typedef struct {
     int node_dim, edge_dim, inner_dim, depth, knn, n_sample;
     float cut_off, mask_dist;
     double r3_min_sigma, r3_max_sigma, so3_min_sigma, so3_max_sigma;   /* Python floats in the reference */
+    int family;    /* 0: Score_Net (score_net_mlsb.py); 1: EGNN_Net behind DFMDock.forward (egnn_net.py, DFMDock.py:68-75) */
+    int agg_mean;  /* family 1: `agg` == 'mean' (1) or 'sum' (0) */
 } ora_hparams;
 
 typedef struct {
     float tr_score[3], rot_score[3];
     float energy;
     int64_t num_clashes;
+    float confidence;   /* family 1: confidence_logits (egnn_net.py:447); 0 otherwise */
 } ora_score_out;
 
 /* optional intermediates of one score evaluation (any pointer may be NULL) */

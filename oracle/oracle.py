@@ -24,12 +24,13 @@ class OraHParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("lm_embed_dim", "positional_embed_dim", "spatial_embed_dim",
                                        "node_dim", "edge_dim", "inner_dim", "depth", "knn", "n_sample")] + \
                [(n, C.c_float) for n in ("cut_off", "mask_dist")] + \
-               [(n, C.c_double) for n in ("r3_min_sigma", "r3_max_sigma", "so3_min_sigma", "so3_max_sigma")]
+               [(n, C.c_double) for n in ("r3_min_sigma", "r3_max_sigma", "so3_min_sigma", "so3_max_sigma")] + \
+               [("family", C.c_int), ("agg_mean", C.c_int)]
 
 
 class OraScoreOut(C.Structure):
     _fields_ = [("tr_score", C.c_float * 3), ("rot_score", C.c_float * 3), ("energy", C.c_float),
-                ("num_clashes", C.c_int64)]
+                ("num_clashes", C.c_int64), ("confidence", C.c_float)]
 
 
 class OraDebug(C.Structure):
@@ -134,7 +135,7 @@ class Oracle:
                              C.byref(out), C.byref(dbg) if dbg is not None else None)
         assert rc == 0
         res = dict(tr_score=np.array(out.tr_score, np.float32)[None], rot_score=np.array(out.rot_score, np.float32)[None],
-                   energy=np.float32(out.energy), num_clashes=int(out.num_clashes))
+                   energy=np.float32(out.energy), num_clashes=int(out.num_clashes), confidence=np.float32(out.confidence))
         res.update(d)
         return res
 

@@ -24,6 +24,21 @@ def blob():
     return pack_blob(make_random_weights(0))
 
 
+PAIR_HP_KW = dict(family=1, mask_dist=20.0)      # configs/model/DFMDock.yaml (EGNN_Net behind DFMDock.forward)
+
+
+def pair_hparams(agg_mean=True):
+    from dfmdock_amd.weights import HParams
+    return HParams(agg_mean=agg_mean, **PAIR_HP_KW)
+
+
+@pytest.fixture(scope="session")
+def blob_pair():
+    from dfmdock_amd.weights import make_random_weights, pack_blob
+    hp = pair_hparams()
+    return pack_blob(make_random_weights(0, hp), hp)
+
+
 def complex_for(case):
     """Rebuild the complex a golden file was generated on (tests/golden/make_golden.py)."""
     from dfmdock_amd.synthetic import make_complex, seq_to_onehot

@@ -6,7 +6,7 @@ reference's own functions (tests/golden/make_golden.py).  CPU only.
 import numpy as np
 import pytest
 
-from conftest import complex_for, load_golden
+from conftest import complex_for, load_golden, pair_hparams
 from oracle import oracle as ora
 
 
@@ -147,6 +147,28 @@ def test_score_matches_reference(case, blob):
     assert rel_inf(r["rot_score"], g["rot_score"]) < 1e-4
     assert abs(float(r["energy"]) - float(g["energy"])) < 1e-4
     assert rel_inf(r["ires"], g["ires"][:, 0]) < 1e-4
+
+
+# ---- f-2: second model family, DFMDock.forward = move_to_lig_center + EGNN_Net(predict=True) ------------
+FWD2_CASES = ["fwd2_syn_9_7", "fwd2_syn_24_16", "fwd2_syn_64_48_p0", "fwd2_syn_64_48_p1", "fwd2_syn_64_48_p2",
+              "fwd2_7CEI_p0", "fwd2_7CEI_p1", "fwd2_7CEI_p2", "fwd2_sum_syn_24_16"]
+
+
+@pytest.mark.parametrize("case", FWD2_CASES)
+def test_pair_family_score_matches_reference(case, blob_pair):
+    g = load_golden(case + ".npz")
+    hp = pair_hparams(agg_mean="sum" not in case)
+    o = ora.Oracle(blob_pair, complex_for(case), hp)       # the blob layout does not depend on `agg`
+    r = o.score(g["lig_pos"], float(g["t"]), edges=g["edges"])
+    assert r["num_clashes"] == int(g["num_clashes"])
+    assert rel_inf(r["h_layers"][0], g["h_first"]) < 2e-5
+    assert rel_inf(r["h_layers"][-1], g["h_last"]) < 5e-5
+    assert rel_inf(r["f"], g["f"]) < 1e-4
+    assert rel_inf(r["tr_score"], g["tr_score"]) < 1e-4
+    assert rel_inf(r["rot_score"], g["rot_score"]) < 1e-4
+    assert abs(float(r["energy"]) - float(g["energy"])) < 1e-4 * max(1.0, abs(float(g["energy"])))
+    assert abs(float(r["confidence"]) - float(g["confidence_logits"])) < 1e-4
+    assert rel_inf(r["ires"], g["ires_logits"]) < 1e-4
 
 
 # ---- a-1 / a-2: the sampler ------------------------------------------------------------
