@@ -35,12 +35,13 @@ class HParamsC(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("lm_embed_dim", "positional_embed_dim", "spatial_embed_dim", "node_dim",
                                        "edge_dim", "inner_dim", "depth", "knn", "n_sample")] + \
                [("cut_off", C.c_float), ("mask_dist", C.c_float)] + \
-               [(n, C.c_double) for n in ("r3_min_sigma", "r3_max_sigma", "so3_min_sigma", "so3_max_sigma")]
+               [(n, C.c_double) for n in ("r3_min_sigma", "r3_max_sigma", "so3_min_sigma", "so3_max_sigma")] + \
+               [("family", C.c_int), ("agg_mean", C.c_int)]
 
 
 class ScoreOutC(C.Structure):
     _fields_ = [("tr_score", F32P), ("rot_score", F32P), ("energy", F32P), ("num_clashes", I32P), ("f", F32P),
-                ("h_last", F32P), ("h_first", F32P), ("edges", I32P), ("edge_codes", U32P)]
+                ("h_last", F32P), ("h_first", F32P), ("edges", I32P), ("edge_codes", U32P), ("confidence", F32P)]
 
 
 class InjectC(C.Structure):

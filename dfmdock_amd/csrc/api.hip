@@ -61,6 +61,7 @@ struct dfm_model {
     LayerDev layers[8];
     HeadsDev heads;
     float *en0_w = nullptr;          // [256][512]
+    PairHeadDev pair[3];             // family 1: 0 to_force, 1 to_energy, 2 to_confidence
 };
 
 struct Workspace {
@@ -72,6 +73,7 @@ struct Workspace {
     uint16_t *Bmb = nullptr, *mbuf = nullptr;
     float *gn_shift = nullptr, *gn_den = nullptr;
     float *fvec = nullptr, *en_part = nullptr; int32_t *clash_part = nullptr;
+    float *fpart = nullptr, *cpart = nullptr, *conf = nullptr;    // family 1: force partials per receptor tile, confidence
     float *scores = nullptr, *lig_cur = nullptr, *tr_update = nullptr, *rot_update = nullptr, *t_dev = nullptr;
 };
 
@@ -97,6 +99,7 @@ extern "C" void dfm_default_hparams(dfm_hparams *hp)
     hp->node_dim = 256; hp->edge_dim = 128; hp->inner_dim = 128; hp->depth = 6; hp->knn = 20; hp->n_sample = 40;
     hp->cut_off = 20.0f; hp->mask_dist = 22.0f;
     hp->r3_min_sigma = 0.1; hp->r3_max_sigma = 30.0; hp->so3_min_sigma = 0.1; hp->so3_max_sigma = 1.5;
+    hp->family = 0; hp->agg_mean = 1;
 }
 
 struct BlobMap {
@@ -106,12 +109,14 @@ struct BlobMap {
             *att_w, *att_b;
     } layer[8];
     const float *en0_w, *en_ln_w, *en_ln_b, *en3_w;
+    struct Ph { const float *w0, *ln_w, *ln_b, *w3; } pair[3];   // family 1: to_force, to_energy, to_confidence
     const float *t_W, *t_lin, *trs0, *trs_ln_w, *trs_ln_b, *trs4, *rots0, *rots_ln_w, *rots_ln_b, *rots4;
     int64_t total;
 };
 
 static void map_blob(const dfm_hparams *hp, const float *blob, BlobMap *w)
-{   // state_dict order of Score_Net (score_net_mlsb.py:249-341, egnn.py:37-93); see dfmdock_amd/weights.py
+{   // state_dict order of Score_Net (score_net_mlsb.py:249-341, egnn.py:37-93) or, family 1, of EGNN_Net
+    // (egnn_net.py:296-385); see dfmdock_amd/weights.py
     const int64_t Hh = hp->node_dim, He = hp->edge_dim, Hi = hp->inner_dim;
     const float *p = blob;
     auto take = [&](const float *&dst, int64_t n) { dst = p; p += n; };
@@ -125,12 +130,21 @@ static void map_blob(const dfm_hparams *hp, const float *blob, BlobMap *w)
         take(Lw.n1_w, Hh * 2 * Hh); take(Lw.n1_b, Hh);
         take(Lw.gn_w, Hh); take(Lw.gn_b, Hh); take(Lw.gn_ms, Hh);
         take(Lw.n2_w, Hh * Hh); take(Lw.n2_b, Hh);
-        if (l == hp->depth - 1) { take(Lw.c1_w, Hh * Hh); take(Lw.c1_b, Hh); take(Lw.c2_w, Hh); }
+        if (l == hp->depth - 1 && hp->family == 0) { take(Lw.c1_w, Hh * Hh); take(Lw.c1_b, Hh); take(Lw.c2_w, Hh); }
         else Lw.c1_w = Lw.c1_b = Lw.c2_w = nullptr;
         take(Lw.att_w, Hh); take(Lw.att_b, 1);
     }
-    take(w->en0_w, Hh * 2 * Hh); take(w->en_ln_w, Hh); take(w->en_ln_b, Hh); take(w->en3_w, Hh);
     const float *skip;
+    if (hp->family == 1) {   // to_energy, to_force, to_dist (training-only, skipped), to_confidence on cat[h_r, h_l, D]
+        auto head = [&](BlobMap::Ph &h) { take(h.w0, Hh * (2 * Hh + 1)); take(h.ln_w, Hh); take(h.ln_b, Hh); take(h.w3, Hh); };
+        head(w->pair[1]); head(w->pair[0]);
+        take(skip, Hh * (2 * Hh + 1)); take(skip, Hh); take(skip, Hh); take(skip, 64 * Hh);
+        head(w->pair[2]);
+        w->en0_w = w->en_ln_w = w->en_ln_b = w->en3_w = nullptr;
+    } else {
+        take(w->en0_w, Hh * 2 * Hh); take(w->en_ln_w, Hh); take(w->en_ln_b, Hh); take(w->en3_w, Hh);
+        for (auto &h : w->pair) h.w0 = h.ln_w = h.ln_b = h.w3 = nullptr;
+    }
     take(skip, 2 * Hh * Hh); take(skip, 2 * Hh); take(skip, 4 * Hh * Hh); take(skip, 2 * Hh);   // to_ires.{0,2}
     take(skip, 2 * Hh); take(skip, 1);                                                          // to_ires.4
     take(w->t_W, Hi / 2); take(w->t_lin, Hi * Hi);
@@ -141,7 +155,7 @@ static void map_blob(const dfm_hparams *hp, const float *blob, BlobMap *w)
 
 extern "C" int64_t dfm_param_count(const dfm_hparams *hp)
 {
-    if (!hp || hp->depth < 1 || hp->depth > 8) return -1;
+    if (!hp || hp->depth < 1 || hp->depth > 8 || hp->family < 0 || hp->family > 1) return -1;
     BlobMap w;
     map_blob(hp, nullptr, &w);
     return w.total;
@@ -253,7 +267,7 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
     if (!blob || !hp) { fail(DFM_E_INVALID, "blob or hp is NULL"); return nullptr; }
     if (hp->node_dim != H || hp->edge_dim != HE || hp->inner_dim != HI || hp->spatial_embed_dim != 100 ||
         hp->positional_embed_dim != 66 || hp->depth < 1 || hp->depth > 8 || hp->knn < 1 || hp->n_sample < 0 ||
-        hp->knn + hp->n_sample > 60 || hp->lm_embed_dim < 1) {
+        hp->knn + hp->n_sample > 60 || hp->lm_embed_dim < 1 || hp->family < 0 || hp->family > 1) {
         fail(DFM_E_INVALID, "unsupported hyper-parameters (kernels are built for node 256 / edge 128 / inner 128, degree <= 60)");
         return nullptr;
     }
@@ -329,9 +343,28 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
     }
     HeadsDev &Hd = m->heads;
     std::memset(&Hd, 0, sizeof(Hd));
-    up(&m->en0_w, w.en0_w, (size_t)H * 2 * H);
-    Hd.en_wa = m->en0_w; Hd.en_wb = m->en0_w ? m->en0_w + H : nullptr;
-    up(&Hd.en_ln_w, w.en_ln_w, H); up(&Hd.en_ln_b, w.en_ln_b, H); up(&Hd.en_w3, w.en3_w, H);
+    std::memset(m->pair, 0, sizeof(m->pair));
+    if (hp->family == 1) {
+        const int Kp = 2 * H + 1;
+        for (int q = 0; q < 3 && ok; ++q) {
+            const auto &src = w.pair[q];
+            std::vector<float> wab((size_t)2 * H * H), wd(H);
+            for (int c = 0; c < H; ++c) {      // rows 0..255: receptor half W[:, :256]; rows 256..511: ligand half W[:, 256:512]
+                std::memcpy(&wab[(size_t)c * H], src.w0 + (size_t)c * Kp, H * sizeof(float));
+                std::memcpy(&wab[(size_t)(H + c) * H], src.w0 + (size_t)c * Kp + H, H * sizeof(float));
+                wd[c] = src.w0[(size_t)c * Kp + 2 * H];
+            }
+            PairHeadDev &D = m->pair[q];
+            std::vector<uint16_t> hi, lo;
+            up(&D.wab, wab.data(), wab.size());
+            split_bf16(wab.data(), 2 * H, H, hi, lo); up16(&D.wab_hi, hi); up16(&D.wab_lo, lo);
+            up(&D.w_d, wd.data(), H); up(&D.ln_w, src.ln_w, H); up(&D.ln_b, src.ln_b, H); up(&D.w3, src.w3, H);
+        }
+    } else {
+        up(&m->en0_w, w.en0_w, (size_t)H * 2 * H);
+        Hd.en_wa = m->en0_w; Hd.en_wb = m->en0_w ? m->en0_w + H : nullptr;
+        up(&Hd.en_ln_w, w.en_ln_w, H); up(&Hd.en_ln_b, w.en_ln_b, H); up(&Hd.en_w3, w.en3_w, H);
+    }
     up(&Hd.t_W, w.t_W, HI / 2); up(&Hd.t_lin, w.t_lin, (size_t)HI * HI);
     up(&Hd.trs0, w.trs0, (size_t)HI * (HI + 1)); up(&Hd.trs_ln_w, w.trs_ln_w, HI); up(&Hd.trs_ln_b, w.trs_ln_b, HI);
     up(&Hd.trs4, w.trs4, HI);
@@ -405,7 +438,8 @@ extern "C" int dfm_complex_degree(const dfm_complex *cx) { return cx ? cx->K : -
 static int ensure_workspace(dfm_complex *cx, int B, bool bf16)
 {
     Workspace &W = cx->ws;
-    const bool need_mbuf = bf16 && !W.mbuf;
+    const bool wants_mbuf = bf16 && cx->m->hp.family == 0;    // gated messages for the coordinate MLP (family 0 only)
+    const bool need_mbuf = wants_mbuf && !W.mbuf;
     if (B <= W.Bcap && !need_mbuf) return DFM_OK;
     if (B > W.Bcap) {
         HIPCHK(hipStreamSynchronize(cx->stream));
@@ -420,13 +454,18 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16)
         HIPCHK(W.pool.alloc(&W.Bmb, b * N * H)); HIPCHK(W.pool.alloc(&W.agg, b * N * H));
         HIPCHK(W.pool.alloc(&W.u, b * N * H));
         HIPCHK(W.pool.alloc(&W.gn_shift, b * H)); HIPCHK(W.pool.alloc(&W.gn_den, b * H));
-        HIPCHK(W.pool.alloc(&W.fvec, b * L * 3)); HIPCHK(W.pool.alloc(&W.en_part, b * R * 2));
-        HIPCHK(W.pool.alloc(&W.clash_part, b * R)); HIPCHK(W.pool.alloc(&W.scores, b * 8));
+        const size_t RT = (R + 63) / 64, NP = R > 4 * RT ? R : 4 * RT;     // partial-sum slots per trajectory
+        HIPCHK(W.pool.alloc(&W.fvec, b * L * 3)); HIPCHK(W.pool.alloc(&W.en_part, b * NP * 2));
+        HIPCHK(W.pool.alloc(&W.clash_part, b * NP)); HIPCHK(W.pool.alloc(&W.scores, b * 8));
+        if (cx->m->hp.family == 1) {
+            HIPCHK(W.pool.alloc(&W.fpart, b * RT * L * 3)); HIPCHK(W.pool.alloc(&W.cpart, b * RT * 4 * 2));
+            HIPCHK(W.pool.alloc(&W.conf, b));
+        }
         HIPCHK(W.pool.alloc(&W.lig_cur, b * L * 9)); HIPCHK(W.pool.alloc(&W.tr_update, b * 3));
         HIPCHK(W.pool.alloc(&W.rot_update, b * 3)); HIPCHK(W.pool.alloc(&W.t_dev, b));
         W.Bcap = B;
     }
-    if (bf16 && !W.mbuf) HIPCHK(W.pool.alloc(&W.mbuf, (size_t)W.Bcap * cx->L * KPAD * H));
+    if (wants_mbuf && !W.mbuf) HIPCHK(W.pool.alloc(&W.mbuf, (size_t)W.Bcap * cx->L * KPAD * H));
     return DFM_OK;
 }
 
@@ -459,7 +498,8 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
     const int N = cx->N, R = cx->R, L = cx->L, K = cx->K, depth = m->hp.depth;
     const uint32_t stream_id = cx->fwd_counter++;
 
-    HIPCHK(launch_prep_pose(cx->rec_pos, W.lig_cur, B, R, L, W.pos, W.ca4, W.cb4, s));
+    const bool pair_family = m->hp.family == 1;
+    HIPCHK(launch_prep_pose(cx->rec_pos, W.lig_cur, B, R, L, pair_family ? 1 : 0, W.pos, W.ca4, W.cb4, s));
     if (o.edges_dev) {
         HIPCHK(hipMemcpy2DAsync(W.edges, (size_t)N * K * 4, o.edges_dev, (size_t)o.edges_pitch * 4, (size_t)N * K * 4, B,
                                 hipMemcpyDeviceToDevice, s));
@@ -477,12 +517,13 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
     for (int l = 0; l < depth; ++l) {
         const LayerDev &Lw = m->layers[l];
         const bool last = (l == depth - 1);
+        const bool coord = last && !pair_family;       // EGNN_Net: update_coords = False in every layer
         EdgeArgs e;
         std::memset(&e, 0, sizeof(e));
         if (l == 0) { e.A = cx->A0; e.Bm = cx->Bm0; e.Bmb = cx->Bmb0; e.ab_bstride = 0; }
         else { e.A = W.A; e.Bm = W.Bm; e.Bmb = W.Bmb; e.ab_bstride = (int64_t)N * H; }
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
-        e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = last; e.fout = W.fvec; e.mbuf = W.mbuf;
+        e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = coord; e.fout = W.fvec; e.mbuf = W.mbuf;
         e.f16 = o.f16 ? 1 : 0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (o.profile) {
@@ -500,7 +541,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             cx->prof.edge_kernel_launches += 1;
             cx->prof.edge_rows += (int64_t)B * N * K;
         }
-        if (last && o.bf16) HIPCHK(launch_coord_bf16(e, s));
+        if (coord && o.bf16) HIPCHK(launch_coord_bf16(e, s));
         // node_model (egnn.py:106-116): u = Linear(cat[h, agg]); GraphNorm; SiLU; Linear; residual
         GemmArgs g;
         std::memset(&g, 0, sizeof(g));
@@ -527,7 +568,33 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
     if (h != W.h) {   // keep the final node features in W.h (depth odd)
         HIPCHK(hipMemcpyAsync(W.h, h, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    if (o.want_energy) {
+    if (pair_family) {
+        // egnn_net.py:430-470: pair heads on cat[h_r, h_l, D].  Per head: one GEMM projects every node through the stacked
+        // halves of Linear(513 -> 256) (reusing the A / Bm buffers), then the elementwise pair kernel.
+        auto run_head = [&](int q, int mode) -> int {
+            const PairHeadDev &Ph = m->pair[q];
+            GemmArgs g;
+            std::memset(&g, 0, sizeof(g));
+            g.A0 = W.h; g.lda = H; g.K = H; g.W = Ph.wab; g.ldw = H; g.M = M; g.Nout = 2 * H; g.epi = 2; g.C = W.A; g.ldc = H;
+            g.C2 = W.Bm;
+            if (o.bf16) HIPCHK(launch_gemm_split(g, Ph.wab_hi, Ph.wab_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
+            PairArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.P = W.A; a.Q = W.Bm; a.ca4 = W.ca4; a.B = B; a.R = R; a.L = L; a.w_d = Ph.w_d; a.ln_w = Ph.ln_w; a.ln_b = Ph.ln_b;
+            a.w3 = Ph.w3; a.mode = mode; a.exact = o.bf16 ? 0 : 1; a.cut_off = m->hp.cut_off; a.fpart = W.fpart;
+            a.spart = mode == 1 ? W.en_part : W.cpart; a.clash_part = W.clash_part;
+            HIPCHK(launch_pair_head(a, s));
+            return DFM_OK;
+        };
+        int rc = run_head(0, 0);
+        if (rc) return rc;
+        if (o.want_energy) {
+            if ((rc = run_head(1, 1)) != DFM_OK) return rc;
+            if ((rc = run_head(2, 2)) != DFM_OK) return rc;
+        }
+        HIPCHK(launch_pair_finish(W.fpart, B, R, L, m->hp.agg_mean ? 1.0f / (float)R : 1.0f, W.fvec, W.cpart,
+                                  o.want_energy ? W.conf : nullptr, s));
+    } else if (o.want_energy) {
         // to_energy.0 on cat[h_r, h_l] = Wa h_r + Wb h_l: project every node once (reuses A / Bm buffers)
         GemmArgs g;
         std::memset(&g, 0, sizeof(g));
@@ -547,6 +614,12 @@ static void fill_head_args(dfm_complex *cx, int B, bool want_energy, HeadArgs *a
     a->fvec = W.fvec; a->ca4 = W.ca4; a->B = B; a->R = cx->R; a->L = cx->L; a->t = W.t_dev; a->hw = &cx->m->heads;
     a->scores = W.scores; a->want_energy = want_energy; a->en_part = W.en_part; a->clash_part = W.clash_part;
     a->lig_cur = W.lig_cur; a->tr_update = W.tr_update; a->rot_update = W.rot_update;
+    const dfm_hparams &hp = cx->m->hp;
+    if (hp.family == 1) {
+        a->n_part = 4 * ((cx->R + 63) / 64); a->en_mode = hp.agg_mean ? 1 : 2; a->pool_div = hp.agg_mean ? (float)cx->L : 1.0f;
+    } else {
+        a->n_part = cx->R; a->en_mode = 0; a->pool_div = (float)cx->L;
+    }
 }
 
 static int finish_profile(dfm_complex *cx)
@@ -612,6 +685,10 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
         if (e == hipSuccess && out->h_first) e = hipMemcpyAsync(out->h_first, h_first_dev, (size_t)B * N * H * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && out->edges) e = hipMemcpyAsync(out->edges, W.edges, (size_t)B * N * K * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && out->edge_codes) e = hipMemcpyAsync(out->edge_codes, W.codes, (size_t)B * N * K * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && out->confidence) {
+            if (cx->m->hp.family == 1 && want_energy) e = hipMemcpyAsync(out->confidence, W.conf, (size_t)B * 4, hipMemcpyDeviceToHost, s);
+            else std::memset(out->confidence, 0, (size_t)B * 4);
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) rc = fail(DFM_E_HIP, hipGetErrorString(e));
         else {

@@ -67,6 +67,14 @@ struct HeadsDev {
     float *rots0, *rots_ln_w, *rots_ln_b, *rots4;
 };
 
+// one receptor x ligand pair head of model family 1 (egnn_net.py:329-358): Linear(513->256) split into the stacked node
+// halves [W[:, :256]; W[:, 256:512]] and the distance column, LayerNorm affine, Linear(256->1)
+struct PairHeadDev {
+    float *wab;                 // [512][256] fp32 (fp32 engine)
+    uint16_t *wab_hi, *wab_lo;  // split-bf16 tiles of the same (16-bit engines)
+    float *w_d, *ln_w, *ln_b, *w3;
+};
+
 // ---- kernel launchers (each returns the hipError of the launch) ---------------------------------
 struct GemmArgs {
     const float *A0;      // [M][lda0]
@@ -95,7 +103,7 @@ hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s);
 // split-bf16 (hi/lo) variant, ~1e-5 relative error; Whi/Wlo = pre-split weights [Nout][ldw] bf16
 hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s);
 
-hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, float *pos,
+hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, int all_atoms, float *pos,
                             float4 *ca4, float4 *cb4, hipStream_t s);
 hipError_t launch_knn_sample(const float4 *ca4, int B, int N, int knn, int nsamp, uint64_t seed, uint32_t stream_id,
                              int32_t *edges, hipStream_t s);
@@ -127,6 +135,22 @@ hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_gn_stats(const float *u, int B, int N, const float *mean_scale, float *shift, float *den,
                            const float *fold_w, const float *fold_b, hipStream_t s);
 
+struct PairArgs {
+    const float *P, *Q;      // [B][N][256] projections of every node (receptor rows of P, ligand rows of Q are used)
+    const float4 *ca4;
+    int B, R, L;
+    const float *w_d, *ln_w, *ln_b, *w3;
+    int mode;                // 0 force (+ clashes), 1 energy, 2 confidence
+    int exact;               // fp32 engine: three-pass LayerNorm, expf
+    float cut_off;
+    float *fpart;            // [B][ceil(R/64)][L][3]
+    float *spart;            // [B][ceil(R/64)*4][2]
+    int32_t *clash_part;     // [B][ceil(R/64)*4]
+};
+hipError_t launch_pair_head(const PairArgs &a, hipStream_t s);
+hipError_t launch_pair_finish(const float *fpart, int B, int R, int L, float inv_pool, float *fvec, const float *cpart,
+                              float *conf, hipStream_t s);
+
 struct HeadArgs {
     const float *fvec;       // [B][L][3]
     const float4 *ca4;       // [B][N]
@@ -136,8 +160,11 @@ struct HeadArgs {
     float *scores;           // [B][8] tr(3) rot(3) energy clashes
     // energy (optional)
     int want_energy;
-    const float *en_part;    // [B][R][2]
-    const int32_t *clash_part;  // [B][R]
+    const float *en_part;    // [B][n_part][2]
+    const int32_t *clash_part;  // [B][n_part]
+    int n_part;              // partial sums per trajectory: R (family 0) or 4*ceil(R/64) (family 1)
+    int en_mode;             // energy = 0: sum/(count + 1e-6) (score_net_mlsb.py:390); 1: sum/max(count, 1); 2: sum (egnn_net.py:438-441)
+    float pool_div;          // tr / rot pooling divisor: L (mean) or 1 (`agg: sum`)
     // Euler-Maruyama update (optional)
     int do_update;
     float g2_r, g_r, hg2_r, g2_t, g_t, hg2_t;   // float32-rounded diffusion coefficients of this step

@@ -13,22 +13,25 @@ namespace dfm {
 // prep_pose: centre receptor + ligand on the ligand CA centroid (score_net_mlsb.py:353-359), build
 // CA and virtual-CB arrays (coords6d.py:71-75).  One workgroup per trajectory.
 __global__ __launch_bounds__(256) void k_prep_pose(const float *__restrict__ rec_pos, const float *__restrict__ lig_cur,
-                                                   int R, int L, float *__restrict__ pos, float4 *__restrict__ ca4,
-                                                   float4 *__restrict__ cb4)
+                                                   int R, int L, int all_atoms, float *__restrict__ pos,
+                                                   float4 *__restrict__ ca4, float4 *__restrict__ cb4)
 {
     __shared__ double scratch[8];
     __shared__ float center[3];
     const int b = blockIdx.x, N = R + L;
     const float *lig = lig_cur + (size_t)b * L * 9;
     double s0 = 0, s1 = 0, s2 = 0;
-    for (int q = threadIdx.x; q < L; q += blockDim.x) {
-        s0 += lig[q * 9 + 3]; s1 += lig[q * 9 + 4]; s2 += lig[q * 9 + 5];
+    if (all_atoms) {   // DFMDock.move_to_lig_center (DFMDock.py:254-257): mean over all L x 3 backbone atoms
+        for (int q = threadIdx.x; q < L * 3; q += blockDim.x) { s0 += lig[q * 3]; s1 += lig[q * 3 + 1]; s2 += lig[q * 3 + 2]; }
+    } else {           // score_net_mlsb.py:353: ligand CA centroid
+        for (int q = threadIdx.x; q < L; q += blockDim.x) { s0 += lig[q * 9 + 3]; s1 += lig[q * 9 + 4]; s2 += lig[q * 9 + 5]; }
     }
     s0 = block_sum_d(s0, scratch);
     s1 = block_sum_d(s1, scratch);
     s2 = block_sum_d(s2, scratch);
     if (threadIdx.x == 0) {
-        center[0] = (float)(s0 / L); center[1] = (float)(s1 / L); center[2] = (float)(s2 / L);
+        const int cnt = all_atoms ? L * 3 : L;
+        center[0] = (float)(s0 / cnt); center[1] = (float)(s1 / cnt); center[2] = (float)(s2 / cnt);
     }
     __syncthreads();
     const float cx = center[0], cy = center[1], cz = center[2];
@@ -58,20 +61,13 @@ __global__ __launch_bounds__(256) void k_prep_pose(const float *__restrict__ rec
     }
 }
 
-hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, float *pos, float4 *ca4,
+hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, int all_atoms, float *pos, float4 *ca4,
                             float4 *cb4, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_prep_pose, dim3(B), dim3(256), 0, s, rec_pos, lig_cur, R, L, pos, ca4, cb4);
+    hipLaunchKernelGGL(k_prep_pose, dim3(B), dim3(256), 0, s, rec_pos, lig_cur, R, L, all_atoms, pos, ca4, cb4);
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// kNN(20) + sample(40, p ~ 1/d^3, without replacement) (score_net_mlsb.py:85-135).
-// One 64-lane wave per (trajectory, node).  The lane owns candidates j = 4*(lane + 64*q) + e
-// (q < NPL/4, e < 4) in registers.  Top-k by repeated wave-wide arg-min on a 64-bit (value, index)
-// key: ascending distance, lowest index first on ties, slot 0 = the node itself.  The sampled slots
-// are an exponential race: key_j = Exp(1)_j * d_j^3, the 40 smallest keys = successive sampling
-// without replacement with p ~ d^-3 (the scheme torch.multinomial uses), Exp(1) from Philox4x32-10.
 // wave-wide unsigned minimum, result wave-uniform: 4 DPP steps inside each 16-lane row, ds_swizzle across the row
 // pair, then the two 32-lane halves meet in scalar registers
 __device__ inline uint32_t wave_min_u32(uint32_t v)
@@ -86,6 +82,13 @@ __device__ inline uint32_t wave_min_u32(uint32_t v)
     return a < b ? a : b;
 }
 
+// ------------------------------------------------------------------------------------------------
+// kNN(20) + sample(40, p ~ 1/d^3, without replacement) (score_net_mlsb.py:85-135).
+// One 64-lane wave per (trajectory, node).  The lane owns candidates j = 4*(lane + 64*q) + e
+// (q < NPL/4, e < 4) in registers.  Top-k by repeated wave-wide arg-min of (value, index):
+// ascending distance, lowest index first on ties, slot 0 = the node itself.  The sampled slots
+// are an exponential race: key_j = Exp(1)_j * d_j^3, the 40 smallest keys = successive sampling
+// without replacement with p ~ d^-3 (the scheme torch.multinomial uses), Exp(1) from Philox4x32-10.
 template <int NPL>
 __global__ __launch_bounds__(256) void k_knn_sample(const float4 *__restrict__ ca4, int B, int N, int knn, int nsamp,
                                                     uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,

@@ -82,6 +82,8 @@ struct HeadKArgs {
     int want_energy;
     const float *en_part;
     const int32_t *clash_part;
+    int n_part, en_mode;
+    float pool_div;
     int do_update;
     float g2_r, g_r, hg2_r, g2_t, g_t, hg2_t, dt, sqrt_dt, rot_noise, tr_noise;
     int ode;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) a[k] = block_sum_d(a[k], dscr);
-    if (tid < 6) s_pred[tid] = (float)(a[tid] / L);
+    if (tid < 6) s_pred[tid] = (float)(a[tid] / p.pool_div);
 
     // :407  t_embed = Sigmoid(Linear(GaussianFourierProjection(t)))
     const float t = p.t[b];
@@ -166,13 +168,17 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
     // energy = sum(e * mask) / (sum(mask) + 1e-6) ; num_clashes
     if (p.want_energy) {
         double es = 0, cs = 0, ks = 0;
-        for (int r = tid; r < R; r += blockDim.x) {
-            es += p.en_part[((size_t)b * R + r) * 2];
-            cs += p.en_part[((size_t)b * R + r) * 2 + 1];
-            ks += p.clash_part[(size_t)b * R + r];
+        for (int r = tid; r < p.n_part; r += blockDim.x) {
+            es += p.en_part[((size_t)b * p.n_part + r) * 2];
+            cs += p.en_part[((size_t)b * p.n_part + r) * 2 + 1];
+            ks += p.clash_part[(size_t)b * p.n_part + r];
         }
         es = block_sum_d(es, dscr); cs = block_sum_d(cs, dscr); ks = block_sum_d(ks, dscr);
-        if (tid == 0) { s_score[6] = (float)es / ((float)cs + 1e-6f); s_score[7] = (float)ks; }
+        if (tid == 0) {
+            s_score[6] = p.en_mode == 0 ? (float)es / ((float)cs + 1e-6f)
+                                        : (p.en_mode == 1 ? (float)es / fmaxf((float)cs, 1.0f) : (float)es);
+            s_score[7] = (float)ks;
+        }
     } else if (tid == 0) {
         s_score[6] = 0.f; s_score[7] = 0.f;
     }
@@ -253,6 +259,7 @@ hipError_t launch_heads(const HeadArgs &a, hipStream_t s)
     HeadKArgs k;
     k.fvec = a.fvec; k.ca4 = a.ca4; k.R = a.R; k.L = a.L; k.t = a.t; k.hw = *a.hw; k.scores = a.scores;
     k.want_energy = a.want_energy; k.en_part = a.en_part; k.clash_part = a.clash_part; k.do_update = a.do_update;
+    k.n_part = a.n_part; k.en_mode = a.en_mode; k.pool_div = a.pool_div;
     k.g2_r = a.g2_r; k.g_r = a.g_r; k.hg2_r = a.hg2_r; k.g2_t = a.g2_t; k.g_t = a.g_t; k.hg2_t = a.hg2_t;
     k.dt = a.dt; k.sqrt_dt = a.sqrt_dt; k.rot_noise = a.rot_noise; k.tr_noise = a.tr_noise; k.ode = a.ode;
     k.z_rot = a.z_rot; k.z_tr = a.z_tr; k.z_bstride = a.z_bstride;

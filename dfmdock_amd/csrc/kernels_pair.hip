@@ -1,0 +1,177 @@
+// kernels_pair.hip - receptor x ligand pair heads of the second model family (EGNN_Net).
+// Reference: src/models/egnn_net.py:413-416 (vec, unit_vec, D), :430-441 (energy), :444 (confidence),
+// :455-470 (force, pooling), :40-41 get_clashes; head shape :329-358:
+//     s(r,l) = Linear(256->1, no bias)( SiLU( LayerNorm( Linear(513->256, no bias)( cat[h_r, h_l, D(r,l)] ))))
+// The first Linear splits exactly into per-node halves and a distance column:
+//     z_c = P[r][c] + Q[l][c] + w_d[c] * D          P = W[:, :256] h_r,  Q = W[:, 256:512] h_l,  w_d = W[:, 512]
+// so the per-pair work is elementwise over the 256 channels (two statistics + SiLU + dot): VALU-bound, no MFMA.
+//
+// Layout: a workgroup owns one trajectory and a tile of 64 receptor residues whose P rows sit TRANSPOSED in LDS
+// (Pt[c][r], 65-float rows: lane r reads without bank conflicts); lanes = receptor residues, the four waves stride
+// over the ligand residues, and everything that depends on (l, c) only - Q, w_d, LayerNorm affine, w3 - is
+// wave-uniform and comes through scalar loads.  No cross-lane traffic inside the channel loops; one wave
+// reduction per (l, tile) for the force, fixed-order partials for the scalars (no atomics).
+#include "dfm_device.h"
+#include "dfm_internal.h"
+
+namespace dfm {
+
+constexpr int PT_LD = 65;
+constexpr int PAIR_LDS_BYTES = H * PT_LD * 4;   // 66560
+
+struct PairKArgs {
+    const float *P, *Q;        // [B][N][H]; receptor rows of P and ligand rows of Q are read
+    const float4 *ca4;         // [B][N] centred CA
+    int R, L;
+    const float *w_d, *ln_w, *ln_b, *w3;
+    int mode;                  // 0 force (+ clash count), 1 energy (masked D < cut_off), 2 confidence
+    float cut_off;
+    float *fpart;              // mode 0: [B][RT][L][3]
+    float *spart;              // mode 1: [B][RT*4][2] (sum, count)   mode 2: [B][RT*4][2] (sum, -)
+    int32_t *clash_part;       // mode 0: [B][RT*4]
+};
+
+template <int EXACT>   // 1: three-pass LayerNorm, expf/division (fp32 engine); 0: sum / sum-of-squares, fast SiLU
+__global__ __launch_bounds__(256) void k_pair_head(PairKArgs p)
+{
+    extern __shared__ float Pt[];
+    const int rt = blockIdx.x, b = blockIdx.y, RT = gridDim.x, N = p.R + p.L;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = rt * 64 + lane;
+    const bool valid = r < p.R;
+
+    // stage the tile: coalesced float4 rows from global, transposed scalar writes to LDS
+    for (int idx = threadIdx.x; idx < 64 * (H / 4); idx += 256) {
+        const int row = idx >> 6, c4 = idx & 63, gr = rt * 64 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < p.R) v = *reinterpret_cast<const float4 *>(p.P + ((size_t)b * N + gr) * H + c4 * 4);
+        Pt[(c4 * 4 + 0) * PT_LD + row] = v.x; Pt[(c4 * 4 + 1) * PT_LD + row] = v.y;
+        Pt[(c4 * 4 + 2) * PT_LD + row] = v.z; Pt[(c4 * 4 + 3) * PT_LD + row] = v.w;
+    }
+    __syncthreads();
+
+    const float4 xr = p.ca4[(size_t)b * N + (valid ? r : 0)];
+    const float *Pl = Pt + lane;
+    double s_acc = 0, c_acc = 0;
+    int clash = 0;
+    for (int l = wave; l < p.L; l += 4) {
+        const float4 xl = p.ca4[(size_t)b * N + p.R + l];
+        const float dx = xr.x - xl.x, dy = xr.y - xl.y, dz = xr.z - xl.z;
+        const float D = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float *Ql = p.Q + ((size_t)b * N + p.R + l) * H;     // wave-uniform: scalar loads
+        float mean, rstd;
+        if (EXACT) {
+            float s = 0.f;
+#pragma unroll 16
+            for (int c = 0; c < H; ++c) s += (Pl[c * PT_LD] + Ql[c]) + p.w_d[c] * D;
+            mean = s * (1.0f / H);
+            float v = 0.f;
+#pragma unroll 16
+            for (int c = 0; c < H; ++c) {
+                const float d = ((Pl[c * PT_LD] + Ql[c]) + p.w_d[c] * D) - mean;
+                v += d * d;
+            }
+            rstd = 1.0f / sqrtf(v * (1.0f / H) + 1e-5f);
+        } else {
+            float s = 0.f, q = 0.f;
+#pragma unroll 16
+            for (int c = 0; c < H; ++c) {
+                const float z = fmaf(p.w_d[c], D, Pl[c * PT_LD]) + Ql[c];
+                s += z;
+                q = fmaf(z, z, q);
+            }
+            mean = s * (1.0f / H);
+            rstd = __builtin_amdgcn_rsqf(fmaxf(q * (1.0f / H) - mean * mean, 0.f) + 1e-5f);
+        }
+        float o = 0.f;
+        if (EXACT) {
+#pragma unroll 16
+            for (int c = 0; c < H; ++c) {
+                const float z = (Pl[c * PT_LD] + Ql[c]) + p.w_d[c] * D;
+                const float y = (z - mean) * rstd * p.ln_w[c] + p.ln_b[c];
+                o += silu_exact(y) * p.w3[c];
+            }
+        } else {
+            const float nm = -mean * rstd;
+#pragma unroll 16
+            for (int c = 0; c < H; ++c) {
+                const float z = fmaf(p.w_d[c], D, Pl[c * PT_LD]) + Ql[c];
+                const float y = fmaf(fmaf(z, rstd, nm), p.ln_w[c], p.ln_b[c]);
+                const float e = __builtin_amdgcn_exp2f(y * -1.44269504088896f);
+                o = fmaf(y * __builtin_amdgcn_rcpf(1.0f + e), p.w3[c], o);
+            }
+        }
+        if (!valid) o = 0.f;
+        if (p.mode == 0) {
+            // fij = F.normalize(vec) * s ; the tile's share of sum_r fij for this ligand residue
+            const float inv = 1.0f / fmaxf(D, 1e-12f);
+            const float fx = wave_sum(dx * inv * o), fy = wave_sum(dy * inv * o), fz = wave_sum(dz * inv * o);
+            if (lane == 0) {
+                float *fo = p.fpart + (((size_t)b * RT + rt) * p.L + l) * 3;
+                fo[0] = fx; fo[1] = fy; fo[2] = fz;
+            }
+            clash += (valid && D <= 3.0f) ? 1 : 0;
+        } else if (p.mode == 1) {
+            if (valid && D < p.cut_off) { s_acc += (double)o; c_acc += 1.0; }
+        } else {
+            s_acc += (double)o;
+        }
+    }
+    if (p.mode == 0) {
+        const int tot = (int)wave_sum((float)clash);       // <= 64 * L / 4 per wave: exact in fp32
+        if (lane == 0) p.clash_part[(size_t)b * RT * 4 + rt * 4 + wave] = tot;
+    } else {
+        const double st = wave_sum_d(s_acc), ct = wave_sum_d(c_acc);
+        if (lane == 0) {
+            float *so = p.spart + ((size_t)b * RT * 4 + rt * 4 + wave) * 2;
+            so[0] = (float)st; so[1] = (float)ct;
+        }
+    }
+}
+
+// f[b][l] = agg over receptor tiles (fixed order) ; confidence[b] = mean over all pairs
+__global__ __launch_bounds__(256) void k_pair_finish(const float *__restrict__ fpart, int RT, int L, float inv_pool,
+                                                     float *__restrict__ fvec, const float *__restrict__ cpart, int R,
+                                                     float *__restrict__ conf)
+{
+    const int b = blockIdx.x;
+    if (fvec) {
+        for (int q = threadIdx.x; q < L * 3; q += blockDim.x) {
+            double s = 0;
+            for (int t = 0; t < RT; ++t) s += fpart[((size_t)b * RT + t) * L * 3 + q];
+            fvec[(size_t)b * L * 3 + q] = (float)(s * inv_pool);
+        }
+    }
+    if (conf && threadIdx.x == 0) {
+        double s = 0;
+        for (int t = 0; t < RT * 4; ++t) s += cpart[((size_t)b * RT * 4 + t) * 2];
+        conf[b] = (float)(s / ((double)R * L));
+    }
+}
+
+hipError_t launch_pair_head(const PairArgs &a, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_head<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_head<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    PairKArgs k;
+    k.P = a.P; k.Q = a.Q; k.ca4 = a.ca4; k.R = a.R; k.L = a.L; k.w_d = a.w_d; k.ln_w = a.ln_w; k.ln_b = a.ln_b; k.w3 = a.w3;
+    k.mode = a.mode; k.cut_off = a.cut_off; k.fpart = a.fpart; k.spart = a.spart; k.clash_part = a.clash_part;
+    const dim3 grid((a.R + 63) / 64, a.B);
+    if (a.exact) hipLaunchKernelGGL(k_pair_head<1>, grid, dim3(256), PAIR_LDS_BYTES, s, k);
+    else hipLaunchKernelGGL(k_pair_head<0>, grid, dim3(256), PAIR_LDS_BYTES, s, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_finish(const float *fpart, int B, int R, int L, float inv_pool, float *fvec, const float *cpart,
+                              float *conf, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pair_finish, dim3(B), dim3(256), 0, s, fpart, (R + 63) / 64, L, inv_pool, fvec, cpart, R, conf);
+    return hipGetLastError();
+}
+
+}  // namespace dfm

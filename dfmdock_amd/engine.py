@@ -105,10 +105,11 @@ class Complex:
         N, Lg, K, H = self.N, self.L, self.K, self.model.hp.node_dim
         o = dict(tr_score=np.zeros((B, 3), np.float32), rot_score=np.zeros((B, 3), np.float32),
                  energy=np.zeros((B,), np.float32), num_clashes=np.zeros((B,), np.int32),
-                 f=np.zeros((B, Lg, 3), np.float32))
+                 f=np.zeros((B, Lg, 3), np.float32), confidence=np.zeros((B,), np.float32))
         out = L.ScoreOutC()
         out.tr_score, out.rot_score = _p(o["tr_score"]), _p(o["rot_score"])
         out.energy, out.num_clashes, out.f = _p(o["energy"]), _p(o["num_clashes"], L.I32P), _p(o["f"])
+        out.confidence = _p(o["confidence"])
         if debug:
             o.update(h_last=np.zeros((B, N, H), np.float32), h_first=np.zeros((B, N, H), np.float32),
                      edges=np.zeros((B, N, K), np.int32), edge_codes=np.zeros((B, N, K), np.uint32))

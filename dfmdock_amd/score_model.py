@@ -10,6 +10,8 @@ math.  PyTorch is only the tensor container the reference's callers expect.
   Euler_Maruyama_sampler      <- src/inference_base.py:390-468
   sample_trajectories         <- the `for i in range(num_samples)` loops of src/inference_base.py:483,:644,
                                  batched on the GPU
+  DFMDock                     <- src/models/DFMDock.py:21-75 (second model family: EGNN_Net behind
+                                 move_to_lig_center), forward(batch) only - the training half is out of scope
 """
 from __future__ import annotations
 
@@ -133,6 +135,39 @@ class Score_Model:
         return {"tr_score": torch.from_numpy(r["tr_score"]), "rot_score": torch.from_numpy(r["rot_score"]),
                 "energy": torch.tensor(float(r["energy"][0]), dtype=torch.float32), "f": torch.from_numpy(r["f"][0]),
                 "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64)}
+
+    __call__ = forward
+
+
+class DFMDock(Score_Model):
+    """Drop-in for the reference's second model family at inference: ``DFMDock.forward(batch)`` =
+    ``move_to_lig_center`` + ``EGNN_Net(batch, predict=True)`` (DFMDock.py:68-75, egnn_net.py:408-505).
+
+    Output keys follow egnn_net.py:486-495: tr_score [1,3], rot_score [1,3], energy [], f [L,3], num_clashes [],
+    confidence_logits [].  ``dist_logits`` [R,L,64] and ``ires_logits`` feed training losses only
+    (DFMDock.py:196-215) and are not evaluated.  The diffusers and the Euler-Maruyama sampler are shared with
+    Score_Model, so ``Euler_Maruyama_sampler(model, batch)`` / ``sample_trajectories`` accept this class too.
+    """
+
+    def __init__(self, weights, hp: HParams | None = None, precision: str = "bf16", device_index: int = 0, seed: int = 0):
+        hp = hp or HParams(family=1, mask_dist=20.0)
+        if hp.family != 1:
+            raise ValueError("DFMDock needs HParams(family=1)")
+        super().__init__(weights, hp=hp, precision=precision, device_index=device_index, seed=seed)
+
+    def forward(self, batch):
+        import torch
+        cx = self.complex_for(batch)
+        t = _np(batch["t"]).reshape(-1)
+        if t.size != 1:
+            raise ValueError("batch['t'] must hold one time value (the reference runs batch_size=1)")
+        self._calls += 1
+        r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, bf16=self.precision == "bf16",
+                     f16=self.precision == "f16", energy=True)
+        return {"tr_score": torch.from_numpy(r["tr_score"]), "rot_score": torch.from_numpy(r["rot_score"]),
+                "energy": torch.tensor(float(r["energy"][0]), dtype=torch.float32), "f": torch.from_numpy(r["f"][0]),
+                "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64),
+                "confidence_logits": torch.tensor(float(r["confidence"][0]), dtype=torch.float32)}
 
     __call__ = forward
 

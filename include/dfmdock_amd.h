@@ -62,6 +62,11 @@ typedef struct {
     float mask_dist;           /* 22.0  angle-feature mask              */
     double r3_min_sigma, r3_max_sigma;    /* 0.1, 30.0                  */
     double so3_min_sigma, so3_max_sigma;  /* 0.1, 1.5 (logarithmic)     */
+    int family;                /* 0: Score_Net (src/models/score_net_mlsb.py:249-425, what inference_single.py loads);
+                                  1: EGNN_Net behind DFMDock.forward (src/models/egnn_net.py:408-505,
+                                     src/models/DFMDock.py:68-75, configs/model/DFMDock.yaml: mask_dist 20):
+                                     no coordinate update, pair force / energy / confidence heads          */
+    int agg_mean;              /* family 1: `agg` 'mean' (1, default) or 'sum' (0), egnn_net.py:438-474     */
 } dfm_hparams;
 
 /* flags for dfm_score / dfm_sample */
@@ -88,6 +93,7 @@ typedef struct {
     float *h_first;       /* [B,N,H]  node features after the first layer               */
     int32_t *edges;       /* [B,N,K]  edge list actually used                           */
     uint32_t *edge_codes; /* [B,N,K]  packed feature bins: d | omega<<6 | theta<<11 | phi<<16 | relpos<<20 */
+    float *confidence;    /* [B]      family 1 + DFM_F_ENERGY: confidence_logits (egnn_net.py:444); may be NULL */
 } dfm_score_out;
 
 /* Injected randomness for parity tests (every pointer may be NULL = draw natively with Philox) */

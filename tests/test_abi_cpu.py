@@ -32,8 +32,11 @@ def test_param_count_and_default_hparams():
     hp = _lib.HParamsC()
     _lib.lib().dfm_default_hparams(C.byref(hp))
     ref = HParams()
+    from dfmdock_amd.weights import HParams as HP
+    hp1 = engine.hparams_c(HP(family=1, mask_dist=20.0))
+    assert _lib.lib().dfm_param_count(C.byref(hp1)) == n_params(HP(family=1)) == 3913543      # EGNN_Net (f-2)
     for k, v in ref.as_dict().items():
-        assert getattr(hp, k) == pytest.approx(v), k
+        assert getattr(hp, k) == pytest.approx(float(v)), k
     assert _lib.lib().dfm_param_count(C.byref(engine.hparams_c())) == n_params() == 3566919
 
 
