@@ -12,7 +12,8 @@
  *   dfm_complex_create  <- get_batch_from_inputs + get_position_matrix
  *                          (src/inference_base.py:192-253)
  *   dfm_score           <- Score_Model.forward(batch)  (src/models/score_model_mlsb.py:61-63 ->
- *                          src/models/score_net_mlsb.py:343-425)
+ *                          src/models/score_net_mlsb.py:343-425); with dfm_hparams.family = 1:
+ *                          DFMDock.forward(batch) (src/models/DFMDock.py:68-75 -> src/models/egnn_net.py:408-505)
  *   dfm_sample          <- Euler_Maruyama_sampler(model, batch, ...) (src/inference_base.py:390-468),
  *                          batched over B independent trajectories
  *   dfm_diffusion_coef  <- R3Diffuser.diffusion_coef / SO3Diffuser.diffusion_coef
