@@ -367,16 +367,21 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 auto mfma_chunk = [&](int kc) {
                     wave_lds_fence();
                     stamp(3 + 2 * kc);
+                    // 32 MFMAs on consecutive weight fragments; the fragment reads run BDEPTH - 1 ahead in a static
+                    // register ring (one register set makes every MFMA wait a full LDS round trip)
+                    constexpr int BDEPTH = 3;
+                    const uint4 *wq = Wf + (size_t)kc * 32 * 64 + lane;
+                    Frag bq[BDEPTH], af[2];
 #pragma unroll
-                    for (int kq = 0; kq < 4; ++kq) {
-                        Frag af;
-                        af.u = *reinterpret_cast<const uint4 *>(stage + l31 * 128 + (((kq * 2 + h) ^ ((l31 >> 1) & 7)) << 4));
+                    for (int d = 0; d < BDEPTH - 1; ++d) bq[d].u = wq[d * 64];
+                    af[0].u = *reinterpret_cast<const uint4 *>(stage + l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4));
 #pragma unroll
-                        for (int nt = 0; nt < 8; ++nt) {
-                            Frag bf;
-                            bf.u = Wf[((kc * 4 + kq) * 8 + nt) * 64 + lane];
-                            acc[nt] = mfma16<F16>(af, bf, acc[nt]);
-                        }
+                    for (int m = 0; m < 32; ++m) {
+                        if (m + BDEPTH - 1 < 32) bq[(m + BDEPTH - 1) % BDEPTH].u = wq[(m + BDEPTH - 1) * 64];
+                        if ((m & 7) == 0 && m < 24)
+                            af[((m >> 3) + 1) & 1].u = *reinterpret_cast<const uint4 *>(
+                                stage + l31 * 128 + (((((m >> 3) + 1) * 2 + h) ^ ((l31 >> 1) & 7)) << 4));
+                        acc[m & 7] = mfma16<F16>(af[(m >> 3) & 1], bq[m % BDEPTH], acc[m & 7]);
                     }
                     wave_lds_fence();
                     stamp(4 + 2 * kc);
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     part[r] = row < K ? sigmoid_fast(part[r] + p.att_b) : 0.f;   // attention gate; masked rows -> 0
                 }
                 const bool store_m = p.last && i >= p.R;
-                if (store_m) {
+                if (store_m) {   // the last layer's launch is bound by these 2.5 GB of HBM writes, not by store issue (measured)
                     uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * KPAD) * H;
 #pragma unroll
                     for (int nt = 0; nt < 8; ++nt)

@@ -7,7 +7,7 @@ python - "$f" "${PAT}" "${VAR}=$a" <<'PY'
 import csv, re, sys
 for r in csv.DictReader(open(sys.argv[1])):
     if re.search(sys.argv[2], r["Name"]):
-        print(f'{sys.argv[3]}  {r["Name"][:44]:44s} calls {r["Calls"]:>5s}  avg {float(r["AverageNs"])/1e3:9.1f} us  {r["Percentage"]:>6s} %')
+        print(f'{sys.argv[3]}  {r["Name"][:44]:44s} calls {r["Calls"]:>5s}  avg {float(r["AverageNs"])/1e3:9.1f} us  min {float(r["MinNs"])/1e3:8.1f}  max {float(r["MaxNs"])/1e3:8.1f}  {r["Percentage"]:>6s} %')
 PY
 grep -o '"value": [0-9.]*' /tmp/b_$a.log | head -1
 done
