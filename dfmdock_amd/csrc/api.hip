@@ -226,22 +226,6 @@ static std::vector<uint16_t> pack_frags(const float *W /*[256 out][256 in]*/, bo
                 }
     return f;
 }
-static std::vector<uint16_t> pack_frags_wr(const float *W /*[256 out][256 in]*/, bool f16)
-{   // A-operand fragments of k_edge_wr: wave w owns channels 32w..32w+31; MFMA row rho <-> channel
-    // 32w + 16*((rho>>2)&1) + 4*(rho>>3) + (rho&3), so that a lane's 16 accumulator rows are 16 contiguous channels
-    std::vector<uint16_t> f((size_t)16 * 8 * 64 * 8);
-    for (int kk = 0; kk < 16; ++kk)
-        for (int w = 0; w < 8; ++w)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 8; ++e) {
-                    const int rho = lane & 31;
-                    const int n = 32 * w + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
-                    const int k = kk * 16 + (lane >> 5) * 8 + e;
-                    const float v = W[(size_t)n * H + k];
-                    f[(((size_t)kk * 8 + w) * 64 + lane) * 8 + e] = f16 ? f2h(v) : f2bf(v);
-                }
-    return f;
-}
 // split-bf16 operands of k_gemm_split, tiled in K-stage order: [K/32][4 k-groups][Nout][8] (W is [Nout][K] row-major)
 static void split_bf16(const float *W, int Nout, int K, std::vector<uint16_t> &hi, std::vector<uint16_t> &lo)
 {
@@ -324,7 +308,6 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
         up(&D.w_r, w_r.data(), w_r.size()); up(&D.T, T.data(), T.size()); up16(&D.T2b, T2b);
         const std::vector<float> W2t = transpose256(Lw.e2_w);
         up(&D.W2t, W2t.data(), W2t.size()); up16(&D.W2f, pack_frags(Lw.e2_w)); up16(&D.W2f16, pack_frags(Lw.e2_w, true));
-        up16(&D.W2tb, pack_frags_wr(Lw.e2_w, false)); up16(&D.W2t16, pack_frags_wr(Lw.e2_w, true));
         up(&D.b2, Lw.e2_b, H); up(&D.att_w, Lw.att_w, H); D.att_b = Lw.att_b[0];
         up(&D.W3, Lw.n1_w, (size_t)H * 2 * H); up(&D.b3, Lw.n1_b, H);
         up(&D.gn_w, Lw.gn_w, H); up(&D.gn_b, Lw.gn_b, H); up(&D.gn_ms, Lw.gn_ms, H);

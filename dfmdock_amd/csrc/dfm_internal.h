@@ -40,7 +40,6 @@ struct LayerDev {
     float *W2t;       // [256 in][256 out] edge_mlp.2.weight transposed (fp32 kernel)
     uint16_t *W2f;    // [16][8][64][8] bf16 MFMA B-fragments of edge_mlp.2.weight
     uint16_t *W2f16;  // same, fp16
-    uint16_t *W2tb, *W2t16;   // [16][8 waves][64][8] A-operand fragments of the weights-in-registers kernel (bf16 / fp16)
     float *b2;        // [256]
     float *att_w;     // [256]
     float att_b;

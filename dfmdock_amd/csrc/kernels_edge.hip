@@ -44,7 +44,6 @@ struct EdgeKArgs {
     int last;
     float *fout;
     uint16_t *mbuf;
-    long long *tl;   // DFM_TIMELINE debug: per-phase s_memtime stamps of wave 0 / workgroup 0 (nullptr normally)
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -248,7 +247,7 @@ template <int F16> __device__ inline uint16_t to16(float x)
     else return __builtin_bit_cast(uint16_t, (__bf16)x);
 }
 
-template <int MODE, int F16, int TL = 0>   // MODE 0: edge messages (+ store of gated messages on the last layer), 1: coordinate MLP
+template <int MODE, int F16>   // MODE 0: edge messages (+ store of gated messages on the last layer), 1: coordinate MLP
                                  // F16 0: bf16 MFMA operands, 1: fp16 MFMA operands (3 more mantissa bits, same rate)
 __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 {
@@ -274,12 +273,6 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
     const float *bias_v = MODE == 0 ? p.b2 : p.bc1;       // bias of this contraction
     const float *dot_v = MODE == 0 ? p.att_w : p.wc2;     // att_w / wc2
 
-    int tl_tile = 0;
-    auto stamp = [&](int k) {
-        if constexpr (TL) {
-            if (blockIdx.x == 8 && wave == 0 && tl_tile < 64 && lane == 0) p.tl[tl_tile * 16 + k] = clock64();
-        }
-    };
     for (unsigned tt = (unsigned)slot * EDGE_WAVES + wave; tt < (unsigned)ntask; tt += (unsigned)wg_per_xcd * EDGE_WAVES) {
         const unsigned tq = tt / (unsigned)NTc, tr = tt - tq * (unsigned)NTc;
         const int u = xcd + 8 * (int)tq;
@@ -296,7 +289,6 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
         float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // MODE 1: sum_s cdiff * w
 
         for (int mt = 0; mt < ntile; ++mt) {
-            stamp(0);
             f32x16 acc[8];
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt)
@@ -363,10 +355,8 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 RawP r0, r1;
                 gather_chunk(0);
                 gather(0, 0, r0); gather(0, 1, r1);
-                stamp(1);
                 auto mfma_chunk = [&](int kc) {
                     wave_lds_fence();
-                    stamp(3 + 2 * kc);
                     // 32 MFMAs on consecutive weight fragments; the fragment reads run BDEPTH - 1 ahead in a static
                     // register ring (one register set makes every MFMA wait a full LDS round trip)
                     constexpr int BDEPTH = 3;
@@ -384,14 +374,12 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                         acc[m & 7] = mfma16<F16>(af[(m >> 3) & 1], bq[m % BDEPTH], acc[m & 7]);
                     }
                     wave_lds_fence();
-                    stamp(4 + 2 * kc);
                 };
                 // two raw buffers in a ring: the gathers of pass q+2 fly under the arithmetic of passes q, q+1 (and the
                 // MFMA phase when they cross a chunk boundary)
 #pragma unroll 1
                 for (int kc = 0; kc < 3; ++kc) {
                     compute_store(0, r0); gather(kc, 2, r0);
-                    if (kc == 0) stamp(2);
                     compute_store(1, r1); gather(kc, 3, r1);
                     compute_store(2, r0); gather(kc + 1, 0, r0);
                     compute_store(3, r1); gather(kc + 1, 1, r1);
@@ -500,8 +488,6 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     }
                 }
             }
-            stamp(11);
-            tl_tile += 1;
         }   // mt
 
         if (MODE == 0) {
@@ -537,7 +523,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.w_r = w->w_r; k.T = w->T; k.W2t = w->W2t; k.b2 = w->b2; k.att_w = w->att_w; k.T2b = w->T2b;
     k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
-    k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.tl = nullptr;
+    k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf;
     return k;
 }
 
@@ -567,456 +553,6 @@ static int persistent_grid(long long wave_tasks)
     return (int)g;
 }
 
-// -------------------------------------------------------------------------------------------------
-// Edge-message kernel, software-pipelined ACROSS tiles (k_edge_bf16<0,.> restarts cold on every tile:
-// metadata load -> dependent gathers -> first SiLU, ~2 L2 latencies exposed per 32 rows).  Here the wave
-// walks one flat sequence of tiles (node, m-tile): during the last K-chunk of tile t it loads the row
-// metadata of tile t+1 into the registers the gathers no longer need, and it issues tile t+1's first
-// chunk of gathers right before tile t's epilogue, so both latencies hide under VALU/MFMA work.
-template <int F16, int NW>   // NW waves per workgroup: 8 (two per SIMD, 256 registers) or 4 (one per SIMD, 512 registers)
-__global__ __launch_bounds__(NW * 64) void k_edge_msg(EdgeKArgs p)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint4 *Wf = reinterpret_cast<uint4 *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char *stage = smem + LDS_WF_BYTES + wave * LDS_STAGE_BYTES;
-    const int h = lane >> 5, l31 = lane & 31;
-    const int r8 = lane >> 3, c8 = lane & 7;
-    for (int q = tid; q < LDS_WF_BYTES / 16; q += NW * 64) Wf[q] = p.Wf[q];
-    __syncthreads();   // the only workgroup barrier: everything below is wave-private
-
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
-    const int NT = p.N;
-    const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;
-    const int NTc = (NT + nsplit - 1) / nsplit;
-    const int U = p.B * nsplit;
-    const int nb = U > xcd ? (U - xcd + 7) >> 3 : 0;
-    const long long ntask = (long long)nb * NTc;
-    const long long tstride = (long long)wg_per_xcd * NW;
-    const int K = p.K, ntile = (K + 31) >> 5;
-
-    struct Tile { int b, i, mt; };
-    long long tt = (long long)slot * NW + wave - tstride;
-    // next node task of this wave (wave-uniform); false when the list is exhausted
-    auto next_node = [&](Tile &t) -> bool {
-        for (;;) {
-            tt += tstride;
-            if (tt >= ntask) return false;
-            const int u = xcd + 8 * (int)(tt / NTc);
-            const int idx = (u % nsplit) * NTc + (int)(tt % NTc);
-            if (idx >= NT) continue;
-            t.b = __builtin_amdgcn_readfirstlane(u / nsplit);
-            t.i = __builtin_amdgcn_readfirstlane(idx);
-            t.mt = 0;
-            return true;
-        }
-    };
-    auto advance = [&](Tile &t) -> bool {
-        if (t.mt + 1 < ntile) { t.mt += 1; return true; }
-        return next_node(t);
-    };
-
-    Tile cur;
-    if (!next_node(cur)) return;
-
-    int jq[4]; uint32_t codeq[4]; float radq[4], radn[4];
-    auto load_meta = [&](const Tile &t, float (&rad)[4]) {
-        const size_t ebase = ((size_t)t.b * p.N + t.i) * K;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int s = t.mt * 32 + q * 8 + r8;
-            const bool v = s < K;
-            jq[q] = v ? p.edges[ebase + s] : t.i;
-            codeq[q] = v ? p.codes[ebase + s] : 0u;
-            rad[q] = v ? p.radial[ebase + s] : 0.f;
-        }
-    };
-    float4 a0, a1, w0, w1;
-    auto gather_chunk = [&](const Tile &t, int kc) {
-        const float *Arow = p.A + (size_t)t.b * p.ab_bstride + (size_t)t.i * H + kc * 64 + c8 * 8;
-        a0 = *reinterpret_cast<const float4 *>(Arow);
-        a1 = *reinterpret_cast<const float4 *>(Arow + 4);
-        w0 = *reinterpret_cast<const float4 *>(p.w_r + kc * 64 + c8 * 8);
-        w1 = *reinterpret_cast<const float4 *>(p.w_r + kc * 64 + c8 * 8 + 4);
-    };
-    auto gather = [&](const Tile &t, int kc, int q, RawP &r) {
-        const uint32_t ch = kc * 64 + c8 * 8;
-        const uint32_t code = codeq[q];
-        r.bm = *reinterpret_cast<const uint4 *>(p.Bmb + (size_t)t.b * p.ab_bstride + ((uint32_t)jq[q] * H + ch));
-        const uint32_t i0 = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * H;
-        const uint32_t i1 = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * H;
-        const uint32_t i2 = (1056u + ((code >> 20) & 127u)) * H;
-        r.t0 = *reinterpret_cast<const uint4 *>(p.T2b + (i0 + ch));
-        r.t1 = *reinterpret_cast<const uint4 *>(p.T2b + (i1 + ch));
-        r.t2 = *reinterpret_cast<const uint4 *>(p.T2b + (i2 + ch));
-    };
-    auto compute_store = [&](int q, const RawP &r) {
-        const f2 rad2 = {radq[q], radq[q]};
-        f2 v[4] = {(f2){w0.x, w0.y} * rad2 + (f2){a0.x, a0.y}, (f2){w0.z, w0.w} * rad2 + (f2){a0.z, a0.w},
-                   (f2){w1.x, w1.y} * rad2 + (f2){a1.x, a1.y}, (f2){w1.z, w1.w} * rad2 + (f2){a1.z, a1.w}};
-        H8 t, t1, t2, bm;
-        t.u = r.t0; t1.u = r.t1; t2.u = r.t2; bm.u = r.bm;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            t.h[e] = __hadd2(__hadd2(t.h[e], t1.h[e]), t2.h[e]);
-            if constexpr (!F16) t.h[e] = __hadd2(t.h[e], bm.h[e]);
-            else v[e] = v[e] + (f2){__low2float(bm.h[e]), __high2float(bm.h[e])};
-            v[e] = v[e] + (f2){__low2float(t.h[e]), __high2float(t.h[e])};
-        }
-        Frag f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const f2 m = silu2(v[e]);
-            if constexpr (F16) { f.f[2 * e] = (_Float16)fminf(m.x, 65504.f); f.f[2 * e + 1] = (_Float16)fminf(m.y, 65504.f); }
-            else { f.b[2 * e] = (__bf16)m.x; f.b[2 * e + 1] = (__bf16)m.y; }
-        }
-        const int row = q * 8 + r8;
-        *reinterpret_cast<uint4 *>(stage + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = f.u;
-    };
-
-    RawP r0, r1, r2, r3;
-    load_meta(cur, radq);
-    gather_chunk(cur, 0);
-    gather(cur, 0, 0, r0); gather(cur, 0, 1, r1); gather(cur, 0, 2, r2); gather(cur, 0, 3, r3);
-    float colsum[8];
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt) colsum[nt] = 0.f;
-
-    for (;;) {
-        f32x16 acc[8];
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-            const float bias = p.b2[nt * 32 + l31];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = bias;
-        }
-        auto mfma_chunk = [&](int kc) {
-            wave_lds_fence();
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                Frag af;
-                af.u = *reinterpret_cast<const uint4 *>(stage + l31 * 128 + (((kq * 2 + h) ^ ((l31 >> 1) & 7)) << 4));
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    Frag bf;
-                    bf.u = Wf[((kc * 4 + kq) * 8 + nt) * 64 + lane];
-                    acc[nt] = mfma16<F16>(af, bf, acc[nt]);
-                }
-            }
-            wave_lds_fence();
-        };
-#pragma unroll 1
-        for (int kc = 0; kc < 3; ++kc) {
-            compute_store(0, r0); gather(cur, kc + 1, 0, r0);
-            compute_store(1, r1); gather(cur, kc + 1, 1, r1);
-            compute_store(2, r2); gather(cur, kc + 1, 2, r2);
-            compute_store(3, r3); gather(cur, kc + 1, 3, r3);
-            gather_chunk(cur, kc + 1);
-            mfma_chunk(kc);
-        }
-        // last chunk: jq / codeq are dead (all gathers of this tile are issued) -> fetch the next tile's metadata
-        Tile nxt = cur;
-        const bool has_next = advance(nxt);
-        if (has_next) load_meta(nxt, radn);
-        compute_store(0, r0); compute_store(1, r1); compute_store(2, r2); compute_store(3, r3);
-        mfma_chunk(3);
-        if (has_next) {   // half of the next tile's first chunk flies under this tile's epilogue (register budget)
-            gather_chunk(nxt, 0);
-            gather(nxt, 0, 0, r0); gather(nxt, 0, 1, r1);
-            if constexpr (NW == 4) { gather(nxt, 0, 2, r2); gather(nxt, 0, 3, r3); }
-        }
-
-        // ---- epilogue: lane owns columns nt*32 + l31, rows rowof(r) ------------------------------------
-        float part[16];
-        {
-            f2 part2[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) part2[q] = (f2){0.f, 0.f};
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const float vs = p.att_w[nt * 32 + l31];
-                const f2 vv = {vs, vs};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const f2 m = silu2((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
-                    acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
-                    part2[q] = m * vv + part2[q];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { part[2 * q] = part2[q].x; part[2 * q + 1] = part2[q].y; }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = cur.mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float g = half_sum_dpp(part[r]);
-            part[r] = row < K ? sigmoid_fast(g + p.att_b) : 0.f;   // attention gate; masked rows -> 0
-        }
-        if (p.last && cur.i >= p.R) {
-            uint16_t *Mout = p.mbuf + (((size_t)cur.b * p.L + (cur.i - p.R)) * KPAD) * H;
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = cur.mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    Mout[(size_t)row * H + nt * 32 + l31] = to16<F16>(acc[nt][r] * part[r]);
-                }
-        }
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-            f2 cs = {0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 8; ++q) cs = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){part[2 * q], part[2 * q + 1]} + cs;
-            colsum[nt] += cs.x + cs.y;
-        }
-        if (cur.mt == ntile - 1) {   // node complete: fixed-degree segment sum -> agg
-            const size_t node = (size_t)cur.b * p.N + cur.i;
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const float t = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
-                if (h == 0) p.agg[node * H + nt * 32 + l31] = t;
-                colsum[nt] = 0.f;
-            }
-        }
-        if (!has_next) break;
-        cur = nxt;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) radq[q] = radn[q];
-        if constexpr (NW != 4) { gather(cur, 0, 2, r2); gather(cur, 0, 3, r3); }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// "Weights in registers" edge-message kernel.
-//
-// The per-wave 32x256 tile of k_edge_bf16 needs 128 accumulator registers and the whole weight matrix in
-// LDS, which leaves two waves per SIMD starved of registers (no read-ahead, exposed LDS latency).  Here the
-// roles are turned around:
-//   * wave w of the 8-wave workgroup owns 32 OUTPUT channels for every node; its slice of the weight
-//     matrix (16 k-steps x 16 B/lane = 64 VGPRs) is loaded once and stays in registers for the launch;
-//   * the workgroup processes one node (64 rows: 60 edges + 4 masked) at a time.  Every wave produces 8 rows
-//     x 256 channels of the first activation (gather layout, whole 128-B lines) into a double-buffered,
-//     XOR-swizzled LDS tile [64][256] that all eight waves then consume;
-//   * the product is computed TRANSPOSED, D[channel][edge] = W[channel][k] * a1[edge][k]^T (weights as the
-//     MFMA A operand, the staged tile as B), so a lane holds 16 contiguous channels of ONE edge: the
-//     attention dot product is in-lane (+ one 8-way exchange through LDS), accumulators shrink to 32
-//     registers, and the 60-row segment sum is 16 DPP row reductions per wave;
-//   * one s_barrier per node: MFMAs of node n are issued interleaved with the producer VALU work of node
-//     n+1 (other half of the double buffer); gathers run one node ahead, row metadata two nodes ahead.
-constexpr int WR_WAVES = 8;
-constexpr int WR_TILE_BYTES = 64 * 256 * 2;                       // one staged node
-constexpr int WR_LDS_BYTES = 2 * WR_TILE_BYTES + 2 * 8 * 64 * 4;  // + double-buffered gate partials
-
-template <int F16>
-__global__ __launch_bounds__(WR_WAVES * 64) void k_edge_wr(EdgeKArgs p)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *gate_part = reinterpret_cast<float *>(smem + 2 * WR_TILE_BYTES);   // [2][8 waves][64 edges]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, l31 = lane & 31;
-    const int r8 = lane >> 3, c8 = lane & 7;
-    const int prow = wave * 8 + r8;                  // the ONE row of the node this lane produces (all four passes)
-    const int K = p.K;
-
-    // resident weight slice: A-operand fragments, row rho <-> channel 32w + 16*((rho>>2)&1) + 4*(rho>>3) + (rho&3)
-    uint4 Wreg[16];
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) Wreg[kk] = p.Wf[(kk * 8 + wave) * 64 + lane];
-    const int ch0 = wave * 32 + h * 16;              // this lane's 16 contiguous output channels
-
-    // node tasks of this workgroup (XCD-aware order, see k_edge_bf16)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
-    const int NT = p.N;
-    const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;
-    const int NTc = (NT + nsplit - 1) / nsplit;
-    const int U = p.B * nsplit;
-    const int nb = U > xcd ? (U - xcd + 7) >> 3 : 0;
-    const unsigned ntask = (unsigned)nb * (unsigned)NTc;
-    struct Node { int b, i; bool ok; };
-    auto node_at = [&](unsigned it) -> Node {        // it-th node of this workgroup; ok = false past the end / padding
-        const unsigned tt = (unsigned)slot + it * (unsigned)wg_per_xcd;
-        Node n{0, 0, false};
-        if (tt >= ntask) return n;
-        const unsigned tq = tt / (unsigned)NTc, tr = tt - tq * (unsigned)NTc;
-        const int u = xcd + 8 * (int)tq;
-        const int idx = (u % nsplit) * NTc + (int)tr;
-        n.b = u / nsplit; n.i = idx; n.ok = idx < NT;
-        return n;
-    };
-    const unsigned niter = ntask > (unsigned)slot ? (ntask - slot + wg_per_xcd - 1) / wg_per_xcd : 0;
-    if (niter == 0) return;
-
-    struct Meta { int j; uint32_t code; float rad; };
-    auto load_meta = [&](const Node &n) -> Meta {
-        Meta m{n.i, 0u, 0.f};
-        if (n.ok && prow < K) {
-            const size_t e = ((size_t)n.b * p.N + n.i) * K + prow;
-            m.j = p.edges[e]; m.code = p.codes[e]; m.rad = p.radial[e];
-        }
-        return m;
-    };
-    auto gather = [&](const Node &n, const Meta &m, int q, RawP &r) {
-        const uint32_t ch = q * 64 + c8 * 8;
-        const size_t ab = (size_t)n.b * p.ab_bstride;
-        r.bm = *reinterpret_cast<const uint4 *>(p.Bmb + ab + ((uint32_t)m.j * H + ch));
-        const uint32_t code = m.code;
-        const uint32_t i0 = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * H;
-        const uint32_t i1 = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * H;
-        const uint32_t i2 = (1056u + ((code >> 20) & 127u)) * H;
-        r.t0 = *reinterpret_cast<const uint4 *>(p.T2b + (i0 + ch));
-        r.t1 = *reinterpret_cast<const uint4 *>(p.T2b + (i1 + ch));
-        r.t2 = *reinterpret_cast<const uint4 *>(p.T2b + (i2 + ch));
-    };
-    // one producer pass: 8 channels of this lane's row -> SiLU -> 16-bit -> staged tile
-    auto compute_store = [&](const Node &n, float rad, int q, const RawP &r, char *tile) {
-        const float *Arow = p.A + (size_t)n.b * p.ab_bstride + (size_t)n.i * H + q * 64 + c8 * 8;
-        const float4 a0 = *reinterpret_cast<const float4 *>(Arow), a1 = *reinterpret_cast<const float4 *>(Arow + 4);
-        const float4 w0 = *reinterpret_cast<const float4 *>(p.w_r + q * 64 + c8 * 8);
-        const float4 w1 = *reinterpret_cast<const float4 *>(p.w_r + q * 64 + c8 * 8 + 4);
-        const f2 rad2 = {rad, rad};
-        f2 v[4] = {(f2){w0.x, w0.y} * rad2 + (f2){a0.x, a0.y}, (f2){w0.z, w0.w} * rad2 + (f2){a0.z, a0.w},
-                   (f2){w1.x, w1.y} * rad2 + (f2){a1.x, a1.y}, (f2){w1.z, w1.w} * rad2 + (f2){a1.z, a1.w}};
-        H8 t, t1, t2, bm;
-        t.u = r.t0; t1.u = r.t1; t2.u = r.t2; bm.u = r.bm;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            t.h[e] = __hadd2(__hadd2(t.h[e], t1.h[e]), t2.h[e]);
-            if constexpr (!F16) t.h[e] = __hadd2(t.h[e], bm.h[e]);
-            else v[e] = v[e] + (f2){__low2float(bm.h[e]), __high2float(bm.h[e])};
-            v[e] = v[e] + (f2){__low2float(t.h[e]), __high2float(t.h[e])};
-        }
-        Frag f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const f2 m = silu2(v[e]);
-            if constexpr (F16) { f.f[2 * e] = (_Float16)fminf(m.x, 65504.f); f.f[2 * e + 1] = (_Float16)fminf(m.y, 65504.f); }
-            else { f.b[2 * e] = (__bf16)m.x; f.b[2 * e + 1] = (__bf16)m.y; }
-        }
-        *reinterpret_cast<uint4 *>(tile + prow * 512 + (((q * 8 + c8) ^ (prow & 15)) << 4)) = f.u;
-    };
-
-    // ---- prologue: stage node 0, start the pipeline --------------------------------------------------
-    Node n0 = node_at(0), n1 = node_at(1), n2 = node_at(2);
-    Meta m0 = load_meta(n0), m1 = load_meta(n1), m2 = load_meta(n2);
-    RawP r0, r1, r2, r3;
-    gather(n0, m0, 0, r0); gather(n0, m0, 1, r1); gather(n0, m0, 2, r2); gather(n0, m0, 3, r3);
-    compute_store(n0, m0.rad, 0, r0, smem); gather(n1, m1, 0, r0);
-    compute_store(n0, m0.rad, 1, r1, smem); gather(n1, m1, 1, r1);
-    compute_store(n0, m0.rad, 2, r2, smem); gather(n1, m1, 2, r2);
-    compute_store(n0, m0.rad, 3, r3, smem); gather(n1, m1, 3, r3);
-    __syncthreads();
-
-    Node cur = n0, nx1 = n1, nx2 = n2;         // node being contracted, node being produced, node being gathered
-    Meta mx1 = m1, mx2 = m2;
-    for (unsigned it = 0; it < niter; ++it) {
-        char *tile_c = smem + (it & 1) * WR_TILE_BYTES, *tile_n = smem + ((it + 1) & 1) * WR_TILE_BYTES;
-        float *gp = gate_part + (it & 1) * 512;
-        const Node nx3 = node_at(it + 3);
-        const Meta mx3 = load_meta(nx3);            // metadata runs two nodes ahead of its gathers' consumers
-
-        // ---- contraction of `cur` (32 MFMAs) interleaved with the producer passes of `nx1` -----------------
-        f32x16 acc[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-        auto mfma_quarter = [&](int q4) {
-#pragma unroll
-            for (int kk = q4 * 4; kk < q4 * 4 + 4; ++kk)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int row = mt * 32 + l31;
-                    Frag bf, af;
-                    bf.u = *reinterpret_cast<const uint4 *>(tile_c + row * 512 + (((kk * 2 + h) ^ (row & 15)) << 4));
-                    af.u = Wreg[kk];
-                    acc[mt] = mfma16<F16>(af, bf, acc[mt]);
-                }
-        };
-        // (padding tasks can sit in the middle of the list, so every stage is predicated on its own node)
-        if (nx1.ok) compute_store(nx1, mx1.rad, 0, r0, tile_n);
-        gather(nx2, mx2, 0, r0); mfma_quarter(0);
-        if (nx1.ok) compute_store(nx1, mx1.rad, 1, r1, tile_n);
-        gather(nx2, mx2, 1, r1); mfma_quarter(1);
-        if (nx1.ok) compute_store(nx1, mx1.rad, 2, r2, tile_n);
-        gather(nx2, mx2, 2, r2); mfma_quarter(2);
-        if (nx1.ok) compute_store(nx1, mx1.rad, 3, r3, tile_n);
-        gather(nx2, mx2, 3, r3); mfma_quarter(3);
-
-        // ---- epilogue part 1: bias, SiLU, partial attention logits of this wave's 32 channels --------------
-        float4 bq[4], dq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bq[q] = *reinterpret_cast<const float4 *>(p.b2 + ch0 + q * 4);
-            dq[q] = *reinterpret_cast<const float4 *>(p.att_w + ch0 + q * 4);
-        }
-        float pg[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            f2 s2 = {0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f2 ma = silu2((f2){acc[mt][4 * q], acc[mt][4 * q + 1]} + (f2){bq[q].x, bq[q].y});
-                const f2 mb = silu2((f2){acc[mt][4 * q + 2], acc[mt][4 * q + 3]} + (f2){bq[q].z, bq[q].w});
-                acc[mt][4 * q] = ma.x; acc[mt][4 * q + 1] = ma.y; acc[mt][4 * q + 2] = mb.x; acc[mt][4 * q + 3] = mb.y;
-                s2 = ma * (f2){dq[q].x, dq[q].y} + s2;
-                s2 = mb * (f2){dq[q].z, dq[q].w} + s2;
-            }
-            pg[mt] = s2.x + s2.y;
-            pg[mt] += __shfl_xor(pg[mt], 32, 64);
-            if (h == 0) gp[wave * 64 + mt * 32 + l31] = pg[mt];
-        }
-        __syncthreads();   // tile_n complete, gate partials complete, every wave done reading tile_c
-
-        // ---- epilogue part 2: gate, fixed-degree segment sum -----------------------------------------------
-        if (cur.ok) {
-            f2 s2[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) s2[q] = (f2){0.f, 0.f};
-            const bool store_m = p.last && cur.i >= p.R;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int edge = mt * 32 + l31;
-                float g = 0.f;
-#pragma unroll
-                for (int w2 = 0; w2 < 8; ++w2) g += gp[w2 * 64 + edge];
-                g = edge < K ? sigmoid_fast(g + p.att_b) : 0.f;
-                const f2 g2 = {g, g};
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const f2 mg = (f2){acc[mt][2 * q], acc[mt][2 * q + 1]} * g2;
-                    acc[mt][2 * q] = mg.x; acc[mt][2 * q + 1] = mg.y;
-                    s2[q] = s2[q] + mg;
-                }
-                if (store_m) {
-                    Frag o0, o1;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        if constexpr (F16) {
-                            o0.f[e] = (_Float16)fminf(fmaxf(acc[mt][e], -65504.f), 65504.f);
-                            o1.f[e] = (_Float16)fminf(fmaxf(acc[mt][8 + e], -65504.f), 65504.f);
-                        } else { o0.b[e] = (__bf16)acc[mt][e]; o1.b[e] = (__bf16)acc[mt][8 + e]; }
-                    }
-                    uint16_t *Mo = p.mbuf + ((((size_t)cur.b * p.L + (cur.i - p.R)) * KPAD) + edge) * H + ch0;
-                    *reinterpret_cast<uint4 *>(Mo) = o0.u;
-                    *reinterpret_cast<uint4 *>(Mo + 8) = o1.u;
-                }
-            }
-            float sum[16];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { sum[2 * q] = half_sum_dpp(s2[q].x); sum[2 * q + 1] = half_sum_dpp(s2[q].y); }
-            if (l31 == 0) {
-                float *ao = p.agg + ((size_t)cur.b * p.N + cur.i) * H + ch0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4 *>(ao + q * 4) = make_float4(sum[4 * q], sum[4 * q + 1], sum[4 * q + 2], sum[4 * q + 3]);
-            }
-        }
-        cur = nx1; nx1 = nx2; nx2 = nx3;
-        mx1 = mx2; mx2 = mx3;
-    }
-}
-
 template <int MODE, int F16> static hipError_t launch_mfma_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
 {
     static bool attr_set = false;
@@ -1030,68 +566,11 @@ template <int MODE, int F16> static hipError_t launch_mfma_t(const EdgeKArgs &k,
     return hipGetLastError();
 }
 
-static int persistent_grid_nw(long long wave_tasks, int nw)
-{
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    long long wgs = (wave_tasks + nw - 1) / nw;
-    long long g = wgs < cus ? wgs : cus;
-    return (int)((g + 7) / 8 * 8);
-}
-
-template <int F16, int NW> static hipError_t launch_msg_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
-{
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_msg<F16, NW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_EDGE_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((k_edge_msg<F16, NW>), dim3(persistent_grid_nw(wave_tasks, NW)), dim3(NW * 64), LDS_EDGE_BYTES, s, k);
-    return hipGetLastError();
-}
-
-template <int F16> static hipError_t launch_wr_t(const EdgeKArgs &k, long long nodes, hipStream_t s)
-{
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_wr<F16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WR_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    long long g = nodes < cus ? nodes : cus;
-    g = (g + 7) / 8 * 8;
-    hipLaunchKernelGGL((k_edge_wr<F16>), dim3((unsigned)g), dim3(WR_WAVES * 64), WR_LDS_BYTES, s, k);
-    return hipGetLastError();
-}
-
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    // DFM_EDGE_KERNEL (A/B timing): "wr" = weights-in-registers kernel, "tile" = per-wave 32x256 tile kernel,
-    // "pipe8"/"pipe4" = cross-tile pipelined tile kernel
-    static const int which = [] {
-        const char *e = getenv("DFM_EDGE_KERNEL");
-        if (!e) return 0;
-        if (!strcmp(e, "wr")) return 1;
-        if (!strcmp(e, "pipe8")) return 8;
-        if (!strcmp(e, "pipe4")) return 4;
-        return 0;
-    }();
     EdgeKArgs k = to_kargs(a);
-    const long long tasks = (long long)a.B * a.N;
-    if (which == 1) {
-        k.Wf = reinterpret_cast<const uint4 *>(a.f16 ? a.lw->W2t16 : a.lw->W2tb);
-        return a.f16 ? launch_wr_t<1>(k, tasks, s) : launch_wr_t<0>(k, tasks, s);
-    }
     if (a.f16) k.Wf = reinterpret_cast<const uint4 *>(a.lw->W2f16);
-    if (which == 8) return a.f16 ? launch_msg_t<1, 8>(k, tasks, s) : launch_msg_t<0, 8>(k, tasks, s);
-    if (which == 4) return a.f16 ? launch_msg_t<1, 4>(k, tasks, s) : launch_msg_t<0, 4>(k, tasks, s);
+    const long long tasks = (long long)a.B * a.N;
     return a.f16 ? launch_mfma_t<0, 1>(k, tasks, s) : launch_mfma_t<0, 0>(k, tasks, s);
 }
 
