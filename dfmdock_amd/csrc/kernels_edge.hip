@@ -207,6 +207,25 @@ __device__ inline f2 silu2(f2 x)
     return x * r;
 }
 __device__ inline float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// a + (float)half of a packed fp16 pair in ONE plain-rate instruction (v_fma_mix_f32: f16 source 0 times 1.0 plus f32 source 2);
+// hipcc otherwise emits v_cvt_f32_f16 x2 + v_pk_add_f32, twice the issue time (tools/ubench/valu_rate.hip)
+__device__ inline float add_half_lo(float a, uint32_t h2)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(a));
+    return r;
+}
+__device__ inline float add_half_hi(float a, uint32_t h2)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(a));
+    return r;
+}
+__device__ inline f2 add_half2(f2 a, __half2 h)
+{
+    const uint32_t u = __builtin_bit_cast(uint32_t, h);
+    return (f2){add_half_lo(a.x, u), add_half_hi(a.y, u)};
+}
 
 __device__ inline void acc8(float (&v)[8], const uint4 &q)
 {
@@ -289,12 +308,15 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
         float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // MODE 1: sum_s cdiff * w
 
         for (int mt = 0; mt < ntile; ++mt) {
+            // accumulators start at the bias of this contraction (lane = output column): the epilogue needs no bias add
             f32x16 acc[8];
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
+            for (int nt = 0; nt < 8; ++nt) {
+                const float bcol = bias_v[nt * 32 + l31];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-            float bv[8], dv[8];   // bias / dot vector of the epilogue, fetched under the last MFMA phase
+                for (int r = 0; r < 16; ++r) acc[nt][r] = bcol;
+            }
+            float dv[8];   // dot vector of the epilogue, fetched under the last MFMA phase
 
             if (MODE == 0) {
                 // per-pass row data: pass q handles rows mt*32 + q*8 + r8 (rows >= K: self edge, code 0 - finite filler)
@@ -337,8 +359,8 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     for (int e = 0; e < 4; ++e) {
                         t.h[e] = __hadd2(__hadd2(t.h[e], t1.h[e]), t2.h[e]);
                         if constexpr (!F16) t.h[e] = __hadd2(t.h[e], bm.h[e]);
-                        else v[e] = v[e] + (f2){__low2float(bm.h[e]), __high2float(bm.h[e])};
-                        v[e] = v[e] + (f2){__low2float(t.h[e]), __high2float(t.h[e])};
+                        else v[e] = add_half2(v[e], bm.h[e]);
+                        v[e] = add_half2(v[e], t.h[e]);
                     }
                     Frag f;   // rows >= K hold finite filler, gated to 0 below
 #pragma unroll
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 compute_store(0, r0); gather(3, 2, r0);
                 compute_store(1, r1); gather(3, 3, r1);
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) { bv[nt] = bias_v[nt * 32 + l31]; dv[nt] = dot_v[nt * 32 + l31]; }
+                for (int nt = 0; nt < 8; ++nt) dv[nt] = dot_v[nt * 32 + l31];
                 compute_store(2, r0); compute_store(3, r1);
                 mfma_chunk(3);
             } else {
@@ -421,7 +443,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     }
                 }
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) { bv[nt] = bias_v[nt * 32 + l31]; dv[nt] = dot_v[nt * 32 + l31]; }
+                for (int nt = 0; nt < 8; ++nt) dv[nt] = dot_v[nt * 32 + l31];
             }
 
             // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) -------------
@@ -432,10 +454,10 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 for (int q = 0; q < 8; ++q) part2[q] = (f2){0.f, 0.f};
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
-                    const f2 vv = {dv[nt], dv[nt]}, bb = {bv[nt], bv[nt]};
+                    const f2 vv = {dv[nt], dv[nt]};
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const f2 m = silu2((f2){acc[nt][2 * q], acc[nt][2 * q + 1]} + bb);
+                        const f2 m = silu2((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
                         acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
                         part2[q] = m * vv + part2[q];
                     }

@@ -30,19 +30,25 @@ int main()
     float *out; long long *cyc, h;
     hipMalloc(&out, 1 << 24); hipMalloc(&cyc, 8);
     const char *names[] = {"v_fma_f32", "v_exp_f32", "v_rcp_f32", "v_pk_fma_f32", "v_pk_mul_f32", "cvt f32->f16->f32 + add", "exp + fma interleaved (2 instr)"};
-    const int iters = 2000;
+    const int iters = 20000;
+    int cus = 256; hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int op = 0; op < 7; ++op)
-        for (int wps = 1; wps <= 4; wps *= 2) {      // waves per SIMD: block of 256*wps threads on one CU
-            dim3 g(1), b(256 * wps);
+        for (int wps = 1; wps <= 8; wps *= 2) {      // waves per SIMD: one block of 256*wps threads per CU (8: two blocks of 1024)
+            dim3 g(wps == 8 ? 2 * cus : cus), b(wps == 8 ? 1024 : 256 * wps);
+            hipEventRecord(e0);
             switch (op) {
             case 0: k<0><<<g, b>>>(out, iters, cyc); break; case 1: k<1><<<g, b>>>(out, iters, cyc); break;
             case 2: k<2><<<g, b>>>(out, iters, cyc); break; case 3: k<3><<<g, b>>>(out, iters, cyc); break;
             case 4: k<4><<<g, b>>>(out, iters, cyc); break; case 5: k<5><<<g, b>>>(out, iters, cyc); break;
             case 6: k<6><<<g, b>>>(out, iters, cyc); break;
             }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms = 0; hipEventElapsedTime(&ms, e0, e1);
             hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
-            printf("%-34s waves/SIMD %d : %.2f cycles per (8-instr group / 8) per wave, %.2f per instr per SIMD\n", names[op], wps,
-                   (double)h / iters / 8, (double)h / iters / 8 / wps);
+            const double instr_per_simd = (double)iters * 8 * wps * (op == 6 ? 2 : (op == 5 ? 3 : 1));
+            printf("%-34s waves/SIMD %d : clock64 %.2f ticks/instr/wave | wall %.3f ms -> %.2f ns per wave64 instr per SIMD (%.2f cycles @2.4 GHz)\n",
+                   names[op], wps, (double)h / iters / 8 / (op == 6 ? 2 : (op == 5 ? 3 : 1)), ms, ms * 1e6 / instr_per_simd, ms * 1e6 / instr_per_simd * 2.4);
         }
     return 0;
 }
