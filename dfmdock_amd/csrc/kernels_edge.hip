@@ -381,7 +381,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     wave_lds_fence();
                     // 32 MFMAs on consecutive weight fragments; the fragment reads run BDEPTH - 1 ahead in a static
                     // register ring (one register set makes every MFMA wait a full LDS round trip)
-                    constexpr int BDEPTH = 3;
+                    constexpr int BDEPTH = 2;
                     const uint4 *wq = Wf + (size_t)kc * 32 * 64 + lane;
                     Frag bq[BDEPTH], af[2];
 #pragma unroll
@@ -415,32 +415,29 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 compute_store(2, r0); compute_store(3, r1);
                 mfma_chunk(3);
             } else {
-                const int s = mt * 32 + l31;
-                const bool valid = s < K;
-                const uint16_t *Mrow = p.mbuf + (((size_t)b * p.L + (i - p.R)) * KPAD + (valid ? s : 0)) * H + h * 8;
-                uint4 cur[4];
+                // the stored messages of this tile are already in A-fragment order (see the store below): one contiguous
+                // 1 KiB per wave instruction; all sixteen k-steps of the tile are requested up front (HBM latency, not
+                // MFMA rate, bounds this kernel); rows >= K were stored as zeros
+                const uint4 *Mt = reinterpret_cast<const uint4 *>(p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H)) + lane;
+                uint4 a16[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const uint4 *>(Mrow + q * 16);
-#pragma unroll 1
+                for (int kk = 0; kk < 16; ++kk) a16[kk] = Mt[kk * 64];
+                constexpr int CDEPTH = 4;      // weight-fragment LDS reads run three ahead in a static register ring
+                const uint4 *wq = Wf + lane;
+                Frag bq[CDEPTH];
+#pragma unroll
+                for (int d = 0; d < CDEPTH - 1; ++d) bq[d].u = wq[d * 64];
+#pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    uint4 a4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) a4[q] = valid ? cur[q] : make_uint4(0, 0, 0, 0);
-                    if (g < 3) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const uint4 *>(Mrow + ((g + 1) * 4 + q) * 16);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int mm = 0; mm < 32; ++mm) {
+                        const int m = g * 32 + mm;
+                        if (m + CDEPTH - 1 < 128) bq[(m + CDEPTH - 1) % CDEPTH].u = wq[(m + CDEPTH - 1) * 64];
                         Frag af;
-                        af.u = a4[q];
-#pragma unroll
-                        for (int nt = 0; nt < 8; ++nt) {
-                            Frag bf;
-                            bf.u = Wf[((g * 4 + q) * 8 + nt) * 64 + lane];
-                            acc[nt] = mfma16<F16>(af, bf, acc[nt]);
-                        }
+                        af.u = a16[m >> 3];
+                        acc[m & 7] = mfma16<F16>(af, bq[m % CDEPTH], acc[m & 7]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next group's reads (spills)
                 }
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) dv[nt] = dot_v[nt * 32 + l31];
@@ -476,14 +473,17 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 }
                 const bool store_m = p.last && i >= p.R;
                 if (store_m) {   // the last layer's launch is bound by these 2.5 GB of HBM writes, not by store issue (measured)
-                    uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * KPAD) * H;
+                    // A-fragment order of the coordinate-MLP kernel: [k-step 16][lane half 2][row 32][8 channels] per tile
+                    uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H);
 #pragma unroll
-                    for (int nt = 0; nt < 8; ++nt)
+                    for (int nt = 0; nt < 8; ++nt) {
+                        const int cbase = (((nt * 2 + (l31 >> 4)) * 2 + ((l31 >> 3) & 1)) * 32) * 8 + (l31 & 7);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            Mout[(size_t)row * H + nt * 32 + l31] = to16<F16>(acc[nt][r] * part[r]);
+                            const int rowin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                            Mout[cbase + rowin * 8] = to16<F16>(acc[nt][r] * part[r]);
                         }
+                    }
                 }
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
@@ -494,20 +494,20 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 }
             } else {
                 // coord_mlp: w = clamp(sum_c silu(.) * wc2, +-2); x_i += mean_s (x_i - x_j)/(|x_i - x_j| + 1) * w
-                if (l31 == 0) {
+                // one lane per row (16 rows per half: lane l31 < 16 takes register row r = l31), so the 32 edge-index /
+                // coordinate loads of a tile are issued together instead of as a 16-long dependent chain in one lane
+                float w = part[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) w = l31 == r ? part[r] : w;
+                const int row = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;
+                if (l31 < 16 && row < K) {
                     const float4 *ca = p.ca4 + (size_t)b * p.N;
                     const float4 xi = ca[i];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (row < K) {
-                            const float w = fminf(fmaxf(part[r], -2.0f), 2.0f);
-                            const float4 xj = ca[p.edges[ebase + row]];
-                            const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-                            const float nrm = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f) + 1.0f;
-                            cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;
-                        }
-                    }
+                    w = fminf(fmaxf(w, -2.0f), 2.0f);
+                    const float4 xj = ca[p.edges[ebase + row]];
+                    const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f) + 1.0f;
+                    cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;
                 }
             }
         }   // mt
@@ -519,9 +519,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 if (h == 0) p.agg[node * H + nt * 32 + l31] = t;
             }
         } else {
-            cacc0 += __shfl_xor(cacc0, 32, 64);
-            cacc1 += __shfl_xor(cacc1, 32, 64);
-            cacc2 += __shfl_xor(cacc2, 32, 64);
+            cacc0 = wave_sum(cacc0); cacc1 = wave_sum(cacc1); cacc2 = wave_sum(cacc2);
             if (lane == 0) {
                 const float4 xi = p.ca4[node];
                 const float inv = 1.0f / (float)(K > 1 ? K : 1);
