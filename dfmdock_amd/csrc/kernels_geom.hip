@@ -122,29 +122,10 @@ __global__ __launch_bounds__(256) void k_knn_sample(const float4 *__restrict__ c
     for (int r = 0; r < NPL; ++r) dist[r] = val[r];
 
     int my_edge = -1;   // lane s keeps the winner of pass s
-    for (int s = 0; s < K; ++s) {
-        if (s == knn) {
-            // switch from distances to race keys for every candidate not yet taken
-#pragma unroll
-            for (int q = 0; q < NPL / 4; ++q) {
-                const u32x4 rnd = philox4x32((uint32_t)node, (uint32_t)(node >> 32) ^ ((uint32_t)(lane + 64 * q) << 8),
-                                             stream_id, RNG_EDGES, seed_lo, seed_hi);
-                const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = q * 4 + e;
-                    float d = dist[r];
-                    float key = __builtin_inff();
-                    if (val[r] != __builtin_inff()) {   // not taken by kNN, j < N
-                        d = d < 1e-10f ? 1e-10f : d;
-                        key = -logf(u01(rr[e])) * ((d * d) * d);
-                    }
-                    val[r] = key;
-                }
-            }
-        }
-        // arg-min of (value, j) over the wave, ties to the smallest j.  Values are non-negative floats, so their bit
-        // patterns order like unsigned integers: min value first (32-bit), then the smallest j that holds it.
+    // ---- kNN: `knn` exact passes of a wave-wide arg-min of (distance, j), ties to the smallest j.  Distances are
+    // non-negative floats, so their bit patterns order like unsigned integers: min value first (32-bit), then the
+    // smallest j that holds it.
+    for (int s = 0; s < knn; ++s) {
         uint32_t mv = 0xFFFFFFFFu;
 #pragma unroll
         for (int r = 0; r < NPL; ++r) { const uint32_t k = __float_as_uint(val[r]); mv = k < mv ? k : mv; }
@@ -158,6 +139,59 @@ __global__ __launch_bounds__(256) void k_knn_sample(const float4 *__restrict__ c
 #pragma unroll
         for (int r = 0; r < NPL; ++r) val[r] = r == rb ? __builtin_inff() : val[r];
         if (lane == s) my_edge = win;
+    }
+    if (nsamp > 0) {
+        // ---- sampling: race keys for every candidate not taken above; the nsamp smallest keys win.  The keys are
+        // random, so their six low mantissa bits are traded for the slot number (a 2^-17 relative perturbation of an
+        // Exp(1) draw): the 32-bit words are then unique inside a lane, each lane sorts its NPL words once (Batcher
+        // odd-even merge network on v_min_u32 / v_max_u32), and a pass is one wave minimum over the list heads plus a
+        // one-register shift in the winning lane.
+        uint32_t kq[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL / 4; ++q) {
+            const u32x4 rnd = philox4x32((uint32_t)node, (uint32_t)(node >> 32) ^ ((uint32_t)(lane + 64 * q) << 8),
+                                         stream_id, RNG_EDGES, seed_lo, seed_hi);
+            const uint32_t rr[4] = {rnd.x, rnd.y, rnd.z, rnd.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = q * 4 + e;
+                float d = dist[r];
+                float key = __builtin_inff();
+                if (val[r] != __builtin_inff()) {   // not taken by kNN, j < N
+                    d = d < 1e-10f ? 1e-10f : d;
+                    key = -logf(u01(rr[e])) * ((d * d) * d);
+                }
+                kq[r] = (__float_as_uint(key) & ~63u) | (uint32_t)r;
+            }
+        }
+        constexpr int P2 = NPL <= 4 ? 4 : (NPL <= 8 ? 8 : (NPL <= 16 ? 16 : (NPL <= 32 ? 32 : 64)));
+#pragma unroll
+        for (int pp = 1; pp < P2; pp *= 2)
+#pragma unroll
+            for (int k = pp; k >= 1; k /= 2)
+#pragma unroll
+                for (int j = k % pp; j <= P2 - 1 - k; j += 2 * k)
+#pragma unroll
+                    for (int ii = 0; ii <= (k - 1 < P2 - j - k - 1 ? k - 1 : P2 - j - k - 1); ++ii)
+                        if ((ii + j) / (2 * pp) == (ii + j + k) / (2 * pp) && ii + j + k < NPL) {
+                            const uint32_t lo = kq[ii + j] < kq[ii + j + k] ? kq[ii + j] : kq[ii + j + k];
+                            const uint32_t hi = kq[ii + j] < kq[ii + j + k] ? kq[ii + j + k] : kq[ii + j];
+                            kq[ii + j] = lo; kq[ii + j + k] = hi;
+                        }
+        for (int s = knn; s < K; ++s) {
+            const uint32_t wm = wave_min_u32(kq[0]);
+            const unsigned long long owners = __ballot(kq[0] == wm);
+            const int wl = __builtin_ctzll(owners);                  // lowest lane on a tie across lanes
+            const int slot = (int)(wm & 63u);
+            const int win = 4 * wl + 256 * (slot >> 2) + (slot & 3);  // wave-uniform
+            // shift the winning lane's list by one.  Written as a bit-select (v_bfi_b32) on a lane mask: a plain
+            // `pop ? kq[r + 1] : kq[r]` is canonicalised into a variable-index extract and lowered to NPL^2 selects
+            const uint32_t pm = lane == wl ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int r = 0; r + 1 < NPL; ++r) kq[r] = (kq[r + 1] & pm) | (kq[r] & ~pm);
+            kq[NPL - 1] |= pm;
+            if (lane == s) my_edge = win;
+        }
     }
     if (lane < K) edges[((size_t)b * N + i) * K + lane] = my_edge;
 }
