@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include <hip/hip_fp16.h>
 
@@ -174,16 +175,18 @@ __global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
 // =================================================================================================
 // 16-bit MFMA kernel (bf16 or fp16 operands).
 //
-// Workgroup = 8 waves, persistent, all 160 KiB of LDS: 128 KiB hold the bf16 B-fragments of the 256x256
-// weight matrix for the whole launch, 32 KiB are eight wave-private 4 KiB staging tiles.  A wave owns one
-// node at a time = two 32-row M-tiles (60 edges + 4 masked rows).  Per M-tile and per 64-channel chunk:
-//   producer  (gather layout: 8 adjacent lanes cover one row's 64 channels = whole 128-B lines):
-//             A_i + Bm_j + w_r*radial + 3 merged T rows (fp16 gathers) -> SiLU -> bf16 -> ds_write_b128 (XOR-swizzled)
-//   consumer  4 k-steps x 8 n-tiles of v_mfma_f32_32x32x16_bf16, A-fragments by ds_read_b128 from the
-//             staging tile, B-fragments by ds_read_b128 from the resident weights.
-// The two waves of a SIMD drift apart, so one wave's gathers/VALU run under the other's MFMAs.
-// Epilogue in the C layout (lane = column, registers = rows): +b2, SiLU, attention gate (in-lane dot +
-// 32-lane butterfly), row mask, 60-row segment sum in registers -> agg; no atomics.
+// Workgroup = 8 waves, persistent, all 160 KiB of LDS: 128 KiB hold the 16-bit B-fragments of the 256x256
+// weight matrix for the whole launch, 32 KiB are eight wave-private 4 KiB staging areas.  A wave owns one
+// node at a time = two 32-row M-tiles (60 edges + 4 masked rows).  Per M-tile, in eight 32-channel chunks:
+//   producer  (gather layout: 4 adjacent lanes cover one row's 32 channels = a 64-byte half line, 16 rows per pass):
+//             A_i + Bm_j + w_r*radial + 3 merged T rows (fp16 gathers) -> SiLU -> bf16/fp16 -> ds_write_b128 into the
+//             staging buffer of the NEXT chunk ([8-channel unit][row ^ 4*unit] x 16 B: conflict-free both ways)
+//   consumer  2 k-steps x 8 n-tiles of v_mfma_f32_32x32x16_{bf16,f16} on the CURRENT chunk's buffer, A-fragments and
+//             the resident weight fragments by ds_read_b128 (reads one ahead).
+// The producer arithmetic is cut into slices laid between the MFMAs in program order (scheduling barriers keep them
+// there), so a wave's MFMAs run in the shadow of its own VALU work; the gathers of chunk c + 2 are in flight meanwhile.
+// Epilogue in the C layout (lane = column, registers = rows): SiLU (bias is in the accumulator init), attention gate
+// (in-lane dot + DPP row reduction), row mask, 60-row segment sum in registers -> agg; no atomics.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -275,7 +278,6 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     char *stage = smem + LDS_WF_BYTES + wave * LDS_STAGE_BYTES;
     const int h = lane >> 5, l31 = lane & 31;
-    const int r8 = lane >> 3, c8 = lane & 7;            // producer layout: row-in-pass, 8-channel group
     for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
     __syncthreads();
 
@@ -318,27 +320,32 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
             }
             float dv[8];   // dot vector of the epilogue, fetched under the last MFMA phase
 
-            if (MODE == 0) {
-                // per-pass row data: pass q handles rows mt*32 + q*8 + r8 (rows >= K: self edge, code 0 - finite filler)
-                int jq[4]; uint32_t codeq[4]; float radq[4];
+            if constexpr (MODE == 0) {
+                // ---- interleaved form: a chunk is 32 channels (two MFMA k-steps, 16 MFMAs).  Producer layout: four
+                // adjacent lanes = one row's 64-byte half line, 16 rows per pass, two passes per chunk.  The wave's 4 KiB
+                // of staging are two 2 KiB buffers laid out [unit u = 8-channel group][row ^ 4u] x 16 B (conflict-free
+                // for the producer's writes and the MFMA A-fragment reads); while the MFMAs of chunk c read buffer c & 1,
+                // the arithmetic of chunk c + 1 fills the other one and the gathers of chunk c + 2 are issued.
+                const int r16 = lane >> 2, c4 = lane & 3;
+                int jq[2]; uint32_t codeq[2]; float radq[2];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int s = mt * 32 + q * 8 + r8;
+                for (int q = 0; q < 2; ++q) {
+                    const int s = mt * 32 + q * 16 + r16;
                     const bool v = s < K;
                     jq[q] = v ? p.edges[ebase + s] : i;
                     codeq[q] = v ? p.codes[ebase + s] : 0u;
                     radq[q] = v ? p.radial[ebase + s] : 0.f;
                 }
-                const float *Arow = p.A + ab + (size_t)i * H + c8 * 8;
-                float4 a0, a1, w0, w1;                 // per-chunk operands shared by the four passes
-                auto gather_chunk = [&](int kc) {
-                    a0 = *reinterpret_cast<const float4 *>(Arow + kc * 64);
-                    a1 = *reinterpret_cast<const float4 *>(Arow + kc * 64 + 4);
-                    w0 = *reinterpret_cast<const float4 *>(p.w_r + kc * 64 + c8 * 8);
-                    w1 = *reinterpret_cast<const float4 *>(p.w_r + kc * 64 + c8 * 8 + 4);
+                const float *Arow = p.A + ab + (size_t)i * H + c4 * 8;
+                float4 a0, a1, w0, w1;
+                auto gather_chunk = [&](int c) {
+                    a0 = *reinterpret_cast<const float4 *>(Arow + c * 32);
+                    a1 = *reinterpret_cast<const float4 *>(Arow + c * 32 + 4);
+                    w0 = *reinterpret_cast<const float4 *>(p.w_r + c * 32 + c4 * 8);
+                    w1 = *reinterpret_cast<const float4 *>(p.w_r + c * 32 + c4 * 8 + 4);
                 };
-                auto gather = [&](int kc, int q, RawP &r) {
-                    const uint32_t ch = kc * 64 + c8 * 8;
+                auto gather = [&](int c, int q, RawP &r) {
+                    const uint32_t ch = c * 32 + c4 * 8;
                     const uint32_t code = codeq[q];
                     r.bm = *reinterpret_cast<const uint4 *>(p.Bmb + ab + ((uint32_t)jq[q] * H + ch));
                     const uint32_t i0 = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * H;
@@ -348,72 +355,84 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     r.t1 = *reinterpret_cast<const uint4 *>(p.T2b + (i1 + ch));
                     r.t2 = *reinterpret_cast<const uint4 *>(p.T2b + (i2 + ch));
                 };
-                auto compute_store = [&](int q, const RawP &r) {
-                    const f2 rad2 = {radq[q], radq[q]};
-                    f2 v[4] = {(f2){w0.x, w0.y} * rad2 + (f2){a0.x, a0.y}, (f2){w0.z, w0.w} * rad2 + (f2){a0.z, a0.w},
-                               (f2){w1.x, w1.y} * rad2 + (f2){a1.x, a1.y}, (f2){w1.z, w1.w} * rad2 + (f2){a1.z, a1.w}};
-                    // table rows (and, with bf16 operands, Bm too) summed as packed fp16, then widened once
-                    H8 t, t1, t2, bm;
-                    t.u = r.t0; t1.u = r.t1; t2.u = r.t2; bm.u = r.bm;
+                // The producer arithmetic of one pass (8 channels of one row per lane) cut into eight slices, so that it can
+                // be laid between MFMAs in program order: even slice 2e = pre-activation of channel pair e, odd slice
+                // 2e + 1 = its SiLU + conversion; slice 7 also stores the finished 16 bytes.
+                H8 pt, pbm;
+                f2 pv[4];
+                Frag pf;
+                auto slice = [&](int q, int k, const RawP &r, char *buf) {
+                    const int e = k >> 1;
+                    if (k == 0) {
+                        H8 t1, t2;
+                        pt.u = r.t0; t1.u = r.t1; t2.u = r.t2; pbm.u = r.bm;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        t.h[e] = __hadd2(__hadd2(t.h[e], t1.h[e]), t2.h[e]);
-                        if constexpr (!F16) t.h[e] = __hadd2(t.h[e], bm.h[e]);
-                        else v[e] = add_half2(v[e], bm.h[e]);
-                        v[e] = add_half2(v[e], t.h[e]);
+                        for (int x = 0; x < 4; ++x) {
+                            pt.h[x] = __hadd2(__hadd2(pt.h[x], t1.h[x]), t2.h[x]);
+                            if constexpr (!F16) pt.h[x] = __hadd2(pt.h[x], pbm.h[x]);
+                        }
                     }
-                    Frag f;   // rows >= K hold finite filler, gated to 0 below
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f2 m = silu2(v[e]);
-                        if constexpr (F16) { f.f[2 * e] = (_Float16)fminf(m.x, 65504.f); f.f[2 * e + 1] = (_Float16)fminf(m.y, 65504.f); }
-                        else { f.b[2 * e] = (__bf16)m.x; f.b[2 * e + 1] = (__bf16)m.y; }
+                    if ((k & 1) == 0) {
+                        const f2 rad2 = {radq[q], radq[q]};
+                        const f2 wv = e == 0 ? (f2){w0.x, w0.y} : (e == 1 ? (f2){w0.z, w0.w} : (e == 2 ? (f2){w1.x, w1.y} : (f2){w1.z, w1.w}));
+                        const f2 av = e == 0 ? (f2){a0.x, a0.y} : (e == 1 ? (f2){a0.z, a0.w} : (e == 2 ? (f2){a1.x, a1.y} : (f2){a1.z, a1.w}));
+                        pv[e] = wv * rad2 + av;
+                        if constexpr (F16) pv[e] = add_half2(pv[e], pbm.h[e]);
+                        pv[e] = add_half2(pv[e], pt.h[e]);
+                    } else {
+                        const f2 m = silu2(pv[e]);
+                        if constexpr (F16) { pf.f[2 * e] = (_Float16)fminf(m.x, 65504.f); pf.f[2 * e + 1] = (_Float16)fminf(m.y, 65504.f); }
+                        else { pf.b[2 * e] = (__bf16)m.x; pf.b[2 * e + 1] = (__bf16)m.y; }
+                        if (k == 7) {
+                            const int row = q * 16 + r16;
+                            *reinterpret_cast<uint4 *>(buf + ((c4 * 32 + (row ^ (4 * c4))) << 4)) = pf.u;
+                        }
                     }
-                    const int row = q * 8 + r8;
-                    *reinterpret_cast<uint4 *>(stage + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4)) = f.u;
                 };
-                // every pass owns one raw buffer that is refilled in place for the NEXT chunk right after it is
-                // consumed: a whole chunk of gathers (16 x 1 KiB per wave) flies under the 32 MFMAs of this chunk
+                auto compute_store = [&](int q, const RawP &r, char *buf) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) slice(q, k, r, buf);
+                };
                 RawP r0, r1;
                 gather_chunk(0);
                 gather(0, 0, r0); gather(0, 1, r1);
-                auto mfma_chunk = [&](int kc) {
+                compute_store(0, r0, stage); gather(1, 0, r0);
+                compute_store(1, r1, stage); gather(1, 1, r1);
+                gather_chunk(1);
+                // one chunk: 16 MFMAs of chunk c; PRODUCE: the arithmetic of chunk c + 1, one slice after every MFMA in
+                // program order with a scheduling barrier behind it; GATHER: the loads of chunk c + 2.
+                auto chunk = [&](int c, auto produce, auto gather_next) {
+                    char *bufc = stage + (c & 1) * 2048, *bufn = stage + ((c + 1) & 1) * 2048;
                     wave_lds_fence();
-                    // 32 MFMAs on consecutive weight fragments; the fragment reads run BDEPTH - 1 ahead in a static
-                    // register ring (one register set makes every MFMA wait a full LDS round trip)
-                    constexpr int BDEPTH = 2;
-                    const uint4 *wq = Wf + (size_t)kc * 32 * 64 + lane;
-                    Frag bq[BDEPTH], af[2];
+                    Frag af[2];
 #pragma unroll
-                    for (int d = 0; d < BDEPTH - 1; ++d) bq[d].u = wq[d * 64];
-                    af[0].u = *reinterpret_cast<const uint4 *>(stage + l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4));
-#pragma unroll
-                    for (int m = 0; m < 32; ++m) {
-                        if (m + BDEPTH - 1 < 32) bq[(m + BDEPTH - 1) % BDEPTH].u = wq[(m + BDEPTH - 1) * 64];
-                        if ((m & 7) == 0 && m < 24)
-                            af[((m >> 3) + 1) & 1].u = *reinterpret_cast<const uint4 *>(
-                                stage + l31 * 128 + (((((m >> 3) + 1) * 2 + h) ^ ((l31 >> 1) & 7)) << 4));
-                        acc[m & 7] = mfma16<F16>(af[(m >> 3) & 1], bq[m % BDEPTH], acc[m & 7]);
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int un = ks * 2 + h;
+                        af[ks].u = *reinterpret_cast<const uint4 *>(bufc + ((un * 32 + (l31 ^ (4 * un))) << 4));
                     }
-                    wave_lds_fence();
-                };
-                // two raw buffers in a ring: the gathers of pass q+2 fly under the arithmetic of passes q, q+1 (and the
-                // MFMA phase when they cross a chunk boundary)
-#pragma unroll 1
-                for (int kc = 0; kc < 3; ++kc) {
-                    compute_store(0, r0); gather(kc, 2, r0);
-                    compute_store(1, r1); gather(kc, 3, r1);
-                    compute_store(2, r0); gather(kc + 1, 0, r0);
-                    compute_store(3, r1); gather(kc + 1, 1, r1);
-                    gather_chunk(kc + 1);
-                    mfma_chunk(kc);
-                }
-                compute_store(0, r0); gather(3, 2, r0);
-                compute_store(1, r1); gather(3, 3, r1);
+                    const uint4 *wq = Wf + (size_t)c * 16 * 64 + lane;
+                    Frag bq[2];
+                    bq[0].u = wq[0];
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) dv[nt] = dot_v[nt * 32 + l31];
-                compute_store(2, r0); compute_store(3, r1);
-                mfma_chunk(3);
+                    for (int m = 0; m < 16; ++m) {
+                        if (m + 1 < 16) bq[(m + 1) & 1].u = wq[(m + 1) * 64];
+                        acc[m & 7] = mfma16<F16>(af[m >> 3], bq[m & 1], acc[m & 7]);
+                        if constexpr (decltype(produce)::value) {
+                            if (m < 8) slice(0, m, r0, bufn); else slice(1, m - 8, r1, bufn);
+                            if constexpr (decltype(gather_next)::value) {
+                                if (m == 7) gather(c + 2, 0, r0);
+                                if (m == 15) { gather(c + 2, 1, r1); gather_chunk(c + 2); }
+                            }
+                        } else {
+                            if (m < 8) dv[m] = dot_v[m * 32 + l31];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+#pragma unroll 1
+                for (int c = 0; c < 6; ++c) chunk(c, std::true_type{}, std::true_type{});
+                chunk(6, std::true_type{}, std::false_type{});
+                chunk(7, std::false_type{}, std::false_type{});
             } else {
                 // the stored messages of this tile are already in A-fragment order (see the store below): one contiguous
                 // 1 KiB per wave instruction; all sixteen k-steps of the tile are requested up front (HBM latency, not
