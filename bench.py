@@ -162,7 +162,11 @@ def main():
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
                          "flop_per_launch": flop_per_launch, "traffic": measured_traffic(args),
-                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)"},
+                         "traffic_gbps": (measured_traffic(args) / avg_launch_s / 1e9) if measured_traffic(args) else None,
+                         "valu_floor_ms": 1.8 if (args.R, args.L, args.batch) == (300, 300, 256) else None,
+                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json); traffic_gbps = HBM GB/s "
+                                         "of that kernel (peak ~8000); valu_floor_ms = the VALU-issue floor of a launch (DESIGN.md 5, "
+                                         "profiles/r01_ubench_valu_rate.txt) - the bound that applies to this kernel"},
             "best_energy": float(D.rank_by_energy(allrec)[0][0, 2]),
         }
         if not args.no_cpu_baseline:

@@ -171,6 +171,23 @@ class DFMDock(Score_Model):
 
     __call__ = forward
 
+    # host-side helpers of the reference wrapper, kept for callers that build their own perturbed poses ---------------
+    @staticmethod
+    def move_to_lig_center(batch):
+        """DFMDock.py:254-257: subtract the mean over all L x 3 ligand backbone atoms from both chains (in place)."""
+        center = batch["lig_pos"].mean(dim=(0, 1)) if hasattr(batch["lig_pos"], "dim") else batch["lig_pos"].mean(axis=(0, 1))
+        batch["rec_pos"] = batch["rec_pos"] - center
+        batch["lig_pos"] = batch["lig_pos"] - center
+
+    @staticmethod
+    def modify_coords(lig_pos, rot_update, tr_update):
+        """DFMDock.py:246-252: rotate about the all-atom centroid (not the CA centroid of inference_base.modify_coords), then translate."""
+        from .pdbio import axis_angle_to_matrix
+        x = np.asarray(lig_pos, np.float32)
+        cen = x.mean(axis=(0, 1))
+        rot = axis_angle_to_matrix(np.asarray(rot_update, np.float64).reshape(3)).astype(np.float32)
+        return ((x - cen) @ rot.T + cen + np.asarray(tr_update, np.float32).reshape(3)).astype(np.float32)
+
 
 def Euler_Maruyama_sampler(model: Score_Model, batch, num_steps=40, device="cpu", batch_size=1, eps=1e-3,
                            use_clash_force=False, noise_annealing=False, tr_noise_scale=0.5, rot_noise_scale=0.5,

@@ -103,6 +103,15 @@ def main():
     for i, (t, rot, trs) in enumerate([(0.001, 0.0, 0.0), (1.0, 60.0, 8.0), (0.3, 12.0, 2.5)]):
         lp = mg.noised_pose(cx, rng, rot, trs) if i else cx["lig_pos"]
         mg.save(f"fwd2_7CEI_p{i}.npz", **forward_case(net, cx, lp, t, seed=40 + i))
+    # DFMDock.modify_coords / move_to_lig_center (DFMDock.py:246-257): rotation about the ALL-ATOM centroid
+    x = torch.from_numpy(rng.standard_normal((9, 3, 3)).astype(np.float32) * 10)
+    rot, tr = torch.tensor([[0.2, -0.1, 0.4]]), torch.tensor([[1.0, -2.0, 0.5]])
+    w = Wrapper(net)
+    x2 = dd.DFMDock.modify_coords(w, x.clone(), rot, tr)
+    b2 = {"rec_pos": x.clone() + 3.0, "lig_pos": x.clone()}
+    w.move_to_lig_center(b2)
+    mg.save("pair_kats.npz", mc_x=x.numpy(), mc_rot=rot.numpy(), mc_tr=tr.numpy(), mc_out=x2.numpy(),
+            centred_rec=b2["rec_pos"].numpy(), centred_lig=b2["lig_pos"].numpy())
     # `agg: sum` variant (egnn_net.py:438-441,:459-474) on one small case
     hp_sum = HParams(family=1, mask_dist=20.0, agg_mean=False)
     net_s = build_net(0, hp_sum)

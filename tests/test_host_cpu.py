@@ -94,3 +94,17 @@ def test_record_gather_world2_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     a, b = np.load(tmp_path / "ranked_0.npy"), np.load(tmp_path / "ranked_1.npy")
     np.testing.assert_array_equal(a, b)         # every rank ends with the same energy-ranked table
+
+
+def test_dfmdock_wrapper_helpers_match_reference():
+    """DFMDock.modify_coords / move_to_lig_center (DFMDock.py:246-257) against values produced by the reference."""
+    import numpy as np
+    from conftest import load_golden
+    from dfmdock_amd.score_model import DFMDock
+    g = load_golden("pair_kats.npz")
+    out = DFMDock.modify_coords(g["mc_x"], g["mc_rot"], g["mc_tr"])
+    assert np.abs(out - g["mc_out"]).max() < 2e-5
+    b = {"rec_pos": g["mc_x"] + 3.0, "lig_pos": g["mc_x"].copy()}
+    DFMDock.move_to_lig_center(b)
+    assert np.abs(b["rec_pos"] - g["centred_rec"]).max() < 1e-5 and np.abs(b["lig_pos"] - g["centred_lig"]).max() < 1e-5
+
