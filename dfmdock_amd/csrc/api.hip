@@ -641,13 +641,14 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     cx->fwd_counter = 0;   // RNG streams are a pure function of (seed, trajectory, evaluation index)
     HIPCHK(hipMemcpyAsync(W.lig_cur, lig_pos, (size_t)B * L * 9 * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(W.t_dev, t, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    DevPool tmp;   // per-call device buffers (injected edges, debug tap); released on every return path
     int32_t *edges_dev = nullptr;
     float *h_first_dev = nullptr;
     if (edges) {
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&edges_dev), (size_t)B * N * K * 4));
+        HIPCHK(tmp.alloc(&edges_dev, (size_t)B * N * K));
         HIPCHK(hipMemcpyAsync(edges_dev, edges, (size_t)B * N * K * 4, hipMemcpyHostToDevice, s));
     }
-    if (out->h_first) HIPCHK(hipMalloc(reinterpret_cast<void **>(&h_first_dev), (size_t)B * N * H * 4));
+    if (out->h_first) HIPCHK(tmp.alloc(&h_first_dev, (size_t)B * N * H));
     FwdOpts o;
     o.bf16 = bf16; o.f16 = f16; o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
     o.edges_pitch = (int64_t)N * K; o.seed = seed; o.h_first_out = h_first_dev;
@@ -683,8 +684,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
             if (o.profile) rc = finish_profile(cx);
         }
     }
-    if (edges_dev) (void)hipFree(edges_dev);
-    if (h_first_dev) (void)hipFree(h_first_dev);
+    if (rc != DFM_OK) (void)hipStreamSynchronize(s);   // nothing may still read the per-call buffers when they are released
     return rc;
 }
 
