@@ -169,7 +169,7 @@ def main():
                                          "profiles/r01_ubench_valu_rate.txt) - the bound that applies to this kernel"},
             "best_energy": float(D.rank_by_energy(allrec)[0][0, 2]),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(blob, cx, args.num_steps)
         print(json.dumps(out))
     if world > 1:
