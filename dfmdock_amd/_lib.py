@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfmdock_amd.so")
+LIB_PATH = os.environ.get("DFM_LIB") or os.path.join(_HERE, "libdfmdock_amd.so")   # DFM_LIB: A/B builds of the same engine
 
 F32P = C.POINTER(C.c_float)
 I32P = C.POINTER(C.c_int32)

@@ -193,6 +193,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 union Frag { uint4 u; bf16x8 b; f16x8 f; };
 union H8 { uint4 u; __half2 h[4]; };   // eight fp16 values of one gathered 16-byte chunk
 
+#ifndef DFM_EDGE_BD
+#define DFM_EDGE_BD 2
+#endif
 constexpr int LDS_WF_BYTES = 16 * 8 * 64 * 16;     // 131072: bf16 B-fragments of one 256x256 matrix
 constexpr int LDS_STAGE_BYTES = 32 * 64 * 2;       // 4096 per wave: 32 rows x 64 channels bf16
 constexpr int EDGE_WAVES = 8;                      // waves per workgroup (two per SIMD, 256 registers each)
@@ -411,12 +414,14 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                         af[ks].u = *reinterpret_cast<const uint4 *>(bufc + ((un * 32 + (l31 ^ (4 * un))) << 4));
                     }
                     const uint4 *wq = Wf + (size_t)c * 16 * 64 + lane;
-                    Frag bq[2];
-                    bq[0].u = wq[0];
+                    constexpr int BD = DFM_EDGE_BD;      // weight-fragment reads run BD - 1 MFMAs ahead
+                    Frag bq[BD];
+#pragma unroll
+                    for (int d = 0; d < BD - 1; ++d) bq[d].u = wq[d * 64];
 #pragma unroll
                     for (int m = 0; m < 16; ++m) {
-                        if (m + 1 < 16) bq[(m + 1) & 1].u = wq[(m + 1) * 64];
-                        acc[m & 7] = mfma16<F16>(af[m >> 3], bq[m & 1], acc[m & 7]);
+                        if (m + BD - 1 < 16) bq[(m + BD - 1) % BD].u = wq[(m + BD - 1) * 64];
+                        acc[m & 7] = mfma16<F16>(af[m >> 3], bq[m % BD], acc[m & 7]);
                         if constexpr (decltype(produce)::value) {
                             if (m < 8) slice(0, m, r0, bufn); else slice(1, m - 8, r1, bufn);
                             if constexpr (decltype(gather_next)::value) {
