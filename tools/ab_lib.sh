@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-for lib in libdfmdock_amd libdfm_bd3 libdfm_bd4 libdfmdock_amd; do
+for lib in ${LIBS:-libdfmdock_amd libdfm_old libdfmdock_amd libdfm_old}; do
 export DFM_LIB=/root/repo/dfmdock_amd/$lib.so
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$lib -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/b_$lib.log 2>&1
 f=$(find /tmp/prof_$lib -name "*kernel_stats.csv" | head -1)
