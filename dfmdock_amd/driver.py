@@ -20,7 +20,7 @@ import numpy as np
 
 from . import distributed as D
 from . import engine, pdbio
-from .metrics import compute_metrics
+from .metrics import NativeContext, compute_metrics
 
 CSV_FIELDS = ["id", "index", "c_rmsd", "i_rmsd", "l_rmsd", "fnat", "DockQ", "energy", "num_clashes"]
 
@@ -61,13 +61,14 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
         if global_rotation:
             rec_pos, lig_pos = random_rotation(rec_pos, lig_pos, np.random.default_rng(rots[ci]))
         gx = engine.Complex(model, c["rec_x"], c["lig_x"], rec_pos, lig_pos)
+        native = NativeContext((rec_pos, lig_pos))
         done = 0
         while done < num_samples:
             b = min(max_batch, num_samples - done)
             r = gx.sample(B=b, num_steps=num_steps, seed=seed * 100003 + ci * 1009 + done, bf16=precision == "bf16",
                           f16=precision == "f16", trace=traj_dir is not None, **sampler_kw)
             for k in range(b):
-                m = compute_metrics((rec_pos, r["lig_pos"][k]), (rec_pos, lig_pos))
+                m = compute_metrics((rec_pos, r["lig_pos"][k]), (rec_pos, lig_pos), native)
                 rows.append({"id": c.get("id", str(ci)), "index": str(done + k), **m, "energy": float(r["energy"][k]),
                              "num_clashes": int(r["num_clashes"][k])})
                 if traj_dir is not None and "rec_seq" in c:
