@@ -71,7 +71,7 @@ struct Workspace {
     int32_t *edges = nullptr; uint32_t *codes = nullptr; float *radial = nullptr;
     float *h = nullptr, *h2 = nullptr, *A = nullptr, *Bm = nullptr, *agg = nullptr, *u = nullptr;
     uint16_t *Bmb = nullptr, *mbuf = nullptr;
-    float *gn_shift = nullptr, *gn_den = nullptr;
+    float *gn_shift = nullptr, *gn_den = nullptr, *gn_part = nullptr;
     float *fvec = nullptr, *en_part = nullptr; int32_t *clash_part = nullptr;
     float *fpart = nullptr, *cpart = nullptr, *conf = nullptr;    // family 1: force partials per receptor tile, confidence
     float *scores = nullptr, *lig_cur = nullptr, *tr_update = nullptr, *rot_update = nullptr, *t_dev = nullptr;
@@ -437,6 +437,7 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16)
         HIPCHK(W.pool.alloc(&W.Bmb, b * N * H)); HIPCHK(W.pool.alloc(&W.agg, b * N * H));
         HIPCHK(W.pool.alloc(&W.u, b * N * H));
         HIPCHK(W.pool.alloc(&W.gn_shift, b * H)); HIPCHK(W.pool.alloc(&W.gn_den, b * H));
+        HIPCHK(W.pool.alloc(&W.gn_part, b * ((N + 63) / 64) * H * 2));
         const size_t RT = (R + 63) / 64, NP = R > 4 * RT ? R : 4 * RT;     // partial-sum slots per trajectory
         HIPCHK(W.pool.alloc(&W.fvec, b * L * 3)); HIPCHK(W.pool.alloc(&W.en_part, b * NP * 2));
         HIPCHK(W.pool.alloc(&W.clash_part, b * NP)); HIPCHK(W.pool.alloc(&W.scores, b * 8));
@@ -530,8 +531,12 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         std::memset(&g, 0, sizeof(g));
         g.A0 = h; g.A1 = W.agg; g.lda = H; g.K = 2 * H; g.pro = 1; g.W = Lw.W3; g.ldw = 2 * H; g.bias = Lw.b3;
         g.M = M; g.Nout = H; g.C = W.u; g.ldc = H;
+        // 16-bit engines: the GEMM leaves per-tile column sums of u behind, so GraphNorm needs no extra pass over u
+        const bool fused_stats = o.bf16 && gemm_rows_per_tile() == 64;
+        if (fused_stats) { g.stat_part = W.gn_part; g.rows_per_graph = N; }
         if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W3_hi, Lw.W3_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
-        HIPCHK(launch_gn_stats(W.u, B, N, Lw.gn_ms, W.gn_shift, W.gn_den, o.bf16 ? Lw.gn_w : nullptr, o.bf16 ? Lw.gn_b : nullptr, s));
+        if (fused_stats) HIPCHK(launch_gn_finish(W.gn_part, B, N, Lw.gn_ms, W.gn_shift, W.gn_den, Lw.gn_w, Lw.gn_b, s));
+        else HIPCHK(launch_gn_stats(W.u, B, N, Lw.gn_ms, W.gn_shift, W.gn_den, o.bf16 ? Lw.gn_w : nullptr, o.bf16 ? Lw.gn_b : nullptr, s));
         std::memset(&g, 0, sizeof(g));
         g.A0 = W.u; g.lda = H; g.K = H; g.pro = 2; g.gn_shift = W.gn_shift; g.gn_den = W.gn_den; g.gn_w = Lw.gn_w;
         g.gn_b = Lw.gn_b; g.rows_per_graph = N; g.W = Lw.W4; g.ldw = H; g.bias = Lw.b4; g.M = M; g.Nout = H;

@@ -175,7 +175,16 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     uint16_t *Ah = lds, *Al = lds + SM * SLD, *Wh = lds + 2 * SM * SLD, *Wl = lds + (2 * SM + SN) * SLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31;
-    const int row0 = blockIdx.x * SM, col0 = blockIdx.y * SN;
+    // row tile: plain 64/128-row blocks of the [M] rows, or - when the GraphNorm column sums are wanted - blocks aligned to
+    // the trajectory (rows_per_graph rows each, last block partial): every block then belongs to one trajectory and the
+    // summation order is the same for every trajectory, whatever its position in the batch (batched == single, bitwise)
+    int row0 = blockIdx.x * SM, row_end = a.M;
+    const int col0 = blockIdx.y * SN;
+    if (MT == 1 && a.stat_part) {
+        const int tpt = (a.rows_per_graph + SM - 1) / SM, tb = blockIdx.x / tpt;
+        row0 = tb * a.rows_per_graph + (blockIdx.x - tb * tpt) * SM;
+        row_end = (tb + 1) * a.rows_per_graph;
+    }
     f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -187,7 +196,7 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     // staging: thread owns 8 consecutive k (kg) of row ar (and ar + 64 when MT = 2); four lanes cover one row's 128-byte line
     const int ar = tid >> 2, kg = (tid & 3) * 8;
     const int halfK = a.K >> 1;
-    const bool rv0 = row0 + ar < a.M, rv1 = MT == 2 && row0 + ar + 64 < a.M;
+    const bool rv0 = row0 + ar < row_end, rv1 = MT == 2 && row0 + ar + 64 < row_end;
     const size_t gr0 = (size_t)(rv0 ? row0 + ar : 0), gr1 = (size_t)(rv1 ? row0 + ar + 64 : 0);
     const int g0 = a.pro == 2 ? (int)(gr0 / a.rows_per_graph) : 0, g1 = a.pro == 2 ? (int)(gr1 / a.rows_per_graph) : 0;
 
@@ -279,6 +288,7 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     // by store issue.  Each wave instead transposes its outputs through a private LDS region (the operand tiles are
     // dead by now) in 32 x 64 passes and stores 16-byte vectors, 256 B per row.
     __syncthreads();
+    float st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0};   // column sums of u and u^2 over this lane's rows (4 columns)
     constexpr int ELD = 72;                               // floats per staged row (64 + 8: the half-waves, 4 rows apart, hit disjoint banks)
     float *est = reinterpret_cast<float *>(lds) + wave * (32 * ELD);   // 9216 B per wave
     const int er = lane >> 4, ec = (lane & 15) * 4;       // read-back: 4 rows x 16 float4 per instruction
@@ -301,7 +311,13 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
                 const float4 v = *reinterpret_cast<const float4 *>(est + lr * ELD + ec);
                 const size_t row = (size_t)row0 + wm * 64 + i * 32 + lr;
                 const int col = col0 + (wn * NJ + jp * 2) * 32 + ec;
-                if (row >= (size_t)a.M) continue;
+                if (row >= (size_t)row_end) continue;
+                if constexpr (MT == 1) {
+                    if (a.stat_part) {      // column sums of u for GraphNorm
+                        st_s[0] += v.x; st_s[1] += v.y; st_s[2] += v.z; st_s[3] += v.w;
+                        st_q[0] += v.x * v.x; st_q[1] += v.y * v.y; st_q[2] += v.z * v.z; st_q[3] += v.w * v.w;
+                    }
+                }
                 if (a.epi == 1) {
                     const float4 rr = *reinterpret_cast<const float4 *>(a.R + row * a.ldc + col);
                     *reinterpret_cast<float4 *>(a.C + row * a.ldc + col) = make_float4(rr.x + v.x, rr.y + v.y, rr.z + v.z, rr.w + v.w);
@@ -322,8 +338,30 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+    if constexpr (MT == 1) {
+        if (a.stat_part) {
+            float *sp = a.stat_part + (size_t)blockIdx.x * (H * 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float ss = st_s[e], qq = st_q[e];
+                ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+                qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
+                if (er == 0) {
+                    const int c = col0 + wn * 64 + ec + e;
+                    sp[c * 2] = ss;
+                    sp[c * 2 + 1] = qq;
+                }
+            }
+        }
+    }
 }
 #undef GEMM_SPLIT_FETCH
+
+int gemm_rows_per_tile()
+{
+    static const int v = [] { const char *e = getenv("DFM_GEMM_MT"); return e && atoi(e) == 2 ? 128 : 64; }();
+    return v;
+}
 
 hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s)
 {
@@ -333,7 +371,10 @@ hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint1
     sa.g = a; sa.Whi = Whi; sa.Wlo = Wlo;
     static int mt = 0;
     if (!mt) { const char *e = getenv("DFM_GEMM_MT"); mt = e && atoi(e) == 2 ? 2 : 1; }
+    if (a.stat_part && (mt != 1 || a.Nout != SN || a.rows_per_graph < 1 || a.M % a.rows_per_graph != 0)) return hipErrorInvalidValue;
     if (mt == 2) hipLaunchKernelGGL(k_gemm_split<2>, dim3((a.M + 127) / 128, a.Nout / SN), dim3(256), 0, s, sa);
+    else if (a.stat_part)
+        hipLaunchKernelGGL(k_gemm_split<1>, dim3((a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64), 1), dim3(256), 0, s, sa);
     else hipLaunchKernelGGL(k_gemm_split<1>, dim3((a.M + 63) / 64, a.Nout / SN), dim3(256), 0, s, sa);
     return hipGetLastError();
 }
@@ -393,6 +434,40 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float *__restrict__ u, i
             den[(size_t)b * H + c] = dn;
         }
     }
+}
+
+// GraphNorm statistics from the per-tile column sums of k_gemm_split (stat_part [B][tiles per trajectory][256][2]); fixed
+// summation order, float64.  var = E[(u - shift)^2] = E[u^2] - 2 shift E[u] + shift^2.
+__global__ __launch_bounds__(256) void k_gn_finish(const float *__restrict__ part, int N, const float *__restrict__ mean_scale,
+                                                   float *__restrict__ shift, float *__restrict__ den,
+                                                   const float *__restrict__ fold_w, const float *__restrict__ fold_b)
+{
+    const int b = blockIdx.x, c = threadIdx.x, tpt = (N + 63) / 64;
+    double s = 0, q = 0;
+    for (int t = 0; t < tpt; ++t) {
+        const float *pp = part + ((size_t)b * tpt + t) * (H * 2) + c * 2;
+        s += pp[0]; q += pp[1];
+    }
+    const double mean = s / N, sft_d = (double)((float)mean * mean_scale[c]);
+    const float sft = (float)sft_d;
+    double var = q / N - 2.0 * sft_d * mean + sft_d * sft_d;
+    var = var > 0 ? var : 0;
+    const float dn = sqrtf((float)var + 1e-5f);
+    if (fold_w) {
+        const float sc = fold_w[c] / dn;
+        den[(size_t)b * H + c] = sc;
+        shift[(size_t)b * H + c] = fold_b[c] - sc * sft;
+    } else {
+        shift[(size_t)b * H + c] = sft;
+        den[(size_t)b * H + c] = dn;
+    }
+}
+
+hipError_t launch_gn_finish(const float *stat_part, int B, int N, const float *mean_scale, float *shift, float *den,
+                            const float *fold_w, const float *fold_b, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gn_finish, dim3(B), dim3(256), 0, s, stat_part, N, mean_scale, shift, den, fold_w, fold_b);
+    return hipGetLastError();
 }
 
 hipError_t launch_gn_stats(const float *u, int B, int N, const float *mean_scale, float *shift, float *den,
