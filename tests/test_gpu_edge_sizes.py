@@ -43,3 +43,29 @@ def test_odd_sizes_fp32_vs_oracle(R, L, family, blob, blob_pair):
     s = gx.sample(B=3, num_steps=3, seed=5, bf16=True)
     assert np.isfinite(s["lig_pos"]).all() and np.isfinite(s["energy"]).all()
     gx.close(); m.close()
+
+
+def test_degenerate_geometry_fp32_vs_oracle(blob):
+    """Duplicated residues (distance 0, NaN dihedrals), collinear backbone atoms, a residue collapsed to a point: same bins,
+    finite outputs and fp32 agreement with the oracle (NaN angles bin to 0 on both sides, score_net_mlsb.py:30-70)."""
+    from dfmdock_amd import engine
+    from dfmdock_amd.synthetic import make_complex
+    from oracle import oracle as ora
+    cx = make_complex(40, 30, seed=9)
+    cx["rec_pos"][5] = cx["rec_pos"][4]
+    cx["lig_pos"][7] = cx["lig_pos"][6]
+    cx["rec_pos"][10, 2] = cx["rec_pos"][10, 1] + (cx["rec_pos"][10, 1] - cx["rec_pos"][10, 0])
+    cx["lig_pos"][12, :] = cx["lig_pos"][12, 1]
+    engine.set_device(0)
+    m = engine.Model(blob)
+    gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    r = gx.score(cx["lig_pos"], 0.5, seed=2, energy=True, debug=True)
+    o = ora.Oracle(blob, cx).score(cx["lig_pos"], 0.5, edges=r["edges"][0])
+    assert int((r["bins"][0] != o["bins"]).sum()) == 0
+    assert np.isfinite(r["f"]).all() and np.isfinite(r["tr_score"]).all() and np.isfinite(r["rot_score"]).all()
+    assert rel_inf(r["f"][0], o["f"]) < 1e-4 and rel_inf(r["tr_score"][0], o["tr_score"].reshape(3)) < 1e-4
+    assert abs(float(r["energy"][0]) - float(o["energy"])) < 1e-4
+    for kw in (dict(bf16=True), dict(f16=True)):
+        r16 = gx.score(cx["lig_pos"], 0.5, edges=r["edges"], energy=True, **kw)
+        assert np.isfinite(r16["f"]).all() and rel_inf(r16["f"][0], o["f"]) < 2e-2
+    gx.close(); m.close()
