@@ -30,6 +30,23 @@ static int fail(int code, const std::string &msg)
         }                                                                                         \
     } while (0)
 
+// Every handle belongs to one device (dfm_model: the device current at creation; dfm_complex: its model's).  Entry points
+// run under a DeviceScope: switch to the handle's device, restore the caller's on the way out.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+#define DEVICE_SCOPE(dev)                                                                          \
+    DeviceScope _ds(dev);                                                                          \
+    if (_ds.err != hipSuccess) return fail(DFM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_ds.err))
+
 // ------------------------------------------------------------------------------------------------
 struct DevPool {
     std::vector<void *> ptrs;
@@ -56,12 +73,14 @@ struct DevPool {
 
 struct dfm_model {
     dfm_hparams hp;
+    int device = 0;
     DevPool pool;
     float *single_embed = nullptr;   // [256][lm]
     LayerDev layers[8];
     HeadsDev heads;
     float *en0_w = nullptr;          // [256][512]
     PairHeadDev pair[3];             // family 1: 0 to_force, 1 to_energy, 2 to_confidence
+    float *ir0_w = nullptr, *ir0_b = nullptr, *ir2_w = nullptr, *ir2_b = nullptr, *ir4_w = nullptr, *ir4_b = nullptr;   // to_ires
 };
 
 struct Workspace {
@@ -79,10 +98,13 @@ struct Workspace {
 
 struct dfm_complex {
     dfm_model *m = nullptr;
+    int device = 0;
+    int homomer = 0;                 // value of the 67th position channel (positional_embed_dim 67)
     int R = 0, L = 0, N = 0, K = 0, knn = 0, nsamp = 0;
     DevPool pool;
     float *rec_pos = nullptr, *lig0 = nullptr;
-    float *h0 = nullptr, *A0 = nullptr, *Bm0 = nullptr; uint16_t *Bmb0 = nullptr;
+    float *h0 = nullptr, *A0 = nullptr, *Bm0 = nullptr;
+    float *A0s = nullptr; uint16_t *Bmb0 = nullptr;   // SILU_S * A0 (fp32), SILU_S * Bm0 (fp16): layer-0 operands of the 16-bit engines
     Workspace ws;
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;      // profiling events (pairs)
@@ -110,6 +132,7 @@ struct BlobMap {
     } layer[8];
     const float *en0_w, *en_ln_w, *en_ln_b, *en3_w;
     struct Ph { const float *w0, *ln_w, *ln_b, *w3; } pair[3];   // family 1: to_force, to_energy, to_confidence
+    const float *ir0_w, *ir0_b, *ir2_w, *ir2_b, *ir4_w, *ir4_b;   // to_ires
     const float *t_W, *t_lin, *trs0, *trs_ln_w, *trs_ln_b, *trs4, *rots0, *rots_ln_w, *rots_ln_b, *rots4;
     int64_t total;
 };
@@ -134,7 +157,7 @@ static void map_blob(const dfm_hparams *hp, const float *blob, BlobMap *w)
         else Lw.c1_w = Lw.c1_b = Lw.c2_w = nullptr;
         take(Lw.att_w, Hh); take(Lw.att_b, 1);
     }
-    const float *skip;
+    const float *skip = nullptr;
     if (hp->family == 1) {   // to_energy, to_force, to_dist (training-only, skipped), to_confidence on cat[h_r, h_l, D]
         auto head = [&](BlobMap::Ph &h) { take(h.w0, Hh * (2 * Hh + 1)); take(h.ln_w, Hh); take(h.ln_b, Hh); take(h.w3, Hh); };
         head(w->pair[1]); head(w->pair[0]);
@@ -145,8 +168,8 @@ static void map_blob(const dfm_hparams *hp, const float *blob, BlobMap *w)
         take(w->en0_w, Hh * 2 * Hh); take(w->en_ln_w, Hh); take(w->en_ln_b, Hh); take(w->en3_w, Hh);
         for (auto &h : w->pair) h.w0 = h.ln_w = h.ln_b = h.w3 = nullptr;
     }
-    take(skip, 2 * Hh * Hh); take(skip, 2 * Hh); take(skip, 4 * Hh * Hh); take(skip, 2 * Hh);   // to_ires.{0,2}
-    take(skip, 2 * Hh); take(skip, 1);                                                          // to_ires.4
+    take(w->ir0_w, 2 * Hh * Hh); take(w->ir0_b, 2 * Hh); take(w->ir2_w, 4 * Hh * Hh); take(w->ir2_b, 2 * Hh);   // to_ires.{0,2}
+    take(w->ir4_w, 2 * Hh); take(w->ir4_b, 1);                                                                  // to_ires.4
     take(w->t_W, Hi / 2); take(w->t_lin, Hi * Hi);
     take(w->trs0, Hi * (Hi + 1)); take(w->trs_ln_w, Hi); take(w->trs_ln_b, Hi); take(w->trs4, Hi);
     take(w->rots0, Hi * (Hi + 1)); take(w->rots_ln_w, Hi); take(w->rots_ln_b, Hi); take(w->rots4, Hi);
@@ -238,6 +261,19 @@ static void split_bf16(const float *W, int Nout, int K, std::vector<uint16_t> &h
             lo[d] = f2bf(w - bf2f(hi[d]));
         }
 }
+// SILU_S * bias as packed (hi | lo << 16) 16-bit pairs: the B operand of the bias k-step of the MFMA edge kernels
+static std::vector<uint32_t> pack_bias(const float *bias, bool f16)
+{
+    std::vector<uint32_t> v(H);
+    for (int c = 0; c < H; ++c) {
+        const float x = SILU_S * bias[c];
+        uint16_t hi, lo;
+        if (f16) { hi = f2h(x); lo = f2h(x - h2f(hi)); }
+        else { hi = f2bf(x); lo = f2bf(x - bf2f(hi)); }
+        v[c] = (uint32_t)hi | ((uint32_t)lo << 16);
+    }
+    return v;
+}
 static std::vector<float> transpose256(const float *W)
 {
     std::vector<float> t((size_t)H * H);
@@ -250,7 +286,7 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
 {
     if (!blob || !hp) { fail(DFM_E_INVALID, "blob or hp is NULL"); return nullptr; }
     if (hp->node_dim != H || hp->edge_dim != HE || hp->inner_dim != HI || hp->spatial_embed_dim != 100 ||
-        hp->positional_embed_dim != 66 || hp->depth < 1 || hp->depth > 8 || hp->knn < 1 || hp->n_sample < 0 ||
+        (hp->positional_embed_dim != 66 && hp->positional_embed_dim != 67) || hp->depth < 1 || hp->depth > 8 || hp->knn < 1 || hp->n_sample < 0 ||
         hp->knn + hp->n_sample > 60 || hp->lm_embed_dim < 1 || hp->family < 0 || hp->family > 1) {
         fail(DFM_E_INVALID, "unsupported hyper-parameters (kernels are built for node 256 / edge 128 / inner 128, degree <= 60)");
         return nullptr;
@@ -263,10 +299,13 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
     }
     dfm_model *m = new dfm_model();
     m->hp = *hp;
+    if (hipGetDevice(&m->device) != hipSuccess) { fail(DFM_E_NODEVICE, "no current HIP device"); delete m; return nullptr; }
+    const int Pd = hp->positional_embed_dim;
     DevPool &P = m->pool;
     bool ok = true;
     auto up = [&](float **dst, const float *src, size_t n) { ok = ok && P.upload(dst, src, n) == hipSuccess; };
     auto up16 = [&](uint16_t **dst, const std::vector<uint16_t> &v) { ok = ok && P.upload(dst, v.data(), v.size()) == hipSuccess; };
+    auto up32 = [&](uint32_t **dst, const std::vector<uint32_t> &v) { ok = ok && P.upload(dst, v.data(), v.size()) == hipSuccess; };
     const int Kin1 = 2 * H + 1 + HE;
     up(&m->single_embed, w.single_embed, (size_t)H * hp->lm_embed_dim);
     for (int l = 0; l < hp->depth && ok; ++l) {
@@ -288,21 +327,45 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
                 double s = 0;
                 for (int k = 0; k < HE; ++k) {
                     const float sp = idx < 100 ? w.spatial_embed[(size_t)k * 100 + idx]
-                                               : w.positional_embed[(size_t)k * 66 + (idx - 100)];
+                                               : w.positional_embed[(size_t)k * Pd + (idx - 100)];
                     s += (double)Lw.e1_w[(size_t)c * Kin1 + 2 * H + 1 + k] * sp;
                 }
                 Td[(size_t)idx * H + c] = s;
                 T[(size_t)idx * H + c] = (float)s;
             }
+        // merged fp16 tables of the 16-bit MFMA kernel, pre-multiplied by SILU_S like every other SiLU input there
+        const double S = (double)SILU_S;
         std::vector<uint16_t> T2b((size_t)NTAB2 * H);
         for (int c = 0; c < H; ++c) {
             for (int om = 0; om < 24; ++om)
                 for (int th = 0; th < 24; ++th)
-                    T2b[(size_t)(om * 24 + th) * H + c] = f2h((float)(Td[(size_t)(40 + om) * H + c] + Td[(size_t)(64 + th) * H + c]));
+                    T2b[(size_t)(om * 24 + th) * H + c] = f2h((float)(S * (Td[(size_t)(40 + om) * H + c] + Td[(size_t)(64 + th) * H + c])));
             for (int ph = 0; ph < 12; ++ph)
                 for (int d = 0; d < 40; ++d)
-                    T2b[(size_t)(576 + ph * 40 + d) * H + c] = f2h((float)(Td[(size_t)(88 + ph) * H + c] + Td[(size_t)d * H + c]));
-            for (int rp = 0; rp < 66; ++rp) T2b[(size_t)(1056 + rp) * H + c] = f2h((float)Td[(size_t)(100 + rp) * H + c]);
+                    T2b[(size_t)(576 + ph * 40 + d) * H + c] = f2h((float)(S * (Td[(size_t)(88 + ph) * H + c] + Td[(size_t)d * H + c])));
+            for (int rp = 0; rp < 66; ++rp) T2b[(size_t)(1056 + rp) * H + c] = f2h((float)(S * Td[(size_t)(100 + rp) * H + c]));
+        }
+        {
+            std::vector<float> wrs(H), babs(2 * H), wc2s(H);
+            for (int c = 0; c < H; ++c) wrs[c] = SILU_S * w_r[c];
+            for (int c = 0; c < 2 * H; ++c) babs[c] = SILU_S * bias_ab[c];
+            up(&D.w_r_s, wrs.data(), H); up(&D.bias_ab_s, babs.data(), 2 * H);
+            up32(&D.b2p, pack_bias(Lw.e2_b, false)); up32(&D.b2p16, pack_bias(Lw.e2_b, true));
+            if (Lw.c1_w) {
+                for (int c = 0; c < H; ++c) wc2s[c] = Lw.c2_w[c] / SILU_S;
+                up(&D.wc2_s, wc2s.data(), H);
+                up32(&D.bc1p, pack_bias(Lw.c1_b, false)); up32(&D.bc1p16, pack_bias(Lw.c1_b, true));
+            }
+        }
+        if (Pd == 67) {   // "sym" channel: one_hot-free constant column of the position matrix -> We . P[:, 66] on every edge
+            std::vector<float> bh(bias_ab), bhs(2 * H);
+            for (int c = 0; c < H; ++c) {
+                double s2 = 0;
+                for (int k = 0; k < HE; ++k) s2 += (double)Lw.e1_w[(size_t)c * Kin1 + 2 * H + 1 + k] * w.positional_embed[(size_t)k * Pd + 66];
+                bh[c] = (float)((double)bias_ab[c] + s2);
+            }
+            for (int c = 0; c < 2 * H; ++c) bhs[c] = SILU_S * bh[c];
+            up(&D.bias_ab_h, bh.data(), 2 * H); up(&D.bias_ab_h_s, bhs.data(), 2 * H);
         }
         up(&D.Wab, Wab.data(), Wab.size()); up(&D.bias_ab, bias_ab.data(), bias_ab.size());
         up(&D.w_r, w_r.data(), w_r.size()); up(&D.T, T.data(), T.size()); up16(&D.T2b, T2b);
@@ -314,7 +377,9 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
         up(&D.W4, Lw.n2_w, (size_t)H * H); up(&D.b4, Lw.n2_b, H);
         {
             std::vector<uint16_t> hi, lo;
-            split_bf16(Wab.data(), 2 * H, H, hi, lo); up16(&D.Wab_hi, hi); up16(&D.Wab_lo, lo);
+            std::vector<float> Wabs(Wab.size());      // [Wa|Wb] of the 16-bit engine: scaled by SILU_S (A, Bm feed a SiLU)
+            for (size_t q = 0; q < Wab.size(); ++q) Wabs[q] = SILU_S * Wab[q];
+            split_bf16(Wabs.data(), 2 * H, H, hi, lo); up16(&D.Wab_hi, hi); up16(&D.Wab_lo, lo);
             split_bf16(Lw.n1_w, H, 2 * H, hi, lo); up16(&D.W3_hi, hi); up16(&D.W3_lo, lo);
             split_bf16(Lw.n2_w, H, H, hi, lo); up16(&D.W4_hi, hi); up16(&D.W4_lo, lo);
         }
@@ -348,6 +413,8 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
         Hd.en_wa = m->en0_w; Hd.en_wb = m->en0_w ? m->en0_w + H : nullptr;
         up(&Hd.en_ln_w, w.en_ln_w, H); up(&Hd.en_ln_b, w.en_ln_b, H); up(&Hd.en_w3, w.en3_w, H);
     }
+    up(&m->ir0_w, w.ir0_w, (size_t)2 * H * H); up(&m->ir0_b, w.ir0_b, 2 * H); up(&m->ir2_w, w.ir2_w, (size_t)4 * H * H);
+    up(&m->ir2_b, w.ir2_b, 2 * H); up(&m->ir4_w, w.ir4_w, 2 * H); up(&m->ir4_b, w.ir4_b, 1);
     up(&Hd.t_W, w.t_W, HI / 2); up(&Hd.t_lin, w.t_lin, (size_t)HI * HI);
     up(&Hd.trs0, w.trs0, (size_t)HI * (HI + 1)); up(&Hd.trs_ln_w, w.trs_ln_w, HI); up(&Hd.trs_ln_b, w.trs_ln_b, HI);
     up(&Hd.trs4, w.trs4, HI);
@@ -361,16 +428,47 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
     return m;
 }
 
-extern "C" void dfm_model_destroy(dfm_model *m) { delete m; }
+extern "C" void dfm_model_destroy(dfm_model *m)
+{
+    if (!m) return;
+    DeviceScope ds(m->device);
+    delete m;
+}
 
 // ------------------------------------------------------------------------------------------------
+// layer-0 operands of the 16-bit MFMA edge kernel: SILU_S * A0 (fp32) and SILU_S * Bm0 (fp16)
+__global__ void k_scale_ab(const float *__restrict__ A0, const float *__restrict__ Bm0, float *__restrict__ A0s,
+                           uint16_t *__restrict__ Bmb0, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { A0s[i] = SILU_S * A0[i]; Bmb0[i] = f2h(SILU_S * Bm0[i]); }
+}
+
+// layer 0's [Wa|Wb] projection of the node embedding: pose independent, once per complex (again when the homomer flag changes)
+static hipError_t project_layer0(dfm_complex *cx)
+{
+    const dfm_model *m = cx->m;
+    const LayerDev &L0 = m->layers[0];
+    const int N = cx->N;
+    GemmArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.A0 = cx->h0; g.lda = H; g.K = H; g.W = L0.Wab; g.ldw = H; g.bias = cx->homomer ? L0.bias_ab_h : L0.bias_ab; g.M = N;
+    g.Nout = 2 * H; g.epi = 2; g.C = cx->A0; g.ldc = H; g.C2 = cx->Bm0;
+    hipError_t e = launch_gemm_f32(g, cx->stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_scale_ab, dim3((N * H + 255) / 256), dim3(256), 0, cx->stream, cx->A0, cx->Bm0, cx->A0s, cx->Bmb0, N * H);
+    return hipGetLastError();
+}
+
 extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, const float *lig_x, const float *rec_pos,
                                            const float *lig_pos, int R, int L)
 {
     if (!m || !rec_x || !lig_x || !rec_pos || !lig_pos) { fail(DFM_E_INVALID, "NULL argument"); return nullptr; }
     if (R < 1 || L < 1 || R + L > MAX_NODES) { fail(DFM_E_INVALID, "need 1 <= R, L and R + L <= 4096"); return nullptr; }
+    DeviceScope ds(m->device);
+    if (ds.err != hipSuccess) { fail(DFM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(ds.err)); return nullptr; }
     dfm_complex *cx = new dfm_complex();
-    cx->m = m; cx->R = R; cx->L = L; cx->N = R + L;
+    cx->m = m; cx->device = m->device; cx->R = R; cx->L = L; cx->N = R + L;
     cx->K = degree_of(m->hp, cx->N, &cx->knn, &cx->nsamp);
     const int N = cx->N, lm = m->hp.lm_embed_dim;
     DevPool &P = cx->pool;
@@ -384,17 +482,14 @@ extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, con
     ok = ok && P.upload(&cx->lig0, lig_pos, (size_t)L * 9) == hipSuccess;
     ok = ok && P.alloc(&cx->h0, (size_t)N * H) == hipSuccess && P.alloc(&cx->A0, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->Bm0, (size_t)N * H) == hipSuccess && P.alloc(&cx->Bmb0, (size_t)N * H) == hipSuccess;
+    ok = ok && P.alloc(&cx->A0s, (size_t)N * H) == hipSuccess;
     if (ok) {
         // node = single_embed(cat[rec_x, lig_x]) (score_net_mlsb.py:365-366): pose independent, once per complex
         GemmArgs g;
         std::memset(&g, 0, sizeof(g));
         g.A0 = x; g.lda = lm; g.K = lm; g.W = m->single_embed; g.ldw = lm; g.M = N; g.Nout = H; g.C = cx->h0; g.ldc = H;
         ok = launch_gemm_f32(g, cx->stream) == hipSuccess;
-        // layer-0 [Wa|Wb] projection is pose independent as well
-        std::memset(&g, 0, sizeof(g));
-        g.A0 = cx->h0; g.lda = H; g.K = H; g.W = m->layers[0].Wab; g.ldw = H; g.bias = m->layers[0].bias_ab; g.M = N;
-        g.Nout = 2 * H; g.epi = 2; g.C = cx->A0; g.ldc = H; g.C2 = cx->Bm0; g.C2b = cx->Bmb0;
-        ok = ok && launch_gemm_f32(g, cx->stream) == hipSuccess;
+        ok = ok && project_layer0(cx) == hipSuccess;
         ok = ok && hipStreamSynchronize(cx->stream) == hipSuccess;
     }
     if (x) (void)hipFree(x);
@@ -409,10 +504,36 @@ extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, con
 extern "C" void dfm_complex_destroy(dfm_complex *cx)
 {
     if (!cx) return;
+    DeviceScope ds(cx->device);
     if (cx->stream) { (void)hipStreamSynchronize(cx->stream); (void)hipStreamDestroy(cx->stream); }
     for (hipEvent_t e : cx->ev) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (cx->ev_total[i]) (void)hipEventDestroy(cx->ev_total[i]);
     delete cx;
+}
+
+extern "C" int dfm_complex_set_pose(dfm_complex *cx, const float *rec_pos, const float *lig_pos)
+{
+    if (!cx) return fail(DFM_E_INVALID, "NULL argument");
+    DEVICE_SCOPE(cx->device);
+    // the stream may still read the old poses (an earlier call never returns before its work is done, but stay safe)
+    HIPCHK(hipStreamSynchronize(cx->stream));
+    if (rec_pos) HIPCHK(hipMemcpy(cx->rec_pos, rec_pos, (size_t)cx->R * 9 * sizeof(float), hipMemcpyHostToDevice));
+    if (lig_pos) HIPCHK(hipMemcpy(cx->lig0, lig_pos, (size_t)cx->L * 9 * sizeof(float), hipMemcpyHostToDevice));
+    return DFM_OK;
+}
+
+extern "C" int dfm_complex_set_homomer(dfm_complex *cx, int flag)
+{
+    if (!cx) return fail(DFM_E_INVALID, "NULL argument");
+    flag = flag ? 1 : 0;
+    if (flag && cx->m->hp.positional_embed_dim != 67)
+        return fail(DFM_E_INVALID, "the model has no sym channel (positional_embed_dim is 66)");
+    if (flag == cx->homomer) return DFM_OK;
+    DEVICE_SCOPE(cx->device);
+    cx->homomer = flag;
+    HIPCHK(project_layer0(cx));
+    HIPCHK(hipStreamSynchronize(cx->stream));
+    return DFM_OK;
 }
 
 extern "C" int dfm_complex_degree(const dfm_complex *cx) { return cx ? cx->K : -1; }
@@ -504,7 +625,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         const bool coord = last && !pair_family;       // EGNN_Net: update_coords = False in every layer
         EdgeArgs e;
         std::memset(&e, 0, sizeof(e));
-        if (l == 0) { e.A = cx->A0; e.Bm = cx->Bm0; e.Bmb = cx->Bmb0; e.ab_bstride = 0; }
+        if (l == 0) { e.A = o.bf16 ? cx->A0s : cx->A0; e.Bm = cx->Bm0; e.Bmb = cx->Bmb0; e.ab_bstride = 0; }
         else { e.A = W.A; e.Bm = W.Bm; e.Bmb = W.Bmb; e.ab_bstride = (int64_t)N * H; }
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
         e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = coord; e.fout = W.fvec; e.mbuf = W.mbuf;
@@ -548,7 +669,8 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         if (!last) {   // next layer's per-node halves of edge_mlp.0: A = Wa h + b1, Bm = Wb h
             const LayerDev &Ln = m->layers[l + 1];
             std::memset(&g, 0, sizeof(g));
-            g.A0 = h; g.lda = H; g.K = H; g.W = Ln.Wab; g.ldw = H; g.bias = Ln.bias_ab; g.M = M; g.Nout = 2 * H;
+            g.A0 = h; g.lda = H; g.K = H; g.W = Ln.Wab; g.ldw = H; g.M = M; g.Nout = 2 * H;
+            g.bias = cx->homomer ? (o.bf16 ? Ln.bias_ab_h_s : Ln.bias_ab_h) : (o.bf16 ? Ln.bias_ab_s : Ln.bias_ab);
             g.epi = 2; g.C = W.A; g.ldc = H; g.C2 = o.bf16 ? nullptr : W.Bm; g.C2b = W.Bmb;   // 16-bit engines gather the fp16 copy only
             if (o.bf16) HIPCHK(launch_gemm_split(g, Ln.Wab_hi, Ln.Wab_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         }
@@ -603,6 +725,7 @@ static void fill_head_args(dfm_complex *cx, int B, bool want_energy, HeadArgs *a
     a->scores = W.scores; a->want_energy = want_energy; a->en_part = W.en_part; a->clash_part = W.clash_part;
     a->lig_cur = W.lig_cur; a->tr_update = W.tr_update; a->rot_update = W.rot_update;
     const dfm_hparams &hp = cx->m->hp;
+    a->all_atoms = hp.family == 1;
     if (hp.family == 1) {
         a->n_part = 4 * ((cx->R + 63) / 64); a->en_mode = hp.agg_mean ? 1 : 2; a->pool_div = hp.agg_mean ? (float)cx->L : 1.0f;
     } else {
@@ -636,6 +759,8 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     if (!cx || !lig_pos || !t || !out || !out->tr_score || !out->rot_score) return fail(DFM_E_INVALID, "NULL argument");
     if (B < 1) return fail(DFM_E_INVALID, "B must be >= 1");
     const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_BF16) || f16, want_energy = flags & DFM_F_ENERGY;
+    const bool want_ires = (flags & DFM_F_IRES) && out->ires;
+    DEVICE_SCOPE(cx->device);
     int rc = ensure_workspace(cx, B, bf16);
     if (rc) return rc;
     Workspace &W = cx->ws;
@@ -654,6 +779,11 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
         HIPCHK(hipMemcpyAsync(edges_dev, edges, (size_t)B * N * K * 4, hipMemcpyHostToDevice, s));
     }
     if (out->h_first) HIPCHK(tmp.alloc(&h_first_dev, (size_t)B * N * H));
+    float *ir1 = nullptr, *ir2 = nullptr, *ir3 = nullptr;
+    if (want_ires) {
+        HIPCHK(tmp.alloc(&ir1, (size_t)B * N * 2 * H)); HIPCHK(tmp.alloc(&ir2, (size_t)B * N * 2 * H));
+        HIPCHK(tmp.alloc(&ir3, (size_t)B * N));
+    }
     FwdOpts o;
     o.bf16 = bf16; o.f16 = f16; o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
     o.edges_pitch = (int64_t)N * K; o.seed = seed; o.h_first_out = h_first_dev;
@@ -665,6 +795,21 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
         hipError_t e = launch_heads(ha, s);
         if (e != hipSuccess) rc = fail(DFM_E_HIP, hipGetErrorString(e));
     }
+    if (rc == DFM_OK && want_ires) {
+        // to_ires (score_net_mlsb.py:297-303,:383): Linear(256,512) SiLU Linear(512,512) SiLU Linear(512,1) on the final node
+        // features; never read by the sampler, fp32 GEMMs in every engine
+        const dfm_model *m = cx->m;
+        GemmArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.A0 = W.h; g.lda = H; g.K = H; g.W = m->ir0_w; g.ldw = H; g.bias = m->ir0_b; g.M = (int)(B * N); g.Nout = 2 * H;
+        g.C = ir1; g.ldc = 2 * H;
+        hipError_t e = launch_gemm_f32(g, s);
+        g.A0 = ir1; g.lda = 2 * H; g.K = 2 * H; g.pro = 3; g.W = m->ir2_w; g.ldw = 2 * H; g.bias = m->ir2_b; g.C = ir2;
+        if (e == hipSuccess) e = launch_gemm_f32(g, s);
+        g.A0 = ir2; g.W = m->ir4_w; g.bias = m->ir4_b; g.Nout = 1; g.C = ir3; g.ldc = 1;
+        if (e == hipSuccess) e = launch_gemm_f32(g, s);
+        if (e != hipSuccess) rc = fail(DFM_E_HIP, hipGetErrorString(e));
+    }
     if (rc == DFM_OK) {
         std::vector<float> sc((size_t)B * 8);
         hipError_t e = hipEventRecord(cx->ev_total[1], s);
@@ -674,6 +819,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
         if (e == hipSuccess && out->h_first) e = hipMemcpyAsync(out->h_first, h_first_dev, (size_t)B * N * H * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && out->edges) e = hipMemcpyAsync(out->edges, W.edges, (size_t)B * N * K * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && out->edge_codes) e = hipMemcpyAsync(out->edge_codes, W.codes, (size_t)B * N * K * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && want_ires) e = hipMemcpyAsync(out->ires, ir3, (size_t)B * N * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && out->confidence) {
             if (cx->m->hp.family == 1 && want_energy) e = hipMemcpyAsync(out->confidence, W.conf, (size_t)B * 4, hipMemcpyDeviceToHost, s);
             else std::memset(out->confidence, 0, (size_t)B * 4);
@@ -700,6 +846,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     if (!cx || !out) return fail(DFM_E_INVALID, "NULL argument");
     if (B < 1 || num_steps < 2) return fail(DFM_E_INVALID, "need B >= 1 and num_steps >= 2");
     const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_BF16) || f16;
+    DEVICE_SCOPE(cx->device);
     int rc = ensure_workspace(cx, B, bf16);
     if (rc) return rc;
     Workspace &W = cx->ws;
@@ -740,7 +887,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     if (out->trace_scores) HIPCHK(tmp.alloc(&tsc_d, (size_t)B * (S + 1) * 8));
 
     HIPCHK(hipEventRecord(cx->ev_total[0], s));
-    HIPCHK(launch_init_pose(cx->rec_pos, cx->lig0, B, cx->R, cx->L, R0_d, trd_d, seed, W.lig_cur, W.tr_update,
+    HIPCHK(launch_init_pose(cx->rec_pos, cx->lig0, B, cx->R, cx->L, hp.family == 1, R0_d, trd_d, seed, W.lig_cur, W.tr_update,
                             W.rot_update, s));
     if (out->init_pose) {
         HIPCHK(tmp.alloc(&ip_d, (size_t)B * L * 9));

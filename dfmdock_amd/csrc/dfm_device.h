@@ -71,6 +71,21 @@ __host__ __device__ inline uint16_t f2h(float f)
     return (uint16_t)(sign | a);
 }
 
+// IEEE half -> float (host side: weight packing)
+__host__ __device__ inline float h2f(uint16_t hbits)
+{
+    const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16, e = (hbits >> 10) & 31u, m = hbits & 0x3ffu;
+    union { float f; uint32_t u; } v;
+    if (e == 0) {
+        if (m == 0) { v.u = sign; return v.f; }
+        float f = (float)m * (1.0f / 16777216.0f);   // m * 2^-24
+        return sign ? -f : f;
+    }
+    if (e == 31) { v.u = sign | 0x7f800000u | (m << 13); return v.f; }
+    v.u = sign | ((e + 112u) << 23) | (m << 13);
+    return v.f;
+}
+
 __device__ inline float bflo(uint32_t packed) { return __uint_as_float(packed << 16); }
 __device__ inline float bfhi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
 __device__ inline uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }

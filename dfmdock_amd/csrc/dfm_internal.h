@@ -14,6 +14,7 @@ constexpr int HI = 128;       // inner_dim
 constexpr int NTAB = 166;     // 100 spatial + 66 positional one-hot slots
 constexpr int KPAD = 64;      // edges per node padded to two 32-row MFMA tiles
 constexpr int MAX_NODES = 4096;
+constexpr float SILU_S = -1.44269504088896340736f;   // -log2(e): scale carried by every SiLU input of the 16-bit MFMA edge kernels
 
 // packed per-edge feature code: T-table row offsets are implied by the field
 // (dist 0..39 | omega 40.. | theta 64.. | phi 88.. | relpos 100..)
@@ -54,6 +55,16 @@ struct LayerDev {
     uint16_t *Wc1f16; // fp16 fragments
     float *bc1;       // [256]
     float *wc2;       // [256]
+    // operands of the 16-bit MFMA edge kernels, pre-multiplied by SILU_S = -log2(e) (kernels_edge.hip): T2b, Wab_hi/lo and
+    // the arrays below.  The fp32 engine never reads them.
+    float *w_r_s;     // [256]  SILU_S * w_r
+    float *bias_ab_s; // [512]  SILU_S * bias_ab
+    // positional_embed_dim 67: the same two biases with the homomer ("sym") channel's contribution We . P[:, 66] added to
+    // the A half - a constant of every edge of a homomeric complex (dfm_complex_set_homomer); nullptr for 66 channels
+    float *bias_ab_h, *bias_ab_h_s;
+    uint32_t *b2p, *b2p16;    // [256]  SILU_S * b2 as packed (hi, lo) bf16 / fp16 pairs (the bias k-step of the contraction)
+    uint32_t *bc1p, *bc1p16;  // [256]  SILU_S * bc1, same packing
+    float *wc2_s;     // [256]  wc2 / SILU_S
 };
 
 struct HeadsDev {
@@ -85,7 +96,7 @@ struct GemmArgs {
     const float *bias;    // [Nout] or nullptr
     int M, Nout;
     // prologue: GraphNorm + SiLU applied to A on load (rows grouped by trajectory: b = row / rows_per_graph)
-    int pro;              // 0 plain, 1 concat(A0,A1) each K/2 wide, 2 graphnorm+silu
+    int pro;              // 0 plain, 1 concat(A0,A1) each K/2 wide, 2 graphnorm+silu, 3 silu (k_gemm_f32 only)
     const float *gn_shift;   // [B][256]  mean*mean_scale
     const float *gn_den;     // [B][256]  sqrt(var+eps)
     const float *gn_w, *gn_b;
@@ -182,6 +193,7 @@ struct HeadArgs {
     int64_t z_bstride;       // stride between trajectories in z arrays
     uint64_t seed;
     uint32_t step;
+    int all_atoms;           // rotate about the all-backbone-atom centroid (second family, src/inference.py:244-254)
     float *lig_cur;          // [B][L][9] in/out
     float *tr_update;        // [B][3]
     float *rot_update;       // [B][3]
@@ -196,7 +208,8 @@ hipError_t launch_energy_pairs(const float *enA, const float *enB, const float4 
                                float cut_off, const HeadsDev *hw, int want_energy, float *en_part,
                                int32_t *clash_part, hipStream_t s);
 
-hipError_t launch_init_pose(const float *rec_pos, const float *lig0, int B, int R, int L, const float *R0,
+// all_atoms: centroids over all backbone atoms (second family, src/inference.py:220-254) instead of the CA atoms
+hipError_t launch_init_pose(const float *rec_pos, const float *lig0, int B, int R, int L, int all_atoms, const float *R0,
                             const float *tr_draw, uint64_t seed, float *lig_cur, float *tr_update,
                             float *rot_update, hipStream_t s);
 hipError_t launch_clash_force(const float *rec_pos, int B, int R, int L, float *lig_cur, float *tr_update,

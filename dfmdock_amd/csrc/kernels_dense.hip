@@ -2,7 +2,7 @@
 // f32, bit-equal to an fmaf chain) and the GraphNorm statistics.
 //
 // One generic tile kernel C[M,Nout] = pro(A)[M,K] * W[Nout,K]^T + bias with
-//   prologue  0: A as is | 1: A = concat(A0, A1) along K | 2: A = SiLU(GraphNorm(A)) per trajectory
+//   prologue  0: A as is | 1: A = concat(A0, A1) along K | 2: A = SiLU(GraphNorm(A)) per trajectory | 3: A = SiLU(A)
 //   epilogue  0: store   | 1: C = R + acc + bias (residual) | 2: split columns into C (<256) and C2 (+fp16 copy)
 // covers single_embed, node_mlp.0, node_mlp.3 (+ the next layer's [Wa|Wb] projection) and the energy
 // head's two projections (egnn.py:106-116, score_net_mlsb.py:366,:386-388).
@@ -61,6 +61,8 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a)
                                 const int g = grow / a.rows_per_graph;
                                 const float o = x - a.gn_shift[(size_t)g * H + k];
                                 x = silu_exact(a.gn_w[k] * o / a.gn_den[(size_t)g * H + k] + a.gn_b[k]);
+                            } else if (a.pro == 3) {
+                                x = silu_exact(x);     // Sequential(..., SiLU, Linear): the activation rides on the next Linear's load
                             }
                         }
                         v[e] = x;

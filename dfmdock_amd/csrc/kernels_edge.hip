@@ -45,6 +45,11 @@ struct EdgeKArgs {
     int last;
     float *fout;
     uint16_t *mbuf;
+    // 16-bit MFMA kernels: everything upstream of a SiLU is pre-multiplied by -log2(e) on the host / in the producing GEMM
+    // (see SILU_S), so SiLU is exp2 -> +1 -> rcp -> mul with no scaling multiply; biasp = the contraction's bias as packed
+    // (hi, lo) 16-bit pairs, added by one extra MFMA k-step instead of 128 accumulator moves
+    const uint32_t *biasp;
+    float inv_s;
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -202,17 +207,6 @@ constexpr int EDGE_WAVES = 8;                      // waves per workgroup (two p
 constexpr int LDS_EDGE_BYTES = LDS_WF_BYTES + 8 * LDS_STAGE_BYTES;   // 163840 = the whole CU
 
 typedef float f2 __attribute__((ext_vector_type(2)));   // packed fp32 pair -> v_pk_{mul,add,fma}_f32 (2 results / instr)
-__device__ inline float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// SiLU of two values: 3 packed ops + 2 v_exp_f32 + 2 v_rcp_f32
-__device__ inline f2 silu2(f2 x)
-{
-    const f2 y = x * (f2){-1.44269504088896f, -1.44269504088896f};
-    f2 e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
-    e = e + (f2){1.0f, 1.0f};
-    const f2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
-    return x * r;
-}
-__device__ inline float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // a + (float)half of a packed fp16 pair in ONE plain-rate instruction (v_fma_mix_f32: f16 source 0 times 1.0 plus f32 source 2);
 // hipcc otherwise emits v_cvt_f32_f16 x2 + v_pk_add_f32, twice the issue time (tools/ubench/valu_rate.hip)
 __device__ inline float add_half_lo(float a, uint32_t h2)
@@ -272,6 +266,42 @@ template <int F16> __device__ inline uint16_t to16(float x)
     else return __builtin_bit_cast(uint16_t, (__bf16)x);
 }
 
+// Every input of a SiLU on this path is carried pre-multiplied by SILU_S = -log2(e): silu(x) = x * sigmoid(x) with
+// x' = SILU_S * x is (x' / SILU_S) / (1 + exp2(x')), i.e. exp2 -> +1 -> rcp -> mul on x' and a constant factor 1 / SILU_S
+// that the next linear stage absorbs:
+//   producer   pre' = S * (A_i + Bm_j + w_r r^2 + table rows)   (tables, w_r, [Wa|Wb] and b1 are scaled on the host / in the
+//              producing GEMM: api.hip)                          m' = pre' / (1 + exp2(pre')) = S * m
+//   contraction acc' = W2 m' + S b2 = S * (W2 m + b2)            (the weights are untouched)
+//   epilogue   m2' = acc' / (1 + exp2(acc')) = S * m2 ;  gate = 1 / (1 + exp2(att_w . m2' + S att_b)) ;
+//              agg = (1 / S) * sum_rows gate * m2' ;  stored messages = gate * m2' = S * (gated message)
+//   coord MLP  acc' = Wc1 (S m~) + S bc1 ;  c' = S * c ;  w = (wc2 / S) . c'
+
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+// 16-byte buffer load: wave-uniform resource + base in SGPRs, per-lane byte offset in ONE VGPR, wave-uniform extra offset in
+// an SGPR / the immediate field - no 64-bit VALU address arithmetic per gather
+__device__ inline uint4 bload16(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline float4 bload16f(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *base)
+{   // raw buffer (stride 0), 2 GiB window, dword-format descriptor word 3 of gfx9
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00027000);
+}
+// SiLU of two pre-scaled values (see SILU_S): 2 v_exp_f32 + 2 v_rcp_f32 + 2 packed ops
+__device__ inline f2 silu2s(f2 x)
+{
+    f2 e = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+    e = e + (f2){1.0f, 1.0f};
+    const f2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    return x * r;
+}
+
 template <int MODE, int F16>   // MODE 0: edge messages (+ store of gated messages on the last layer), 1: coordinate MLP
                                  // F16 0: bf16 MFMA operands, 1: fp16 MFMA operands (3 more mantissa bits, same rate)
 __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
@@ -292,18 +322,45 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
     const int NTc = (NT + nsplit - 1) / nsplit;           // nodes per chunk
     const int U = p.B * nsplit;                           // chunks; chunk u lives on XCD u % 8
     const int nb = U > xcd ? (U - xcd + 7) >> 3 : 0;      // chunks owned by this XCD
-    const long long ntask = (long long)nb * NTc;
+    const unsigned ntask = (unsigned)nb * (unsigned)NTc;
+    const unsigned tstride = (unsigned)wg_per_xcd * EDGE_WAVES;
     const int K = p.K, ntile = (K + 31) >> 5;
-    const float *bias_v = MODE == 0 ? p.b2 : p.bc1;       // bias of this contraction
-    const float *dot_v = MODE == 0 ? p.att_w : p.wc2;     // att_w / wc2
+    const float *dot_v = MODE == 0 ? p.att_w : p.wc2;     // att_w / wc2 (wc2 pre-divided by SILU_S)
 
-    for (unsigned tt = (unsigned)slot * EDGE_WAVES + wave; tt < (unsigned)ntask; tt += (unsigned)wg_per_xcd * EDGE_WAVES) {
+    // task tt of this XCD -> (trajectory, node); wave-uniform, kept in SGPRs
+    auto task_node = [&](unsigned tt, int &b, int &i) -> bool {
         const unsigned tq = tt / (unsigned)NTc, tr = tt - tq * (unsigned)NTc;
         const int u = xcd + 8 * (int)tq;
-        const int b = __builtin_amdgcn_readfirstlane(u / nsplit);                    // wave-uniform -> SGPRs
+        b = __builtin_amdgcn_readfirstlane(u / nsplit);
         const int idx = __builtin_amdgcn_readfirstlane((u % nsplit) * NTc + (int)tr);
-        if (idx >= NT) continue;
-        const int i = (MODE == 0 ? 0 : p.R) + idx;
+        i = (MODE == 0 ? 0 : p.R) + idx;
+        return idx < NT;
+    };
+    // the constant A operand of the bias k-step: (1, 1, 0 ...) in k = 0, 1 of every row; bias = hi + lo in the B operand
+    Frag onef;
+    onef.u = make_uint4(h == 0 ? (F16 ? 0x3c003c00u : 0x3f803f80u) : 0u, 0u, 0u, 0u);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(p.T2b), rs_w = make_rsrc(p.w_r);
+
+    // edge indices / feature codes / radial of the tile a wave works on next, requested under the current tile's last MFMA
+    // phase so that the first gathers of the next tile do not wait for them (MODE 0)
+    bool pref = false;
+    int jqn[2] = {0, 0}; uint32_t codeqn[2] = {0u, 0u}; float radqn[2] = {0.f, 0.f};
+    const int r16 = lane >> 2, c4 = lane & 3;
+    auto load_idx = [&](size_t ebase, int i, int mt, int (&jq)[2], uint32_t (&codeq)[2], float (&radq)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int s = mt * 32 + q * 16 + r16;
+            const bool v = s < K;
+            jq[q] = v ? p.edges[ebase + s] : i;
+            codeq[q] = v ? p.codes[ebase + s] : 0u;
+            radq[q] = v ? p.radial[ebase + s] : 0.f;
+        }
+    };
+
+    for (unsigned tt = (unsigned)slot * EDGE_WAVES + wave; tt < ntask; tt += tstride) {
+        int b, i;
+        if (!task_node(tt, b, i)) continue;
         const size_t node = (size_t)b * p.N + i;
         const size_t ebase = node * K;
         const size_t ab = (size_t)b * p.ab_bstride;
@@ -313,15 +370,9 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
         float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // MODE 1: sum_s cdiff * w
 
         for (int mt = 0; mt < ntile; ++mt) {
-            // accumulators start at the bias of this contraction (lane = output column): the epilogue needs no bias add
             f32x16 acc[8];
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const float bcol = bias_v[nt * 32 + l31];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][r] = bcol;
-            }
-            float dv[8];   // dot vector of the epilogue, fetched under the last MFMA phase
+            float dv[8];        // dot vector of the epilogue, fetched under the last MFMA phase
+            uint32_t bp[8];     // packed (hi, lo) bias of this lane's column per n-tile (lanes 32..63: 0)
 
             if constexpr (MODE == 0) {
                 // ---- interleaved form: a chunk is 32 channels (two MFMA k-steps, 16 MFMAs).  Producer layout: four
@@ -329,34 +380,36 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 // of staging are two 2 KiB buffers laid out [unit u = 8-channel group][row ^ 4u] x 16 B (conflict-free
                 // for the producer's writes and the MFMA A-fragment reads); while the MFMAs of chunk c read buffer c & 1,
                 // the arithmetic of chunk c + 1 fills the other one and the gathers of chunk c + 2 are issued.
-                const int r16 = lane >> 2, c4 = lane & 3;
                 int jq[2]; uint32_t codeq[2]; float radq[2];
+                if (pref) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { jq[q] = jqn[q]; codeq[q] = codeqn[q]; radq[q] = radqn[q]; }
+                } else {
+                    load_idx(ebase, i, mt, jq, codeq, radq);
+                }
+                // per-lane byte offsets of the four gathered rows of each pass (one VGPR each); the channel chunk goes in
+                // the scalar offset of the buffer load
+                const __amdgpu_buffer_rsrc_t rs_bm = make_rsrc(p.Bmb + ab), rs_a = make_rsrc(p.A + ab + (size_t)i * H);
+                uint32_t obm[2], ot0[2], ot1[2], ot2[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const int s = mt * 32 + q * 16 + r16;
-                    const bool v = s < K;
-                    jq[q] = v ? p.edges[ebase + s] : i;
-                    codeq[q] = v ? p.codes[ebase + s] : 0u;
-                    radq[q] = v ? p.radial[ebase + s] : 0.f;
+                    const uint32_t code = codeq[q];
+                    obm[q] = (uint32_t)jq[q] * (H * 2) + c4 * 16;
+                    ot0[q] = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * (H * 2) + c4 * 16;
+                    ot1[q] = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * (H * 2) + c4 * 16;
+                    ot2[q] = (1056u + ((code >> 20) & 127u)) * (H * 2) + c4 * 16;
                 }
-                const float *Arow = p.A + ab + (size_t)i * H + c4 * 8;
+                const uint32_t oc4 = c4 * 32;
                 float4 a0, a1, w0, w1;
                 auto gather_chunk = [&](int c) {
-                    a0 = *reinterpret_cast<const float4 *>(Arow + c * 32);
-                    a1 = *reinterpret_cast<const float4 *>(Arow + c * 32 + 4);
-                    w0 = *reinterpret_cast<const float4 *>(p.w_r + c * 32 + c4 * 8);
-                    w1 = *reinterpret_cast<const float4 *>(p.w_r + c * 32 + c4 * 8 + 4);
+                    a0 = bload16f(rs_a, oc4, c * 128); a1 = bload16f(rs_a, oc4, c * 128 + 16);
+                    w0 = bload16f(rs_w, oc4, c * 128); w1 = bload16f(rs_w, oc4, c * 128 + 16);
                 };
                 auto gather = [&](int c, int q, RawP &r) {
-                    const uint32_t ch = c * 32 + c4 * 8;
-                    const uint32_t code = codeq[q];
-                    r.bm = *reinterpret_cast<const uint4 *>(p.Bmb + ab + ((uint32_t)jq[q] * H + ch));
-                    const uint32_t i0 = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * H;
-                    const uint32_t i1 = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * H;
-                    const uint32_t i2 = (1056u + ((code >> 20) & 127u)) * H;
-                    r.t0 = *reinterpret_cast<const uint4 *>(p.T2b + (i0 + ch));
-                    r.t1 = *reinterpret_cast<const uint4 *>(p.T2b + (i1 + ch));
-                    r.t2 = *reinterpret_cast<const uint4 *>(p.T2b + (i2 + ch));
+                    r.bm = bload16(rs_bm, obm[q], c * 64);
+                    r.t0 = bload16(rs_t, ot0[q], c * 64);
+                    r.t1 = bload16(rs_t, ot1[q], c * 64);
+                    r.t2 = bload16(rs_t, ot2[q], c * 64);
                 };
                 // The producer arithmetic of one pass (8 channels of one row per lane) cut into eight slices, so that it can
                 // be laid between MFMAs in program order: even slice 2e = pre-activation of channel pair e, odd slice
@@ -383,8 +436,8 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                         if constexpr (F16) pv[e] = add_half2(pv[e], pbm.h[e]);
                         pv[e] = add_half2(pv[e], pt.h[e]);
                     } else {
-                        const f2 m = silu2(pv[e]);
-                        if constexpr (F16) { pf.f[2 * e] = (_Float16)fminf(m.x, 65504.f); pf.f[2 * e + 1] = (_Float16)fminf(m.y, 65504.f); }
+                        const f2 m = silu2s(pv[e]);
+                        if constexpr (F16) { pf.f[2 * e] = (_Float16)fmaxf(m.x, -65504.f); pf.f[2 * e + 1] = (_Float16)fmaxf(m.y, -65504.f); }
                         else { pf.b[2 * e] = (__bf16)m.x; pf.b[2 * e + 1] = (__bf16)m.y; }
                         if (k == 7) {
                             const int row = q * 16 + r16;
@@ -403,8 +456,9 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 compute_store(1, r1, stage); gather(1, 1, r1);
                 gather_chunk(1);
                 // one chunk: 16 MFMAs of chunk c; PRODUCE: the arithmetic of chunk c + 1, one slice after every MFMA in
-                // program order with a scheduling barrier behind it; GATHER: the loads of chunk c + 2.
-                auto chunk = [&](int c, auto produce, auto gather_next) {
+                // program order with a scheduling barrier behind it; GATHER: the loads of chunk c + 2; FIRST: the chunk that
+                // opens the accumulators (C operand = 0, no accumulator initialisation on the VALU)
+                auto chunk = [&](int c, auto produce, auto gather_next, auto first) {
                     char *bufc = stage + (c & 1) * 2048, *bufn = stage + ((c + 1) & 1) * 2048;
                     wave_lds_fence();
                     Frag af[2];
@@ -421,7 +475,12 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 #pragma unroll
                     for (int m = 0; m < 16; ++m) {
                         if (m + BD - 1 < 16) bq[(m + BD - 1) % BD].u = wq[(m + BD - 1) * 64];
-                        acc[m & 7] = mfma16<F16>(af[m >> 3], bq[m % BD], acc[m & 7]);
+                        if constexpr (decltype(first)::value) {
+                            if (m < 8) acc[m] = mfma16<F16>(af[0], bq[m % BD], zero16);
+                            else acc[m & 7] = mfma16<F16>(af[1], bq[m % BD], acc[m & 7]);
+                        } else {
+                            acc[m & 7] = mfma16<F16>(af[m >> 3], bq[m % BD], acc[m & 7]);
+                        }
                         if constexpr (decltype(produce)::value) {
                             if (m < 8) slice(0, m, r0, bufn); else slice(1, m - 8, r1, bufn);
                             if constexpr (decltype(gather_next)::value) {
@@ -429,15 +488,28 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                                 if (m == 15) { gather(c + 2, 1, r1); gather_chunk(c + 2); }
                             }
                         } else {
-                            if (m < 8) dv[m] = dot_v[m * 32 + l31];
+                            if (m < 8) {
+                                dv[m] = dot_v[m * 32 + l31];
+                                const uint32_t bw = p.biasp[m * 32 + l31];
+                                bp[m] = h == 0 ? bw : 0u;
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
+                chunk(0, std::true_type{}, std::true_type{}, std::true_type{});
 #pragma unroll 1
-                for (int c = 0; c < 6; ++c) chunk(c, std::true_type{}, std::true_type{});
-                chunk(6, std::true_type{}, std::false_type{});
-                chunk(7, std::false_type{}, std::false_type{});
+                for (int c = 1; c < 6; ++c) chunk(c, std::true_type{}, std::true_type{}, std::false_type{});
+                chunk(6, std::true_type{}, std::false_type{}, std::false_type{});
+                // indices of the tile this wave works on next: the second tile of this node, or the first tile of its next task
+                {
+                    int nb2 = b, ni = i, nmt = mt + 1;
+                    bool nvalid = true;
+                    if (nmt == ntile) { nmt = 0; nvalid = tt + tstride < ntask && task_node(tt + tstride, nb2, ni); }
+                    pref = nvalid;
+                    if (nvalid) load_idx(((size_t)nb2 * p.N + ni) * K, ni, nmt, jqn, codeqn, radqn);
+                }
+                chunk(7, std::false_type{}, std::false_type{}, std::false_type{});
             } else {
                 // the stored messages of this tile are already in A-fragment order (see the store below): one contiguous
                 // 1 KiB per wave instruction; all sixteen k-steps of the tile are requested up front (HBM latency, not
@@ -459,12 +531,24 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                         if (m + CDEPTH - 1 < 128) bq[(m + CDEPTH - 1) % CDEPTH].u = wq[(m + CDEPTH - 1) * 64];
                         Frag af;
                         af.u = a16[m >> 3];
-                        acc[m & 7] = mfma16<F16>(af, bq[m % CDEPTH], acc[m & 7]);
+                        if (m < 8) acc[m] = mfma16<F16>(af, bq[m % CDEPTH], zero16);
+                        else acc[m & 7] = mfma16<F16>(af, bq[m % CDEPTH], acc[m & 7]);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next group's reads (spills)
                 }
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) dv[nt] = dot_v[nt * 32 + l31];
+                for (int nt = 0; nt < 8; ++nt) {
+                    dv[nt] = dot_v[nt * 32 + l31];
+                    const uint32_t bw = p.biasp[nt * 32 + l31];
+                    bp[nt] = h == 0 ? bw : 0u;
+                }
+            }
+            // bias k-step: acc += 1 * hi + 1 * lo (the accumulators were opened with C = 0)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                Frag bb;
+                bb.u = make_uint4(bp[nt], 0u, 0u, 0u);
+                acc[nt] = mfma16<F16>(onef, bb, acc[nt]);
             }
 
             // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) -------------
@@ -478,7 +562,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     const f2 vv = {dv[nt], dv[nt]};
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const f2 m = silu2((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
+                        const f2 m = silu2s((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
                         acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
                         part2[q] = m * vv + part2[q];
                     }
@@ -493,10 +577,11 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    part[r] = row < K ? sigmoid_fast(part[r] + p.att_b) : 0.f;   // attention gate; masked rows -> 0
+                    // attention gate sigmoid(logit) = 1 / (1 + exp2(S logit)); part = S * (att_w . m2), att_b pre-scaled
+                    part[r] = row < K ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(part[r] + p.att_b)) : 0.f;
                 }
                 const bool store_m = p.last && i >= p.R;
-                if (store_m) {   // the last layer's launch is bound by these 2.5 GB of HBM writes, not by store issue (measured)
+                if (store_m) {
                     // A-fragment order of the coordinate-MLP kernel: [k-step 16][lane half 2][row 32][8 channels] per tile
                     uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H);
 #pragma unroll
@@ -540,7 +625,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
                 const float t = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
-                if (h == 0) p.agg[node * H + nt * 32 + l31] = t;
+                if (h == 0) p.agg[node * H + nt * 32 + l31] = t * p.inv_s;
             }
         } else {
             cacc0 = wave_sum(cacc0); cacc1 = wave_sum(cacc1); cacc2 = wave_sum(cacc2);
@@ -560,6 +645,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 static EdgeKArgs to_kargs(const EdgeArgs &a)
 {
     EdgeKArgs k;
+    std::memset(&k, 0, sizeof(k));
     k.A = a.A; k.Bm = a.Bm; k.Bmb = a.Bmb; k.ab_bstride = a.ab_bstride;
     k.edges = a.edges; k.codes = a.codes; k.radial = a.radial; k.ca4 = a.ca4;
     k.B = a.B; k.N = a.N; k.R = a.R; k.K = a.K; k.L = a.N - a.R;
@@ -568,6 +654,16 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
     k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf;
+    return k;
+}
+// the 16-bit MFMA kernels take the -log2(e)-scaled operands (SILU_S, api.hip)
+static EdgeKArgs to_kargs_mfma(const EdgeArgs &a, int mode)
+{
+    EdgeKArgs k = to_kargs(a);
+    const LayerDev *w = a.lw;
+    k.w_r = w->w_r_s; k.att_b = w->att_b * SILU_S; k.inv_s = 1.0f / SILU_S; k.wc2 = w->wc2_s;
+    if (mode == 0) { k.Wf = reinterpret_cast<const uint4 *>(a.f16 ? w->W2f16 : w->W2f); k.biasp = a.f16 ? w->b2p16 : w->b2p; }
+    else { k.Wf = reinterpret_cast<const uint4 *>(a.f16 ? w->Wc1f16 : w->Wc1f); k.biasp = a.f16 ? w->bc1p16 : w->bc1p; }
     return k;
 }
 
@@ -612,16 +708,14 @@ template <int MODE, int F16> static hipError_t launch_mfma_t(const EdgeKArgs &k,
 
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    EdgeKArgs k = to_kargs(a);
-    if (a.f16) k.Wf = reinterpret_cast<const uint4 *>(a.lw->W2f16);
+    const EdgeKArgs k = to_kargs_mfma(a, 0);
     const long long tasks = (long long)a.B * a.N;
     return a.f16 ? launch_mfma_t<0, 1>(k, tasks, s) : launch_mfma_t<0, 0>(k, tasks, s);
 }
 
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    EdgeKArgs k = to_kargs(a);
-    k.Wf = reinterpret_cast<const uint4 *>(a.f16 ? a.lw->Wc1f16 : a.lw->Wc1f);
+    const EdgeKArgs k = to_kargs_mfma(a, 1);
     const long long tasks = (long long)a.B * (a.N - a.R);
     return a.f16 ? launch_mfma_t<1, 1>(k, tasks, s) : launch_mfma_t<1, 0>(k, tasks, s);
 }

@@ -310,7 +310,7 @@ __device__ inline float normal_from(uint32_t a, uint32_t b)
 }
 
 __global__ __launch_bounds__(256) void k_init_pose(const float *__restrict__ rec_pos, const float *__restrict__ lig0, int R,
-                                                   int L, const float *__restrict__ R0_inj,
+                                                   int L, int all_atoms, const float *__restrict__ R0_inj,
                                                    const float *__restrict__ tr_inj, uint32_t seed_lo, uint32_t seed_hi,
                                                    float *__restrict__ lig_cur, float *__restrict__ tr_update,
                                                    float *__restrict__ rot_update)
@@ -319,13 +319,19 @@ __global__ __launch_bounds__(256) void k_init_pose(const float *__restrict__ rec
     __shared__ float sh[24];   // c2[3], tr[3], R0[9]
     const int b = blockIdx.x;
     double a0 = 0, a1 = 0, a2 = 0, l0 = 0, l1 = 0, l2 = 0;
-    for (int q = threadIdx.x; q < R; q += blockDim.x) { a0 += rec_pos[q * 9 + 3]; a1 += rec_pos[q * 9 + 4]; a2 += rec_pos[q * 9 + 5]; }
-    for (int q = threadIdx.x; q < L; q += blockDim.x) { l0 += lig0[q * 9 + 3]; l1 += lig0[q * 9 + 4]; l2 += lig0[q * 9 + 5]; }
+    if (all_atoms) {   // second family: torch.mean(x, dim=(0, 1)) over all backbone atoms (src/inference.py:224-225)
+        for (int q = threadIdx.x; q < R * 3; q += blockDim.x) { a0 += rec_pos[q * 3]; a1 += rec_pos[q * 3 + 1]; a2 += rec_pos[q * 3 + 2]; }
+        for (int q = threadIdx.x; q < L * 3; q += blockDim.x) { l0 += lig0[q * 3]; l1 += lig0[q * 3 + 1]; l2 += lig0[q * 3 + 2]; }
+    } else {
+        for (int q = threadIdx.x; q < R; q += blockDim.x) { a0 += rec_pos[q * 9 + 3]; a1 += rec_pos[q * 9 + 4]; a2 += rec_pos[q * 9 + 5]; }
+        for (int q = threadIdx.x; q < L; q += blockDim.x) { l0 += lig0[q * 9 + 3]; l1 += lig0[q * 9 + 4]; l2 += lig0[q * 9 + 5]; }
+    }
+    const int nr = all_atoms ? R * 3 : R, nl = all_atoms ? L * 3 : L;
     a0 = block_sum_d(a0, scratch); a1 = block_sum_d(a1, scratch); a2 = block_sum_d(a2, scratch);
     l0 = block_sum_d(l0, scratch); l1 = block_sum_d(l1, scratch); l2 = block_sum_d(l2, scratch);
     if (threadIdx.x == 0) {
-        const float c1[3] = {(float)(a0 / R), (float)(a1 / R), (float)(a2 / R)};
-        const float c2[3] = {(float)(l0 / L), (float)(l1 / L), (float)(l2 / L)};
+        const float c1[3] = {(float)(a0 / nr), (float)(a1 / nr), (float)(a2 / nr)};
+        const float c2[3] = {(float)(l0 / nl), (float)(l1 / nl), (float)(l2 / nl)};
         float R0[9], draw[3];
         if (R0_inj) {
             for (int k = 0; k < 9; ++k) R0[k] = R0_inj[b * 9 + k];
@@ -372,11 +378,11 @@ __global__ __launch_bounds__(256) void k_init_pose(const float *__restrict__ rec
     }
 }
 
-hipError_t launch_init_pose(const float *rec_pos, const float *lig0, int B, int R, int L, const float *R0,
+hipError_t launch_init_pose(const float *rec_pos, const float *lig0, int B, int R, int L, int all_atoms, const float *R0,
                             const float *tr_draw, uint64_t seed, float *lig_cur, float *tr_update, float *rot_update,
                             hipStream_t s)
 {
-    hipLaunchKernelGGL(k_init_pose, dim3(B), dim3(256), 0, s, rec_pos, lig0, R, L, R0, tr_draw, (uint32_t)seed,
+    hipLaunchKernelGGL(k_init_pose, dim3(B), dim3(256), 0, s, rec_pos, lig0, R, L, all_atoms, R0, tr_draw, (uint32_t)seed,
                        (uint32_t)(seed >> 32), lig_cur, tr_update, rot_update);
     return hipGetLastError();
 }

@@ -90,6 +90,7 @@ struct HeadKArgs {
     const float *z_rot, *z_tr;
     long long z_bstride;
     uint32_t seed_lo, seed_hi, step;
+    int all_atoms;
     float *lig_cur, *tr_update, *rot_update;
     float *trace_pose;
     long long trace_bstride;
@@ -192,8 +193,13 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
     // ---- Euler-Maruyama step (inference_base.py:439-456) ---------------------------------------
     float *lig = p.lig_cur + (size_t)b * L * 9;
     double c0 = 0, c1 = 0, c2 = 0;
-    for (int q = tid; q < L; q += blockDim.x) { c0 += lig[q * 9 + 3]; c1 += lig[q * 9 + 4]; c2 += lig[q * 9 + 5]; }
+    if (p.all_atoms) {   // second family: centre = mean over all backbone atoms (src/inference.py:245, DFMDock.py:247)
+        for (int q = tid; q < L * 3; q += blockDim.x) { c0 += lig[q * 3]; c1 += lig[q * 3 + 1]; c2 += lig[q * 3 + 2]; }
+    } else {
+        for (int q = tid; q < L; q += blockDim.x) { c0 += lig[q * 9 + 3]; c1 += lig[q * 9 + 4]; c2 += lig[q * 9 + 5]; }
+    }
     c0 = block_sum_d(c0, dscr); c1 = block_sum_d(c1, dscr); c2 = block_sum_d(c2, dscr);
+    const int ncen = p.all_atoms ? L * 3 : L;
     if (tid == 0) {
         float zr[3], zt[3];
         if (p.z_rot) {
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
         aa_to_mat(rot, Rm);
         for (int k = 0; k < 9; ++k) s_upd[k] = Rm[k];
         for (int k = 0; k < 3; ++k) s_upd[9 + k] = tr[k];
-        s_upd[12] = (float)(c0 / L); s_upd[13] = (float)(c1 / L); s_upd[14] = (float)(c2 / L);
+        s_upd[12] = (float)(c0 / ncen); s_upd[13] = (float)(c1 / ncen); s_upd[14] = (float)(c2 / ncen);
         // tr_update += tr ; rot_update = axis_angle(R(rot) @ R(rot_update))
         float ru[3] = {p.rot_update[b * 3], p.rot_update[b * 3 + 1], p.rot_update[b * 3 + 2]}, rn[3];
         rot_compose(ru, rot, rn);
@@ -263,7 +269,7 @@ hipError_t launch_heads(const HeadArgs &a, hipStream_t s)
     k.g2_r = a.g2_r; k.g_r = a.g_r; k.hg2_r = a.hg2_r; k.g2_t = a.g2_t; k.g_t = a.g_t; k.hg2_t = a.hg2_t;
     k.dt = a.dt; k.sqrt_dt = a.sqrt_dt; k.rot_noise = a.rot_noise; k.tr_noise = a.tr_noise; k.ode = a.ode;
     k.z_rot = a.z_rot; k.z_tr = a.z_tr; k.z_bstride = a.z_bstride;
-    k.seed_lo = (uint32_t)a.seed; k.seed_hi = (uint32_t)(a.seed >> 32); k.step = a.step;
+    k.seed_lo = (uint32_t)a.seed; k.seed_hi = (uint32_t)(a.seed >> 32); k.step = a.step; k.all_atoms = a.all_atoms;
     k.lig_cur = a.lig_cur; k.tr_update = a.tr_update; k.rot_update = a.rot_update;
     k.trace_pose = a.trace_pose; k.trace_bstride = a.trace_bstride;
     k.trace_scores = a.trace_scores; k.trace_s_bstride = a.trace_s_bstride;

@@ -25,6 +25,9 @@
  * negative dfm_status otherwise (the reference raises Python exceptions:
  * ValueError for t outside [0,1] -> DFM_E_INVALID).  Handles must not be shared
  * between host threads without external locking; one process (or thread) per GPU.
+ * A model lives on the device that was current at dfm_model_create (dfm_set_device), a
+ * complex on its model's device; every entry point switches to the handle's device for
+ * the duration of the call and restores the caller's current device.
  * Everything computes on the GPU: there is no CPU fallback in this library.
  */
 #ifndef DFMDOCK_AMD_H
@@ -51,7 +54,8 @@ typedef enum {
 /* configs/model/score_model_mlsb.yaml:3-27 (+ score_net_mlsb.py:33,:85 constants) */
 typedef struct {
     int lm_embed_dim;          /* 1301 = 1280 (ESM-2) + 21 (one-hot)   */
-    int positional_embed_dim;  /* 66                                    */
+    int positional_embed_dim;  /* 66, or 67 = 66 relpos + 1 "sym" channel (configs/model/DFMDock.yaml:5):
+                                  the homomer flag of the complex, see dfm_complex_set_homomer            */
     int spatial_embed_dim;     /* 100 = 40 + 24 + 24 + 12               */
     int node_dim;              /* 256 (only value supported by kernels) */
     int edge_dim;              /* 128                                   */
@@ -79,7 +83,8 @@ enum {
     DFM_F_ODE = 1u << 4,             /* so3_diffuser.py:367-368                                  */
     DFM_F_PROFILE = 1u << 5,         /* time the dominant kernel with HIP events (dfm_get_profile) */
     DFM_F_STEP_ENERGY = 1u << 6,     /* dfm_sample: evaluate the energy head on every step (traces) */
-    DFM_F_F16 = 1u << 7              /* like DFM_F_BF16 but with fp16 MFMA operands (11-bit mantissa, same rate) */
+    DFM_F_F16 = 1u << 7,             /* like DFM_F_BF16 but with fp16 MFMA operands (11-bit mantissa, same rate) */
+    DFM_F_IRES = 1u << 8             /* dfm_score: also evaluate the interface-residue head (score_net_mlsb.py:383) */
 };
 
 /* Output of dfm_score.  Required: tr_score, rot_score.  Any other pointer may be NULL. */
@@ -95,6 +100,8 @@ typedef struct {
     int32_t *edges;       /* [B,N,K]  edge list actually used                           */
     uint32_t *edge_codes; /* [B,N,K]  packed feature bins: d | omega<<6 | theta<<11 | phi<<16 | relpos<<20 */
     float *confidence;    /* [B]      family 1 + DFM_F_ENERGY: confidence_logits (egnn_net.py:444); may be NULL */
+    float *ires;          /* [B,N]    needs DFM_F_IRES: to_ires(node_out) (score_net_mlsb.py:297-303,:383; family 1:
+                                      ires_logits, egnn_net.py:362-368,:462); may be NULL                     */
 } dfm_score_out;
 
 /* Injected randomness for parity tests (every pointer may be NULL = draw natively with Philox) */
@@ -140,6 +147,15 @@ void dfm_model_destroy(dfm_model *m);
 dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x /*[R,lm]*/, const float *lig_x /*[L,lm]*/,
                                 const float *rec_pos /*[R,9]*/, const float *lig_pos /*[L,9]*/, int R, int L);
 void dfm_complex_destroy(dfm_complex *cx);
+/* Replace the poses stored by dfm_complex_create (either pointer may be NULL = keep): rec_pos [R,9] is what every later
+ * dfm_score / dfm_sample call sees as the receptor, lig_pos [L,9] is the start pose of dfm_sample.  The node features and
+ * everything derived from them stay resident - a caller that re-centres the complex every step (DFMDock.move_to_lig_center,
+ * src/models/DFMDock.py:254-257) or docks several ligand conformations does not pay the feature upload again. */
+int dfm_complex_set_pose(dfm_complex *cx, const float *rec_pos_or_null, const float *lig_pos_or_null);
+/* positional_embed_dim = 67 only: value of the 67th ("sym") position channel for this complex - 1 when receptor and ligand
+ * have the same sequence (is_homomer, src/datasets/docking_dataset.py:129), 0 otherwise (the default).  DFM_E_INVALID for a
+ * 66-channel model and flag != 0. */
+int dfm_complex_set_homomer(dfm_complex *cx, int flag);
 /* edges per node for this complex: min(N,20) + min(40, N-20) */
 int dfm_complex_degree(const dfm_complex *cx);
 

@@ -310,6 +310,13 @@ static void ca_mean(const float *x, int n, float c[3])
         for (int d = 0; d < 3; ++d) s[d] += x[i * 9 + 3 + d];
     for (int d = 0; d < 3; ++d) c[d] = (float)(s[d] / n);
 }
+static void atom_mean(const float *x, int n, float c[3])
+{   /* torch.mean(x, dim=(0, 1)): all n x 3 backbone atoms (src/inference.py:224-225,:245; DFMDock.py:247) */
+    double s[3] = {0, 0, 0};
+    for (int a = 0; a < n * 3; ++a)
+        for (int d = 0; d < 3; ++d) s[d] += x[a * 3 + d];
+    for (int d = 0; d < 3; ++d) c[d] = (float)(s[d] / (n * 3));
+}
 static void rotate_about(float *x, int n, const float c[3], const float Rm[9])
 {   /* (x - c) @ R.T + c on every backbone atom */
     for (int a = 0; a < n * 3; ++a) {
@@ -325,6 +332,15 @@ void ora_modify_coords(float *x, int n, const float rot[3], const float tr[3])
 {   /* inference_base.py:342-352 */
     float c[3], Rm[9];
     ca_mean(x, n, c);
+    ora_axis_angle_to_matrix(rot, Rm);
+    rotate_about(x, n, c, Rm);
+    for (int a = 0; a < n * 3; ++a)
+        for (int d = 0; d < 3; ++d) x[a * 3 + d] += tr[d];
+}
+void ora_modify_coords_all_atom(float *x, int n, const float rot[3], const float tr[3])
+{   /* second family: src/inference.py:244-254 == DFMDock.py:246-252 (rotation about the all-atom centroid) */
+    float c[3], Rm[9];
+    atom_mean(x, n, c);
     ora_axis_angle_to_matrix(rot, Rm);
     rotate_about(x, n, c, Rm);
     for (int a = 0; a < n * 3; ++a)
@@ -528,6 +544,11 @@ void ora_knn_sample(const ora_hparams *hp, const float *ca, int N, uint64_t seed
 
 /* ------------------------------------------------------------------------- */
 /* a-5: Score_Net.forward(predict=True) (score_net_mlsb.py:343-425) */
+/* positional_embed_dim = 67 (configs/model/DFMDock.yaml:5): the 67th position channel is the homomer flag of the complex
+ * (`is_homomer`, datasets/docking_dataset.py:129), the same value on every residue pair */
+static int g_homomer = 0;
+void ora_set_homomer(int flag) { g_homomer = flag ? 1 : 0; }
+
 int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const float *rec_x, const float *lig_x,
               const float *rec_pos, const float *lig_pos, float t, const int32_t *edges_in, uint64_t seed,
               int want_energy, ora_score_out *out, ora_debug *dbg)
@@ -601,7 +622,9 @@ int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const floa
             for (int c = 0; c < He; ++c) {
                 const float *ws = w.spatial_embed + (int64_t)c * Sd;
                 float sp = ((ws[b[0]] + ws[40 + b[1]]) + ws[64 + b[2]]) + ws[88 + b[3]];
-                eattr[e * He + c] = sp + w.positional_embed[(int64_t)c * Pd + rp];
+                float pe = w.positional_embed[(int64_t)c * Pd + rp];
+                if (Pd == 67 && g_homomer) pe += w.positional_embed[(int64_t)c * Pd + 66];
+                eattr[e * He + c] = sp + pe;
             }
             /* egnn.py:139-148 coord2radial, normalize=True */
             const float dx = ca[i * 3] - ca[j * 3], dy = ca[i * 3 + 1] - ca[j * 3 + 1],
@@ -901,8 +924,9 @@ int ora_sample(const ora_hparams *hp, const float *blob, int R, int L, const flo
 
     /* :412 randomize_pose */
     float c1[3], c2[3], R0f[9], tr_update[3], rot_update[3];
-    ca_mean(rec_pos, R, c1);
-    ca_mean(lig, L, c2);
+    const int all_atom = hp->family == 1;      /* src/inference.py:220-254 (second family) vs inference_base.py:318-352 */
+    if (all_atom) { atom_mean(rec_pos, R, c1); atom_mean(lig, L, c2); }
+    else { ca_mean(rec_pos, R, c1); ca_mean(lig, L, c2); }
     {
         double R0[9];
         if (inj && inj->R0) memcpy(R0, inj->R0, sizeof(R0)); else haar_rotation(&rng, R0);
@@ -942,7 +966,8 @@ int ora_sample(const ora_hparams *hp, const float *blob, int R, int L, const flo
         for (int d = 0; d < 3; ++d) zt[d] = (inj && inj->z_tr) ? inj->z_tr[i * 3 + d] : (float)rng_normal(&rng);
         ora_torch_reverse(ora_so3_g(hp, (double)t), so.rot_score, dt, rotn, zr, ode, rot);   /* :439-444 */
         ora_torch_reverse(ora_r3_g(hp, (double)t), so.tr_score, dt, trn, zt, ode, tr);       /* :446-451 */
-        ora_modify_coords(lig, L, rot, tr);                                                  /* :453 */
+        if (all_atom) ora_modify_coords_all_atom(lig, L, rot, tr);
+        else ora_modify_coords(lig, L, rot, tr);                                             /* :453 */
         for (int d = 0; d < 3; ++d) tr_update[d] += tr[d];                                   /* :455 */
         { float tmp[3]; ora_rot_compose(rot_update, rot, tmp); memcpy(rot_update, tmp, 12); } /* :456 */
         if (use_clash_force) {                                                               /* :458-461 */

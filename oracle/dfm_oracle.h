@@ -87,6 +87,8 @@ void ora_quaternion_to_axis_angle(const float q[4], float aa[3]);
 void ora_matrix_to_axis_angle(const float R[9], float aa[3]);
 void ora_rot_compose(const float r1[3], const float r2[3], float out[3]);
 void ora_modify_coords(float *x /*[n,9] in/out*/, int n, const float rot[3], const float tr[3]);
+void ora_modify_coords_all_atom(float *x /*[n,9] in/out*/, int n, const float rot[3], const float tr[3]);  /* inference.py:244-254 */
+void ora_set_homomer(int flag);   /* 67th position channel (configs/model/DFMDock.yaml:5); test-time global, default 0 */
 /* a-17: inference_base.py:366-384 (closed-form gradient of the reference's autograd) */
 void ora_clash_force(const float *rec /*[R,9]*/, int R, const float *lig /*[L,9]*/, int L, float out[3]);
 

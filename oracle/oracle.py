@@ -78,6 +78,8 @@ def lib():
         L.ora_sample.argtypes = [C.POINTER(OraHParams), F32P, C.c_int, C.c_int, F32P, F32P, F32P, F32P,
                                  C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_uint64, C.POINTER(OraInject), C.POINTER(OraTrajOut)]
+        L.ora_set_homomer.argtypes = [C.c_int]
+        L.ora_set_homomer.restype = None
         _lib = L
     return _lib
 

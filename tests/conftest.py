@@ -39,6 +39,32 @@ def blob_pair():
     return pack_blob(make_random_weights(0, hp), hp)
 
 
+_db5 = None
+
+
+def db5_ids():
+    global _db5
+    if _db5 is None:
+        _db5 = load_golden("db5_backbones.npz")
+    return [str(x) for x in _db5["ids"]]
+
+
+def db5_complex(cid):
+    """One of the 24 DB5 test complexes: the reference's backbone + sequence (tests/golden/db5_backbones.npz) with
+    node features N(0,1) seeded by the id || one-hot(seq) - the ESM-2 blocks are too large to commit."""
+    import zlib
+    from dfmdock_amd.synthetic import seq_to_onehot
+    db5_ids()
+    out = {"id": cid}
+    for side in ("rec", "lig"):
+        seq = str(_db5[f"{cid}_{side}_seq"])
+        rng = np.random.Generator(np.random.PCG64(zlib.crc32(f"{cid}:{side}".encode())))
+        out[side + "_x"] = np.concatenate([rng.standard_normal((len(seq), 1280)).astype(np.float32), seq_to_onehot(seq)], 1)
+        out[side + "_pos"] = _db5[f"{cid}_{side}_pos"]
+        out[side + "_seq"] = seq
+    return out
+
+
 def complex_for(case):
     """Rebuild the complex a golden file was generated on (tests/golden/make_golden.py)."""
     from dfmdock_amd.synthetic import make_complex, seq_to_onehot
@@ -47,7 +73,10 @@ def complex_for(case):
         rx = np.concatenate([d["rec_esm16"].astype(np.float32), seq_to_onehot(str(d["rec_seq"]))], 1)
         lx = np.concatenate([d["lig_esm16"].astype(np.float32), seq_to_onehot(str(d["lig_seq"]))], 1)
         return {"rec_x": rx, "lig_x": lx, "rec_pos": d["rec_pos"], "lig_pos": d["lig_pos"]}
-    table = {"syn_24_16": (24, 16, 5), "syn_9_7": (9, 7, 6), "syn_64_48": (64, 48, 7)}
+    if "db5_" in case:       # DB5 backbone + seeded features (tests/golden/make_golden_r02.py: seeded_features)
+        return db5_complex(case.split("db5_")[1].split(".")[0])
+    table = {"syn_24_16": (24, 16, 5), "syn_9_7": (9, 7, 6), "syn_64_48": (64, 48, 7), "c3_300_300": (300, 300, 1),
+             "c5_1000_1000": (1000, 1000, 1)}
     for k, (R, L, seed) in table.items():
         if k in case:
             return make_complex(R, L, seed=seed)

@@ -216,3 +216,94 @@ def test_sampler_teacher_forced_steps(case, steps, blob):
         np.testing.assert_allclose(tr, g["step_tr"][i], atol=1e-6, rtol=1e-6)
         nxt = ora.modify_coords(pose, g["step_rot"][i], g["step_tr"][i])
         assert np.abs(nxt - g["poses"][i]).max() < 1e-4
+
+
+# ---- f-4: sampler variants pinned to reference runs (tests/golden/make_golden_r02.py) ---------------------------
+def _ca_rmsd(a, b):
+    return np.sqrt(((a[:, :, 1, :] - b[:, :, 1, :]) ** 2).sum(-1).mean(-1))
+
+
+@pytest.mark.parametrize("case,steps", [("rollout_anneal_syn_24_16", 40), ("rollout_anneal_7CEI", 6)])
+def test_sampler_noise_annealing_vs_reference(case, steps, blob):
+    """inference_base.py:428-430: noise scale = the time step."""
+    g = load_golden(case + ".npz")
+    o = ora.Oracle(blob, complex_for(case))
+    inj = dict(R0=g["R0"], tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"])
+    r = o.sample(num_steps=steps, inject=inj, trace=True, noise_annealing=True)
+    rmsd = _ca_rmsd(r["trace_pose"], g["poses"])
+    assert rmsd[:5].max() < 0.05 and rmsd.max() < 0.5, rmsd
+    np.testing.assert_allclose(r["trace_scores"][0, 0:3], g["tr_score"][0], rtol=0, atol=1e-4 * np.abs(g["tr_score"][0]).max())
+    if rmsd.max() < 1e-3:
+        assert abs(float(r["energy"]) - float(g["final_energy"])) < 1e-3
+        np.testing.assert_allclose(r["tr_update"], g["tr_update"], atol=2e-3)
+
+
+@pytest.mark.parametrize("case,steps", [("rollout_ode_syn_24_16", 40), ("rollout_ode_7CEI", 6)])
+def test_sampler_ode_vs_reference(case, steps, blob):
+    """inference_mlsb.Sampler.Euler_Maruyama_sampler(ode=True) (src/inference_mlsb.py:264-350; so3_diffuser.py:367-368).
+    That sampler centres both chains first, so its poses are inference_base's shifted by -c1 (SE(3) equivariance)."""
+    g = load_golden(case + ".npz")
+    o = ora.Oracle(blob, complex_for(case))
+    inj = dict(R0=g["R0"], tr_draw=g["tr_draw"], edges=g["edges"])
+    r = o.sample(num_steps=steps, inject=inj, trace=True, ode=True)
+    np.testing.assert_allclose(r["init_pose"] - g["c1"], g["init_pose"], atol=5e-5)
+    rmsd = _ca_rmsd(r["trace_pose"] - g["c1"], g["poses"])
+    assert rmsd[:5].max() < 0.05 and rmsd.max() < 0.5, rmsd
+    np.testing.assert_allclose(r["trace_scores"][0, 0:3], g["tr_score"][0], rtol=0, atol=2e-4 * np.abs(g["tr_score"][0]).max())
+    if rmsd.max() < 1e-3:
+        assert abs(float(r["energy"]) - float(g["final_energy"])) < 1e-3
+        assert r["num_clashes"] == int(g["final_num_clashes"])
+
+
+@pytest.mark.parametrize("case,steps", [("rollout2_syn_24_16", 40), ("rollout2_7CEI", 6)])
+def test_pair_family_sampler_vs_reference(case, steps, blob_pair):
+    """Second family's sampler (src/inference.py:292-372): randomize_pose / modify_coords about the ALL-ATOM centroids
+    (:220-254), DFMDock.forward as the model."""
+    g = load_golden(case + ".npz")
+    o = ora.Oracle(blob_pair, complex_for(case), pair_hparams())
+    inj = dict(R0=g["R0"], tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"])
+    r = o.sample(num_steps=steps, inject=inj, trace=True)
+    np.testing.assert_allclose(r["init_pose"], g["init_pose"], atol=3e-5)
+    rmsd = _ca_rmsd(r["trace_pose"], g["poses"])
+    assert rmsd[:5].max() < 0.05 and rmsd.max() < 0.5, rmsd
+    if rmsd.max() < 1e-3:
+        assert abs(float(r["energy"]) - float(g["final_energy"])) < 1e-3 * max(1.0, abs(float(g["final_energy"])))
+        np.testing.assert_allclose(r["tr_update"], g["tr_update"], atol=2e-3)
+        np.testing.assert_allclose(r["rot_update"], g["rot_update"], atol=2e-4)
+
+
+@pytest.mark.parametrize("flag", [0, 1])
+def test_pair_family_sym_channel(flag):
+    """positional_embed_dim = 67 (configs/model/DFMDock.yaml:5): the 67th channel is the homomer flag."""
+    from dfmdock_amd.weights import HParams, make_random_weights, pack_blob
+    hp = HParams(family=1, mask_dist=20.0, positional_embed_dim=67)
+    blob67 = pack_blob(make_random_weights(0, hp), hp)
+    g = load_golden(f"fwd2_sym{flag}_syn_24_16.npz")
+    o = ora.Oracle(blob67, complex_for("syn_24_16"), hp)
+    ora.lib().ora_set_homomer(flag)
+    try:
+        r = o.score(g["lig_pos"], float(g["t"]), edges=g["edges"])
+    finally:
+        ora.lib().ora_set_homomer(0)
+    assert rel_inf(r["f"], g["f"]) < 1e-4 and rel_inf(r["tr_score"], g["tr_score"]) < 1e-4
+    assert abs(float(r["energy"]) - float(g["energy"])) < 1e-4 * max(1.0, abs(float(g["energy"])))
+    assert abs(float(r["confidence"]) - float(g["confidence_logits"])) < 1e-4
+
+
+# ---- BASELINE configurations C3 / C5 / DB5 backbones: one reference evaluation each -------------------------------
+@pytest.mark.parametrize("case", ["fwd_c3_300_300", "fwd_db5_1AVX", "fwd_db5_4POU", "fwd_c5_1000_1000"])
+def test_score_matches_reference_large(case, blob):
+    g = load_golden(case + ".npz")
+    o = ora.Oracle(blob, complex_for(case))
+    r = o.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32))
+    assert int(r["bins"].astype(np.int64).sum()) == int(g["codes_sum"])
+    np.testing.assert_array_equal(r["bins"][::37], g["bins_sample"])
+    np.testing.assert_array_equal(r["relpos"][::37], g["relpos_sample"])
+    assert r["num_clashes"] == int(g["num_clashes"])
+    habs = np.abs(r["h_layers"]).reshape(o.hp.depth, -1)
+    np.testing.assert_allclose(habs.mean(1), g["h_absmean"], rtol=2e-5)
+    assert rel_inf(r["f"], g["f"]) < 1e-4
+    assert rel_inf(r["tr_score"], g["tr_score"]) < 1e-4
+    assert rel_inf(r["rot_score"], g["rot_score"]) < 1e-4
+    assert abs(float(r["energy"]) - float(g["energy"])) < 1e-4
+    assert rel_inf(r["ires"], g["ires"][:, 0]) < 1e-4
