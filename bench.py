@@ -30,34 +30,63 @@ PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3       # fp32 vector / f32-input MFMA
 
 
-def cpu_baseline(blob, cx, num_steps, n_forwards=8):
-    """Oracle (plain-C port of the reference, OpenMP) timed on a bounded sample: n_forwards score
-    evaluations of one trajectory; extrapolated to 41 evaluations per trajectory."""
-    from oracle import oracle as ora
-    o = ora.Oracle(blob, cx)
-    cores = ora.lib().ora_num_threads()
-    t0 = time.perf_counter()
-    r = o.sample(num_steps=num_steps, max_forwards=n_forwards, seed=1)
-    dt = time.perf_counter() - t0
-    per_fwd = dt / max(r["forwards"], 1)
-    return {"value": 1.0 / (per_fwd * (num_steps + 1)), "unit": "trajectories/s", "cores": int(cores), "kind": "port",
-            "sample": f"{r['forwards']} of {num_steps + 1} score evaluations of 1 trajectory on the same 300+300 complex "
-                      f"({dt:.1f} s), extrapolated"}
-
-
-def measured_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC run (profiles/r01_traffic.json);
-    PMC counters cannot be read from inside this process, so the number is attached only for the exact configuration
-    it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+def cpu_model():
     try:
-        t = json.load(open(path))
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except OSError:
-        return None
-    c = t["config"]
-    if (c["R"], c["L"], c["batch"], c["precision"]) == (args.R, args.L, args.batch, args.precision):
-        return t["traffic_bytes_per_launch"]
-    return None
+        pass
+    return "unknown"
+
+
+def cpu_baseline(blob, cx, num_steps, repeats=3):
+    """Oracle (plain-C port of the reference as written, OpenMP) timed on the host cores of this box on a bounded sample:
+    a few score evaluations of ONE trajectory of the same complex, extrapolated to the 41 evaluations of a trajectory.
+    Threads are pinned (OMP_PROC_BIND / OMP_PLACES, set in main() before the OpenMP runtime starts), one untimed
+    evaluation warms the pages, and the reported value is the MEDIAN of `repeats` samples; the same is measured with 8
+    threads."""
+    import statistics
+    from oracle import oracle as ora
+    L = ora.lib()
+    o = ora.Oracle(blob, cx)
+    all_cores = int(L.ora_num_threads())
+
+    def sample(n_threads, n_forwards):
+        L.ora_set_num_threads(n_threads)
+        o.sample(num_steps=num_steps, max_forwards=1, seed=1)                 # warm-up
+        vals = []
+        for r in range(repeats):
+            t0 = time.perf_counter()
+            res = o.sample(num_steps=num_steps, max_forwards=n_forwards, seed=2 + r)
+            dt = time.perf_counter() - t0
+            vals.append(1.0 / (dt / max(res["forwards"], 1) * (num_steps + 1)))
+        return vals
+
+    full = sample(all_cores, 6)
+    eight = sample(min(8, all_cores), 2)
+    L.ora_set_num_threads(all_cores)
+    return {"value": statistics.median(full), "unit": "trajectories/s", "cores": all_cores, "kind": "port",
+            "repeats": [round(v, 5) for v in full], "value_8_threads": statistics.median(eight),
+            "repeats_8_threads": [round(v, 5) for v in eight], "cpu_model": cpu_model(),
+            "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
+            "sample": f"median of {repeats} x 6 (all {all_cores} threads) / {repeats} x 2 (8 threads) score evaluations of 1 trajectory "
+                      f"of the same complex, after one warm-up evaluation, extrapolated to {num_steps + 1} evaluations per trajectory"}
+
+
+def replayed_traffic(args):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process: the number is
+    REPLAYED from the committed rocprofv3 --pmc run of this exact configuration (profiles/*_traffic.json, collected as
+    MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2) and is absent otherwise."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except OSError:
+            continue
+        c = t["config"]
+        if (c["R"], c["L"], c["batch"], c["precision"]) == (args.R, args.L, args.batch, args.precision):
+            return t["traffic_bytes_per_launch"], "replayed profiles/" + name
+    return None, None
 
 
 def main():
@@ -74,6 +103,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # pin the CPU baseline's OpenMP threads (must be in the environment before the oracle library starts its runtime)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     import torch
     import torch.distributed as dist
     from dfmdock_amd import distributed as D
@@ -141,6 +173,7 @@ def main():
         flop_per_launch = B * N * FLOP_PER_NODE_LAYER
         achieved = flop_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if mfma16 else PEAK_F32_TFLOPS
+        traffic, traffic_src = replayed_traffic(args)
         out = {
             "metric": "docking trajectories/sec (N_res~300+300, 40 steps)",
             "value": total_traj / elapsed,
@@ -161,12 +194,12 @@ def main():
             "roofline": {"bound": "mfma", "kernel": ("k_edge_bf16<0,%d>" % int(f16)) if mfma16 else "k_edge_f32", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
-                         "flop_per_launch": flop_per_launch, "traffic": measured_traffic(args),
-                         "traffic_gbps": (measured_traffic(args) / avg_launch_s / 1e9) if measured_traffic(args) else None,
-                         "valu_floor_ms": 1.8 if (args.R, args.L, args.batch) == (300, 300, 256) else None,
-                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json); traffic_gbps = HBM GB/s "
-                                         "of that kernel (peak ~8000); valu_floor_ms = the VALU-issue floor of a launch (DESIGN.md 5, "
-                                         "profiles/r01_ubench_valu_rate.txt) - the bound that applies to this kernel"},
+                         "flop_per_launch": flop_per_launch, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_gbps": (traffic / avg_launch_s / 1e9) if traffic else None,
+                         "algorithmic_bytes_per_launch": 8 * B * N * H,
+                         "note": "achieved = B*N*(2*K*H*H + 2*K*H) FLOP / launch time from HIP events on the engine's stream, live; "
+                                 "traffic = HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run: see "
+                                 "traffic_source; algorithmic bytes per launch = 8*N*H per trajectory (SURVEY 8d)"},
             "best_energy": float(D.rank_by_energy(allrec)[0][0, 2]),
         }
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only

@@ -23,10 +23,12 @@ DFM_F_ODE = 1 << 4
 DFM_F_PROFILE = 1 << 5
 DFM_F_STEP_ENERGY = 1 << 6
 DFM_F_F16 = 1 << 7
+DFM_F_IRES = 1 << 8
 
 EXPORTS = [
     "dfm_last_error", "dfm_device_count", "dfm_set_device", "dfm_default_hparams", "dfm_param_count",
     "dfm_model_create", "dfm_model_destroy", "dfm_complex_create", "dfm_complex_destroy", "dfm_complex_degree",
+    "dfm_complex_set_pose", "dfm_complex_set_homomer",
     "dfm_score", "dfm_sample", "dfm_get_profile", "dfm_diffusion_coef",
 ]
 
@@ -41,7 +43,8 @@ class HParamsC(C.Structure):
 
 class ScoreOutC(C.Structure):
     _fields_ = [("tr_score", F32P), ("rot_score", F32P), ("energy", F32P), ("num_clashes", I32P), ("f", F32P),
-                ("h_last", F32P), ("h_first", F32P), ("edges", I32P), ("edge_codes", U32P), ("confidence", F32P)]
+                ("h_last", F32P), ("h_first", F32P), ("edges", I32P), ("edge_codes", U32P), ("confidence", F32P),
+                ("ires", F32P)]
 
 
 class InjectC(C.Structure):
@@ -56,7 +59,7 @@ class TrajOutC(C.Structure):
 
 class ProfileC(C.Structure):
     _fields_ = [("edge_kernel_ms", C.c_double), ("edge_kernel_launches", C.c_int64), ("edge_rows", C.c_int64),
-                ("total_ms", C.c_double)]
+                ("total_ms", C.c_double), ("phase_cycles", C.c_double * 4), ("slot_cycles", C.c_double * 16)]
 
 
 _lib = None
@@ -88,6 +91,8 @@ def lib():
     L.dfm_complex_destroy.argtypes = [C.c_void_p]
     L.dfm_complex_destroy.restype = None
     L.dfm_complex_degree.argtypes = [C.c_void_p]
+    L.dfm_complex_set_pose.argtypes = [C.c_void_p, F32P, F32P]
+    L.dfm_complex_set_homomer.argtypes = [C.c_void_p, C.c_int]
     L.dfm_score.argtypes = [C.c_void_p, C.c_int, F32P, F32P, I32P, C.c_uint64, C.c_uint32, C.POINTER(ScoreOutC)]
     L.dfm_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint64,
                              C.POINTER(InjectC), C.POINTER(TrajOutC)]

@@ -110,7 +110,8 @@ struct dfm_complex {
     std::vector<hipEvent_t> ev;      // profiling events (pairs)
     size_t ev_used = 0;
     hipEvent_t ev_total[2] = {nullptr, nullptr};
-    dfm_profile prof = {0, 0, 0, 0};
+    dfm_profile prof = {};
+    unsigned long long *stamp_dev = nullptr;   // [8 waves][4 phases] (diagnostic builds)
     uint32_t fwd_counter = 0;
 };
 
@@ -264,13 +265,13 @@ static void split_bf16(const float *W, int Nout, int K, std::vector<uint16_t> &h
 // SILU_S * bias as packed (hi | lo << 16) 16-bit pairs: the B operand of the bias k-step of the MFMA edge kernels
 static std::vector<uint32_t> pack_bias(const float *bias, bool f16)
 {
-    std::vector<uint32_t> v(H);
+    std::vector<uint32_t> v(2 * H, 0u);      // [8 n-tiles][64 lanes]: lanes 0..31 = columns, lanes 32..63 = 0 (k >= 8)
     for (int c = 0; c < H; ++c) {
         const float x = SILU_S * bias[c];
         uint16_t hi, lo;
         if (f16) { hi = f2h(x); lo = f2h(x - h2f(hi)); }
         else { hi = f2bf(x); lo = f2bf(x - bf2f(hi)); }
-        v[c] = (uint32_t)hi | ((uint32_t)lo << 16);
+        v[(c / 32) * 64 + (c % 32)] = (uint32_t)hi | ((uint32_t)lo << 16);
     }
     return v;
 }
@@ -483,6 +484,9 @@ extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, con
     ok = ok && P.alloc(&cx->h0, (size_t)N * H) == hipSuccess && P.alloc(&cx->A0, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->Bm0, (size_t)N * H) == hipSuccess && P.alloc(&cx->Bmb0, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->A0s, (size_t)N * H) == hipSuccess;
+#ifdef DFM_EDGE_STAMP
+    ok = ok && P.alloc(&cx->stamp_dev, 48) == hipSuccess && hipMemset(cx->stamp_dev, 0, 48 * 8) == hipSuccess;
+#endif
     if (ok) {
         // node = single_embed(cat[rec_x, lig_x]) (score_net_mlsb.py:365-366): pose independent, once per complex
         GemmArgs g;
@@ -630,6 +634,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
         e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = coord; e.fout = W.fvec; e.mbuf = W.mbuf;
         e.f16 = o.f16 ? 1 : 0;
+        e.stamp = (o.profile && l == 2) ? cx->stamp_dev : nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (o.profile) {
             if (cx->ev_used + 2 > cx->ev.size()) {
@@ -742,6 +747,19 @@ static int finish_profile(dfm_complex *cx)
         HIPCHK(hipEventElapsedTime(&ms, cx->ev[i], cx->ev[i + 1]));
         cx->prof.edge_kernel_ms += ms;
     }
+#ifdef DFM_EDGE_STAMP
+    if (cx->stamp_dev) {
+        unsigned long long st[48];
+        HIPCHK(hipMemcpy(st, cx->stamp_dev, sizeof(st), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 16; ++k) cx->prof.slot_cycles[k] = (double)st[32 + k];
+        const double tiles = (double)cx->prof.edge_rows / (double)cx->prof.edge_kernel_launches / 32.0 / 2048.0;   // per wave
+        for (int k = 0; k < 4; ++k) {
+            double s2 = 0;
+            for (int w = 0; w < 8; ++w) s2 += (double)st[w * 4 + k];
+            cx->prof.phase_cycles[k] = s2 / 8.0 / (tiles > 0 ? tiles : 1.0);
+        }
+    }
+#endif
     return DFM_OK;
 }
 
@@ -766,7 +784,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     Workspace &W = cx->ws;
     hipStream_t s = cx->stream;
     const size_t N = cx->N, L = cx->L, K = cx->K;
-    cx->prof = dfm_profile{0, 0, 0, 0};
+    cx->prof = dfm_profile{};
     cx->ev_used = 0;
     cx->fwd_counter = 0;   // RNG streams are a pure function of (seed, trajectory, evaluation index)
     HIPCHK(hipMemcpyAsync(W.lig_cur, lig_pos, (size_t)B * L * 9 * sizeof(float), hipMemcpyHostToDevice, s));
@@ -853,7 +871,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     hipStream_t s = cx->stream;
     const dfm_hparams &hp = cx->m->hp;
     const size_t N = cx->N, L = cx->L, K = cx->K, S = num_steps;
-    cx->prof = dfm_profile{0, 0, 0, 0};
+    cx->prof = dfm_profile{};
     cx->ev_used = 0;
     cx->fwd_counter = 0;   // evaluation i of this call draws its graph from Philox stream i
 

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/dfmdock_amd.h"
 
 namespace dfm {
@@ -62,8 +64,8 @@ struct LayerDev {
     // positional_embed_dim 67: the same two biases with the homomer ("sym") channel's contribution We . P[:, 66] added to
     // the A half - a constant of every edge of a homomeric complex (dfm_complex_set_homomer); nullptr for 66 channels
     float *bias_ab_h, *bias_ab_h_s;
-    uint32_t *b2p, *b2p16;    // [256]  SILU_S * b2 as packed (hi, lo) bf16 / fp16 pairs (the bias k-step of the contraction)
-    uint32_t *bc1p, *bc1p16;  // [256]  SILU_S * bc1, same packing
+    uint32_t *b2p, *b2p16;    // [8][64] SILU_S * b2 as packed (hi, lo) bf16 / fp16 pairs per (n-tile, lane), 0 for lanes >= 32
+    uint32_t *bc1p, *bc1p16;  // [8][64] SILU_S * bc1, same packing
     float *wc2_s;     // [256]  wc2 / SILU_S
 };
 
@@ -84,6 +86,21 @@ struct PairHeadDev {
     uint16_t *wab_hi, *wab_lo;  // split-bf16 tiles of the same (16-bit engines)
     float *w_d, *ln_w, *ln_b, *w3;
 };
+
+constexpr int MAX_DEVICES = 64;
+// The opt-in to more than 64 KiB of dynamic LDS is a per-device function attribute: remember it per device (atomic flags:
+// two host threads may drive two GPUs)
+inline hipError_t ensure_lds_attr(const void *fn, int bytes, std::atomic<bool> (&done)[MAX_DEVICES])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[dev].store(true, std::memory_order_release);
+    return e;
+}
 
 // ---- kernel launchers (each returns the hipError of the launch) ---------------------------------
 struct GemmArgs {
@@ -141,6 +158,7 @@ struct EdgeArgs {
     float *fout;           // [B][L][3]   (last)
     uint16_t *mbuf;        // [B][L][64][256] 16-bit gated messages (MFMA path, last)
     int f16;               // MFMA operand type: 0 bf16, 1 fp16
+    unsigned long long *stamp;   // diagnostic builds (DFM_EDGE_STAMP): [8 waves][4 phases] cycle sums of workgroup 0, or nullptr
 };
 hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s);

@@ -47,9 +47,11 @@ struct EdgeKArgs {
     uint16_t *mbuf;
     // 16-bit MFMA kernels: everything upstream of a SiLU is pre-multiplied by -log2(e) on the host / in the producing GEMM
     // (see SILU_S), so SiLU is exp2 -> +1 -> rcp -> mul with no scaling multiply; biasp = the contraction's bias as packed
-    // (hi, lo) 16-bit pairs, added by one extra MFMA k-step instead of 128 accumulator moves
+    // (hi, lo) 16-bit pairs laid out per (n-tile, lane) [8][64] with zeros for lanes 32..63, added by one extra MFMA k-step
+    // instead of 128 accumulator moves
     const uint32_t *biasp;
     float inv_s;
+    unsigned long long *stamp;   // DFM_EDGE_STAMP builds only: per-phase cycle sums of workgroup 0 (tools/edge_phases.py)
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -201,6 +203,31 @@ union H8 { uint4 u; __half2 h[4]; };   // eight fp16 values of one gathered 16-b
 #ifndef DFM_EDGE_BD
 #define DFM_EDGE_BD 2
 #endif
+#ifndef DFM_EDGE_SB
+#define DFM_EDGE_SB 1      // a scheduling barrier after every DFM_EDGE_SB-th MFMA slot of a chunk
+#endif
+// Slots (MFMA index inside a chunk) after which the producer requests the next-but-one chunk's operands.  The vector-memory
+// counter completes in order, so a wait for the YOUNGEST load a slot needs also waits for everything issued before it:
+// the per-chunk constants (A_i, w_r: L1 hits, used from slot 0 of the next chunk) go out BEFORE the second pass's gathers (L2
+// hits, used from slot 8), and both gathers as early as their registers are dead (pass registers die after the pass's slice 0).
+#ifndef DFM_EDGE_G0
+#define DFM_EDGE_G0 7
+#endif
+#ifndef DFM_EDGE_G1
+#define DFM_EDGE_G1 15
+#endif
+#ifndef DFM_EDGE_GC
+#define DFM_EDGE_GC 14
+#endif
+// Waves w and w + 4 of a workgroup share a SIMD.  Started together they stay in lockstep - both in the latency-bound main loop,
+// then both in the VALU-dense epilogue; delaying the second one by about half a tile at launch puts one wave's epilogue beside
+// the other's main loop (units of 64 cycles per step of s_sleep 127 ~ 8k cycles; 0 = off)
+#ifndef DFM_EDGE_STAGGER
+#define DFM_EDGE_STAGGER 0
+#endif
+#ifndef DFM_EDGE_PERM
+#define DFM_EDGE_PERM 0    // 1: producer slices of a pass in the order (pre 0, pre 1, act 0, act 1, pre 2, pre 3, act 2, act 3)
+#endif
 constexpr int LDS_WF_BYTES = 16 * 8 * 64 * 16;     // 131072: bf16 B-fragments of one 256x256 matrix
 constexpr int LDS_STAGE_BYTES = 32 * 64 * 2;       // 4096 per wave: 32 rows x 64 channels bf16
 constexpr int EDGE_WAVES = 8;                      // waves per workgroup (two per SIMD, 256 registers each)
@@ -313,6 +340,10 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
     const int h = lane >> 5, l31 = lane & 31;
     for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
     __syncthreads();
+    if constexpr (MODE == 0 && DFM_EDGE_STAGGER > 0) {
+        if (wave >= EDGE_WAVES / 2)
+            for (int z = 0; z < DFM_EDGE_STAGGER; ++z) __builtin_amdgcn_s_sleep(127);
+    }
 
     // XCD-aware task order (speed only): workgroup g runs on XCD g % 8; give every XCD whole
     // trajectories so that the gathered rows of Bm stay in that XCD's L2.
@@ -347,17 +378,29 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
     bool pref = false;
     int jqn[2] = {0, 0}; uint32_t codeqn[2] = {0u, 0u}; float radqn[2] = {0.f, 0.f};
     const int r16 = lane >> 2, c4 = lane & 3;
-    auto load_idx = [&](size_t ebase, int i, int mt, int (&jq)[2], uint32_t (&codeq)[2], float (&radq)[2]) {
+    const __amdgpu_buffer_rsrc_t rs_e = make_rsrc(p.edges), rs_c = make_rsrc(p.codes), rs_r = make_rsrc(p.radial);
+    // raw loads only (rows past K read the node's last edge; they are masked where the values are used): nothing here
+    // depends on the loaded data, so the wave does not wait on them
+    auto load_idx = [&](uint32_t ebase, int mt, int (&jq)[2], uint32_t (&codeq)[2], float (&radq)[2]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int s = mt * 32 + q * 16 + r16;
-            const bool v = s < K;
-            jq[q] = v ? p.edges[ebase + s] : i;
-            codeq[q] = v ? p.codes[ebase + s] : 0u;
-            radq[q] = v ? p.radial[ebase + s] : 0.f;
+            const uint32_t off = (ebase + (uint32_t)(s < K ? s : K - 1)) * 4u;
+            jq[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_e, (int)off, 0, 0);
+            codeq[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)off, 0, 0);
+            radq[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)off, 0, 0));
         }
     };
-
+#ifdef DFM_EDGE_STAMP
+    // phase timing (diagnostic build): cycles of [prologue | chunks 0-6 | chunk 7 + bias | epilogue] summed over the tiles of a wave
+    unsigned long long st_t[5] = {0, 0, 0, 0, 0}, st_prev = 0;
+#define STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _n = __builtin_amdgcn_s_memtime(); st_t[k] += _n - st_prev; st_prev = _n; __builtin_amdgcn_sched_barrier(0); }
+#define STAMP0() { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    unsigned long long st_slot[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_sprev = 0;
+#else
+#define STAMP(k)
+#define STAMP0()
+#endif
     for (unsigned tt = (unsigned)slot * EDGE_WAVES + wave; tt < ntask; tt += tstride) {
         int b, i;
         if (!task_node(tt, b, i)) continue;
@@ -370,9 +413,10 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
         float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // MODE 1: sum_s cdiff * w
 
         for (int mt = 0; mt < ntile; ++mt) {
+            STAMP0();
             f32x16 acc[8];
             float dv[8];        // dot vector of the epilogue, fetched under the last MFMA phase
-            uint32_t bp[8];     // packed (hi, lo) bias of this lane's column per n-tile (lanes 32..63: 0)
+            uint32_t bp[8];     // packed (hi, lo) bias of this lane's column per n-tile (biasp is [8][64]: lanes 32..63 hold 0)
 
             if constexpr (MODE == 0) {
                 // ---- interleaved form: a chunk is 32 channels (two MFMA k-steps, 16 MFMAs).  Producer layout: four
@@ -381,11 +425,11 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 // for the producer's writes and the MFMA A-fragment reads); while the MFMAs of chunk c read buffer c & 1,
                 // the arithmetic of chunk c + 1 fills the other one and the gathers of chunk c + 2 are issued.
                 int jq[2]; uint32_t codeq[2]; float radq[2];
-                if (pref) {
+                if (!pref) load_idx((uint32_t)ebase, mt, jqn, codeqn, radqn);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) { jq[q] = jqn[q]; codeq[q] = codeqn[q]; radq[q] = radqn[q]; }
-                } else {
-                    load_idx(ebase, i, mt, jq, codeq, radq);
+                for (int q = 0; q < 2; ++q) {     // masked rows (>= K): self edge, zero features -> finite values, gate forced to 0
+                    const bool v = mt * 32 + q * 16 + r16 < K;
+                    jq[q] = v ? jqn[q] : i; codeq[q] = v ? codeqn[q] : 0u; radq[q] = v ? radqn[q] : 0.f;
                 }
                 // per-lane byte offsets of the four gathered rows of each pass (one VGPR each); the channel chunk goes in
                 // the scalar offset of the buffer load
@@ -455,6 +499,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 compute_store(0, r0, stage); gather(1, 0, r0);
                 compute_store(1, r1, stage); gather(1, 1, r1);
                 gather_chunk(1);
+                STAMP(0);
                 // one chunk: 16 MFMAs of chunk c; PRODUCE: the arithmetic of chunk c + 1, one slice after every MFMA in
                 // program order with a scheduling barrier behind it; GATHER: the loads of chunk c + 2; FIRST: the chunk that
                 // opens the accumulators (C operand = 0, no accumulator initialisation on the VALU)
@@ -474,6 +519,15 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     for (int d = 0; d < BD - 1; ++d) bq[d].u = wq[d * 64];
 #pragma unroll
                     for (int m = 0; m < 16; ++m) {
+#ifdef DFM_EDGE_STAMP
+                        if (c == 3) {    // per-slot timing of one mid-tile chunk
+                            __builtin_amdgcn_sched_barrier(0);
+                            const unsigned long long _n = __builtin_amdgcn_s_memtime();
+                            if (m > 0) st_slot[m] += _n - st_sprev;
+                            st_sprev = _n;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#endif
                         if (m + BD - 1 < 16) bq[(m + BD - 1) % BD].u = wq[(m + BD - 1) * 64];
                         if constexpr (decltype(first)::value) {
                             if (m < 8) acc[m] = mfma16<F16>(af[0], bq[m % BD], zero16);
@@ -482,33 +536,38 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                             acc[m & 7] = mfma16<F16>(af[m >> 3], bq[m % BD], acc[m & 7]);
                         }
                         if constexpr (decltype(produce)::value) {
-                            if (m < 8) slice(0, m, r0, bufn); else slice(1, m - 8, r1, bufn);
+                            constexpr int perm[8] = {0, 2, 1, 3, 4, 6, 5, 7};
+                            const int ks = DFM_EDGE_PERM ? perm[m & 7] : (m & 7);
+                            if (m < 8) slice(0, ks, r0, bufn); else slice(1, ks, r1, bufn);
                             if constexpr (decltype(gather_next)::value) {
-                                if (m == 7) gather(c + 2, 0, r0);
-                                if (m == 15) { gather(c + 2, 1, r1); gather_chunk(c + 2); }
+                                if (m == DFM_EDGE_G0) gather(c + 2, 0, r0);
+                                if (m == DFM_EDGE_GC) gather_chunk(c + 2);
+                                if (m == DFM_EDGE_G1) gather(c + 2, 1, r1);
                             }
                         } else {
                             if (m < 8) {
                                 dv[m] = dot_v[m * 32 + l31];
-                                const uint32_t bw = p.biasp[m * 32 + l31];
-                                bp[m] = h == 0 ? bw : 0u;
+                                bp[m] = p.biasp[m * 64 + lane];     // plain loads: nothing waits on them before the bias k-step
                             }
                         }
-                        __builtin_amdgcn_sched_barrier(0);
+                        if ((m + 1) % DFM_EDGE_SB == 0) __builtin_amdgcn_sched_barrier(0);
                     }
                 };
                 chunk(0, std::true_type{}, std::true_type{}, std::true_type{});
 #pragma unroll 1
                 for (int c = 1; c < 6; ++c) chunk(c, std::true_type{}, std::true_type{}, std::false_type{});
-                chunk(6, std::true_type{}, std::false_type{}, std::false_type{});
-                // indices of the tile this wave works on next: the second tile of this node, or the first tile of its next task
+                // indices of the tile this wave works on next (the second tile of this node, or the first tile of its next task),
+                // requested two chunks before anything younger is waited for: by the time the epilogue constants below are
+                // needed (the vector-memory counter is in order) they have landed
                 {
                     int nb2 = b, ni = i, nmt = mt + 1;
                     bool nvalid = true;
                     if (nmt == ntile) { nmt = 0; nvalid = tt + tstride < ntask && task_node(tt + tstride, nb2, ni); }
                     pref = nvalid;
-                    if (nvalid) load_idx(((size_t)nb2 * p.N + ni) * K, ni, nmt, jqn, codeqn, radqn);
+                    if (nvalid) load_idx(((uint32_t)nb2 * (uint32_t)p.N + (uint32_t)ni) * (uint32_t)K, nmt, jqn, codeqn, radqn);
                 }
+                chunk(6, std::true_type{}, std::false_type{}, std::false_type{});
+                STAMP(1);
                 chunk(7, std::false_type{}, std::false_type{}, std::false_type{});
             } else {
                 // the stored messages of this tile are already in A-fragment order (see the store below): one contiguous
@@ -539,8 +598,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 #pragma unroll
                 for (int nt = 0; nt < 8; ++nt) {
                     dv[nt] = dot_v[nt * 32 + l31];
-                    const uint32_t bw = p.biasp[nt * 32 + l31];
-                    bp[nt] = h == 0 ? bw : 0u;
+                    bp[nt] = p.biasp[nt * 64 + lane];
                 }
             }
             // bias k-step: acc += 1 * hi + 1 * lo (the accumulators were opened with C = 0)
@@ -550,6 +608,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 bb.u = make_uint4(bp[nt], 0u, 0u, 0u);
                 acc[nt] = mfma16<F16>(onef, bb, acc[nt]);
             }
+            STAMP(2);
 
             // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) -------------
             float part[16];
@@ -590,7 +649,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int rowin = (r & 3) + 8 * (r >> 2) + 4 * h;
-                            Mout[cbase + rowin * 8] = to16<F16>(acc[nt][r] * part[r]);
+                            Mout[cbase + rowin * 8] = to16<1>(acc[nt][r] * part[r]);     // always fp16: see launch_coord_bf16
                         }
                     }
                 }
@@ -619,6 +678,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                     cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;
                 }
             }
+            STAMP(3);
         }   // mt
 
         if (MODE == 0) {
@@ -639,6 +699,14 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
             }
         }
     }
+#ifdef DFM_EDGE_STAMP
+    if (p.stamp && blockIdx.x == 0 && lane == 0) {
+        for (int k = 0; k < 4; ++k) p.stamp[wave * 4 + k] = st_t[k];
+        if (wave == 0) for (int k = 0; k < 16; ++k) p.stamp[32 + k] = st_slot[k];
+    }
+#endif
+#undef STAMP
+#undef STAMP0
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -653,7 +721,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.w_r = w->w_r; k.T = w->T; k.W2t = w->W2t; k.b2 = w->b2; k.att_w = w->att_w; k.T2b = w->T2b;
     k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
-    k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf;
+    k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.stamp = a.stamp;
     return k;
 }
 // the 16-bit MFMA kernels take the -log2(e)-scaled operands (SILU_S, api.hip)
@@ -669,13 +737,11 @@ static EdgeKArgs to_kargs_mfma(const EdgeArgs &a, int mode)
 
 hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s)
 {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_done[MAX_DEVICES];
     const int lds = KF * H * 4 + 4 * 64 * 4;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_f32),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    {
+        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_f32), lds, attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const EdgeKArgs k = to_kargs(a);
     hipLaunchKernelGGL(k_edge_f32, dim3((unsigned)((long long)a.B * a.N)), dim3(256), lds, s, k);
@@ -695,12 +761,10 @@ static int persistent_grid(long long wave_tasks)
 
 template <int MODE, int F16> static hipError_t launch_mfma_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_bf16<MODE, F16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_EDGE_BYTES);
+    static std::atomic<bool> attr_done[MAX_DEVICES];
+    {
+        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_bf16<MODE, F16>), LDS_EDGE_BYTES, attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((k_edge_bf16<MODE, F16>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
     return hipGetLastError();
@@ -713,11 +777,16 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
     return a.f16 ? launch_mfma_t<0, 1>(k, tasks, s) : launch_mfma_t<0, 0>(k, tasks, s);
 }
 
+// The coordinate MLP runs on fp16 operands in BOTH 16-bit engines: it is 4 % of the time, its output IS the force f, and the
+// gated messages it reads are O(1) (no range problem) - three more mantissa bits where they count at no cost.  The bf16
+// engine therefore stores its last layer's messages as fp16 too.
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    const EdgeKArgs k = to_kargs_mfma(a, 1);
+    EdgeArgs a16 = a;
+    a16.f16 = 1;
+    const EdgeKArgs k = to_kargs_mfma(a16, 1);
     const long long tasks = (long long)a.B * (a.N - a.R);
-    return a.f16 ? launch_mfma_t<1, 1>(k, tasks, s) : launch_mfma_t<1, 0>(k, tasks, s);
+    return launch_mfma_t<1, 1>(k, tasks, s);
 }
 
 }  // namespace dfm

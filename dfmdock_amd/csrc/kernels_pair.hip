@@ -151,12 +151,11 @@ __global__ __launch_bounds__(256) void k_pair_finish(const float *__restrict__ f
 
 hipError_t launch_pair_head(const PairArgs &a, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_head<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pair_head<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_BYTES);
+    static std::atomic<bool> done0[MAX_DEVICES], done1[MAX_DEVICES];
+    {
+        hipError_t e = a.exact ? ensure_lds_attr(reinterpret_cast<const void *>(k_pair_head<1>), PAIR_LDS_BYTES, done1)
+                               : ensure_lds_attr(reinterpret_cast<const void *>(k_pair_head<0>), PAIR_LDS_BYTES, done0);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     PairKArgs k;
     k.P = a.P; k.Q = a.Q; k.ca4 = a.ca4; k.R = a.R; k.L = a.L; k.w_d = a.w_d; k.ln_w = a.ln_w; k.ln_b = a.ln_b; k.w3 = a.w3;

@@ -95,7 +95,22 @@ class Complex:
             pass
 
     # ------------------------------------------------------------------
-    def score(self, lig_pos, t, edges=None, seed=0, bf16=False, energy=True, debug=False, profile=False, f16=False):
+    def set_pose(self, rec_pos=None, lig_pos=None):
+        """Replace the resident receptor pose and / or the ligand start pose of `sample` (features stay resident)."""
+        rp = None if rec_pos is None else _f32(rec_pos).reshape(-1, 9)
+        lp = None if lig_pos is None else _f32(lig_pos).reshape(-1, 9)
+        if (rp is not None and rp.shape[0] != self.R) or (lp is not None and lp.shape[0] != self.L):
+            raise ValueError("set_pose: positions must keep the residue counts of the complex")
+        L.check(L.lib().dfm_complex_set_pose(self._h, _p(rp), _p(lp)), "dfm_complex_set_pose")
+        if lp is not None:
+            self.lig_pos0 = lp.reshape(self.L, 3, 3).copy()
+
+    def set_homomer(self, flag: bool):
+        """Value of the 67th ("sym") position channel (positional_embed_dim = 67 models only)."""
+        L.check(L.lib().dfm_complex_set_homomer(self._h, int(bool(flag))), "dfm_complex_set_homomer")
+
+    def score(self, lig_pos, t, edges=None, seed=0, bf16=False, energy=True, debug=False, profile=False, f16=False,
+              ires=False, return_edges=False):
         """B score evaluations.  lig_pos [B,L,3,3] (or [L,3,3]), t [B] (or scalar)."""
         lig_pos = _f32(lig_pos)
         if lig_pos.ndim == 3:
@@ -110,6 +125,12 @@ class Complex:
         out.tr_score, out.rot_score = _p(o["tr_score"]), _p(o["rot_score"])
         out.energy, out.num_clashes, out.f = _p(o["energy"]), _p(o["num_clashes"], L.I32P), _p(o["f"])
         out.confidence = _p(o["confidence"])
+        if ires:
+            o["ires"] = np.zeros((B, N), np.float32)
+            out.ires = _p(o["ires"])
+        if return_edges and not debug:      # the graph each evaluation used, without the [B,N,H] debug taps
+            o["edges"] = np.zeros((B, N, K), np.int32)
+            out.edges = _p(o["edges"], L.I32P)
         if debug:
             o.update(h_last=np.zeros((B, N, H), np.float32), h_first=np.zeros((B, N, H), np.float32),
                      edges=np.zeros((B, N, K), np.int32), edge_codes=np.zeros((B, N, K), np.uint32))
@@ -123,7 +144,7 @@ class Complex:
             if e.shape != (B, N, K):
                 raise ValueError(f"edges must be [B,N,K] = {(B, N, K)}, got {e.shape}")
         flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_ENERGY if energy else 0) | (L.DFM_F_PROFILE if profile else 0) | \
-                (L.DFM_F_F16 if f16 else 0)
+                (L.DFM_F_F16 if f16 else 0) | (L.DFM_F_IRES if ires else 0)
         rc = L.lib().dfm_score(self._h, B, _p(lig_pos), _p(t), _p(e, L.I32P), int(seed), flags, C.byref(out))
         L.check(rc, "dfm_score")
         if debug:
@@ -172,4 +193,4 @@ class Complex:
         p = L.ProfileC()
         L.check(L.lib().dfm_get_profile(self._h, C.byref(p)), "dfm_get_profile")
         return dict(edge_kernel_ms=p.edge_kernel_ms, edge_kernel_launches=p.edge_kernel_launches,
-                    edge_rows=p.edge_rows, total_ms=p.total_ms)
+                    edge_rows=p.edge_rows, total_ms=p.total_ms, phase_cycles=list(p.phase_cycles), slot_cycles=list(p.slot_cycles))

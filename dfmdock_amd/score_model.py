@@ -29,6 +29,15 @@ def _np(x):
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+def _digest(a: np.ndarray) -> bytes:
+    return hashlib.blake2b(memoryview(np.ascontiguousarray(a)).cast("B"), digest_size=16).digest()
+
+
+def _version(x):
+    """Mutation counter of a torch tensor (None for anything else: its content is then hashed on every call)."""
+    return getattr(x, "_version", None) if hasattr(x, "detach") else None
+
+
 class R3Diffuser:
     """VE-SDE on R^3 (src/utils/r3_diffuser.py)."""
 
@@ -83,8 +92,8 @@ class Score_Model:
 
     batch: {rec_x [R,1301], lig_x [L,1301], rec_pos [R,3,3], lig_pos [L,3,3], t [1]} (position_matrix is
     accepted and ignored: relpos is derived from (R, L) on the GPU).  Output keys / shapes follow
-    score_net_mlsb.py:413-425: tr_score [1,3], rot_score [1,3], energy [], f [L,3], num_clashes [] (int64).
-    `ires` (unused by the sampler) is not evaluated.
+    score_net_mlsb.py:413-425: tr_score [1,3], rot_score [1,3], energy [], f [L,3], num_clashes [] (int64),
+    ires [N,1].
     """
 
     def __init__(self, weights, hp: HParams | None = None, precision: str = "bf16", device_index: int = 0, seed: int = 0):
@@ -97,6 +106,9 @@ class Score_Model:
         self.so3_diffuser = SO3Diffuser(self.hp)
         self._cx = None
         self._cx_key = None
+        self._pose_key = None
+        self._feat_refs = None
+        self._homomer = False
         self._calls = 0
         self.seed = seed
 
@@ -115,26 +127,57 @@ class Score_Model:
 
     # ----------------------------------------------------------------------------------------------
     def complex_for(self, batch) -> engine.Complex:
-        rec_x, lig_x, rec_pos = batch["rec_x"], batch["lig_x"], _np(batch["rec_pos"])
-        key = (tuple(rec_x.shape), tuple(lig_x.shape), id(rec_x), id(lig_x), hashlib.sha1(rec_pos.tobytes()).hexdigest())
-        if key != self._cx_key:
-            if self._cx is not None:
-                self._cx.close()
-            self._cx = engine.Complex(self.model, _np(rec_x), _np(lig_x), rec_pos, _np(batch["lig_pos"]))
-            self._cx_key = key
+        """The device-resident complex of `batch`.  The expensive part (feature upload + node embedding) is keyed on the
+        CONTENT of rec_x / lig_x; the poses are compared on every call and, when they changed (a second ligand
+        conformation, a re-centred receptor - DFMDock.move_to_lig_center), pushed with dfm_complex_set_pose, so that
+        sampler calls always start from batch['lig_pos'] (inference_base.py:408-412)."""
+        rec_x, lig_x = batch["rec_x"], batch["lig_x"]
+        same_obj = (self._feat_refs is not None and rec_x is self._feat_refs[0] and lig_x is self._feat_refs[1]
+                    and _version(rec_x) is not None and (_version(rec_x), _version(lig_x)) == self._feat_refs[2])
+        rec_pos, lig_pos = _np(batch["rec_pos"]), _np(batch["lig_pos"])
+        if not same_obj:
+            rx, lx = _np(rec_x), _np(lig_x)
+            key = (rx.shape, lx.shape, _digest(rx), _digest(lx))
+            if key != self._cx_key:
+                if self._cx is not None:
+                    self._cx.close()
+                self._cx = engine.Complex(self.model, rx, lx, rec_pos, lig_pos)
+                self._cx_key = key
+                self._pose_key = (_digest(rec_pos), _digest(lig_pos))
+                self._homomer = False
+            # holding the objects keeps their ids from being reused; _version catches in-place edits of torch tensors
+            self._feat_refs = (rec_x, lig_x, (_version(rec_x), _version(lig_x)))
+        pose_key = (_digest(rec_pos), _digest(lig_pos))
+        if pose_key != self._pose_key:
+            self._cx.set_pose(rec_pos if pose_key[0] != self._pose_key[0] else None,
+                              lig_pos if pose_key[1] != self._pose_key[1] else None)
+            self._pose_key = pose_key
+        if self.hp.positional_embed_dim == 67:
+            hom = bool(batch.get("is_homomer", False))
+            if hom != self._homomer:
+                self._cx.set_homomer(hom)
+                self._homomer = hom
         return self._cx
 
-    def forward(self, batch):
+    _ires_key = "ires"              # score_net_mlsb.py:413-425
+
+    def _score_dict(self, batch):
         import torch
         cx = self.complex_for(batch)
         t = _np(batch["t"]).reshape(-1)
         if t.size != 1:
             raise ValueError("batch['t'] must hold one time value (the reference runs batch_size=1)")
         self._calls += 1
-        r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, bf16=self.precision == "bf16", f16=self.precision == "f16", energy=True)
-        return {"tr_score": torch.from_numpy(r["tr_score"]), "rot_score": torch.from_numpy(r["rot_score"]),
-                "energy": torch.tensor(float(r["energy"][0]), dtype=torch.float32), "f": torch.from_numpy(r["f"][0]),
-                "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64)}
+        r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, bf16=self.precision == "bf16",
+                     f16=self.precision == "f16", energy=True, ires=True)
+        out = {"tr_score": torch.from_numpy(r["tr_score"]), "rot_score": torch.from_numpy(r["rot_score"]),
+               "energy": torch.tensor(float(r["energy"][0]), dtype=torch.float32), "f": torch.from_numpy(r["f"][0]),
+               "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64),
+               self._ires_key: torch.from_numpy(r["ires"][0].reshape(-1, 1).copy())}
+        return out, r
+
+    def forward(self, batch):
+        return self._score_dict(batch)[0]
 
     __call__ = forward
 
@@ -144,8 +187,10 @@ class DFMDock(Score_Model):
     ``move_to_lig_center`` + ``EGNN_Net(batch, predict=True)`` (DFMDock.py:68-75, egnn_net.py:408-505).
 
     Output keys follow egnn_net.py:486-495: tr_score [1,3], rot_score [1,3], energy [], f [L,3], num_clashes [],
-    confidence_logits [].  ``dist_logits`` [R,L,64] and ``ires_logits`` feed training losses only
-    (DFMDock.py:196-215) and are not evaluated.  The diffusers and the Euler-Maruyama sampler are shared with
+    confidence_logits [], ires_logits [N,1].  ``dist_logits`` [R,L,64] feeds a training loss only (DFMDock.py:196-215) and
+    is not evaluated.  With a 67-channel checkpoint (configs/model/DFMDock.yaml:5) ``batch['is_homomer']`` selects the
+    value of the sym channel (default False).  The sampler of this family rotates about the all-backbone-atom centroids
+    (src/inference.py:220-254); the engine does the same for ``family=1`` models.  The diffusers and the Euler-Maruyama sampler are shared with
     Score_Model, so ``Euler_Maruyama_sampler(model, batch)`` / ``sample_trajectories`` accept this class too.
     """
 
@@ -155,19 +200,13 @@ class DFMDock(Score_Model):
             raise ValueError("DFMDock needs HParams(family=1)")
         super().__init__(weights, hp=hp, precision=precision, device_index=device_index, seed=seed)
 
+    _ires_key = "ires_logits"       # egnn_net.py:486-495
+
     def forward(self, batch):
         import torch
-        cx = self.complex_for(batch)
-        t = _np(batch["t"]).reshape(-1)
-        if t.size != 1:
-            raise ValueError("batch['t'] must hold one time value (the reference runs batch_size=1)")
-        self._calls += 1
-        r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, bf16=self.precision == "bf16",
-                     f16=self.precision == "f16", energy=True)
-        return {"tr_score": torch.from_numpy(r["tr_score"]), "rot_score": torch.from_numpy(r["rot_score"]),
-                "energy": torch.tensor(float(r["energy"][0]), dtype=torch.float32), "f": torch.from_numpy(r["f"][0]),
-                "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64),
-                "confidence_logits": torch.tensor(float(r["confidence"][0]), dtype=torch.float32)}
+        out, r = self._score_dict(batch)
+        out["confidence_logits"] = torch.tensor(float(r["confidence"][0]), dtype=torch.float32)
+        return out
 
     __call__ = forward
 

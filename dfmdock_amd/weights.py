@@ -195,7 +195,7 @@ def unpack_blob(blob: np.ndarray, hp: HParams = HParams()):
 # Lightning checkpoint reader (reference: Score_Model.load_from_checkpoint, src/inference_base.py:611-614).
 # A Lightning ckpt is a torch-pickled dict with `state_dict` (keys `net.<name>`) and `hyper_parameters`
 # holding omegaconf DictConfig objects.  Neither pytorch_lightning nor omegaconf is needed to read it:
-# unknown classes are unpickled into attribute bags.
+# only an explicit allow-list of globals is resolved, every other class is unpickled into an inert attribute bag.
 class _Bag:
     def __init__(self, *a, **k):
         self._args, self._kwargs = a, k
@@ -210,16 +210,35 @@ class _Bag:
         return self
 
 
+# Globals a Lightning / torch checkpoint legitimately needs: tensor rebuild helpers, storages, plain containers.  Anything
+# else named by the pickle stream (omegaconf, pytorch_lightning, arbitrary builtins such as getattr / eval / __import__ ...)
+# is NOT resolved: it becomes an inert attribute bag (_Bag), so a crafted file cannot reach code through this reader.
+_ALLOWED_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch.nn.parameter", "Parameter"), ("torch", "Tensor"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
+    ("torch.serialization", "_get_layout"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("_codecs", "encode"),
+}
+_ALLOWED_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "complex", "bool", "str", "bytes",
+                     "bytearray", "slice", "range"}
+_TORCH_DTYPES = {"float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool"}
+
+
 def _stub_pickle_module():
     import pickle
     import types
 
     class Unpickler(pickle.Unpickler):
         def find_class(self, module, name):
-            root = module.split(".")[0]
-            if root in ("torch", "numpy", "collections", "builtins", "_codecs", "copyreg"):
+            if (module, name) in _ALLOWED_GLOBALS or (module == "builtins" and name in _ALLOWED_BUILTINS):
                 return super().find_class(module, name)
-            return type(name, (_Bag,), {"__module__": module})
+            if module == "torch" and (name.endswith("Storage") or name in _TORCH_DTYPES):
+                return super().find_class(module, name)
+            return type(name, (_Bag,), {"__module__": module})      # inert: stores its arguments / state, runs nothing
 
     mod = types.ModuleType("dfm_stub_pickle")
     mod.Unpickler = Unpickler
@@ -256,19 +275,35 @@ def load_lightning_checkpoint(path):
         if hasattr(v, "detach"):
             out[k] = v.detach().cpu().float().numpy()
     hp = HParams()
-    hyper = ck.get("hyper_parameters") if isinstance(ck, dict) else None
+    kw = {}
+    # model family from the state_dict itself (a bare state_dict carries no hyper_parameters)
+    if "to_force.0.weight" in out:      # EGNN_Net checkpoint (DFMDock.yaml: mask 20 A, agg)
+        kw["family"] = 1
+        kw["mask_dist"] = 20.0
+    if "positional_embed.weight" in out:
+        pd = int(out["positional_embed.weight"].shape[1])
+        if pd not in (66, 67):
+            raise ValueError(f"positional_embed_dim = {pd}: this engine supports 66 (relpos) and 67 (relpos + sym)")
+        kw["positional_embed_dim"] = pd
+    hyper = ck.get("hyper_parameters") if isinstance(ck, dict) and "state_dict" in ck else None
     model_cfg = _cfg_get(hyper, "model")
     if model_cfg is not None:
-        kw = {}
-        for f in ("lm_embed_dim", "positional_embed_dim", "spatial_embed_dim", "node_dim", "edge_dim", "inner_dim", "depth",
-                  "cut_off"):
+        for f in ("lm_embed_dim", "spatial_embed_dim", "node_dim", "edge_dim", "inner_dim", "depth", "cut_off"):
             v = _cfg_get(model_cfg, f)
-            if isinstance(v, (int, float)):
+            if isinstance(v, (int, float)) and not isinstance(v, bool):
                 kw[f] = type(getattr(hp, f))(v)
-        if "to_force.0.weight" in out:      # EGNN_Net checkpoint (DFMDock.yaml: mask 20 A, agg)
-            kw["family"] = 1
-            kw["mask_dist"] = 20.0
-            agg = _cfg_get(model_cfg, "agg")
-            kw["agg_mean"] = (agg != "sum")
-        hp = HParams(**{**hp.as_dict(), **kw})
+        v = _cfg_get(model_cfg, "positional_embed_dim")
+        if isinstance(v, int) and "positional_embed_dim" in kw and v != kw["positional_embed_dim"]:
+            raise ValueError(f"hyper_parameters say positional_embed_dim = {v}, the weights have {kw['positional_embed_dim']}")
+        if kw.get("family") == 1:
+            kw["agg_mean"] = (_cfg_get(model_cfg, "agg") != "sum")
+    # diffusion schedules the reference reads from the checkpoint's config (score_model_mlsb.py:36-37, DFMDock.py:45-46)
+    diff_cfg = _cfg_get(hyper, "diffuser")
+    for sub, prefix in (("r3", "r3_"), ("so3", "so3_")):
+        node = _cfg_get(diff_cfg, sub)
+        for f in ("min_sigma", "max_sigma"):
+            v = _cfg_get(node, f)
+            if isinstance(v, (int, float)) and not isinstance(v, bool):
+                kw[prefix + f] = float(v)
+    hp = HParams(**{**hp.as_dict(), **kw})
     return out, hp

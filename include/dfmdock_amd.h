@@ -131,6 +131,10 @@ typedef struct {
     int64_t edge_kernel_launches;
     int64_t edge_rows;        /* edge rows (B*N*K) processed by those launches           */
     double total_ms;          /* HIP-event time of the whole last dfm_sample / dfm_score  */
+    double phase_cycles[4];   /* diagnostic builds only (-DDFM_EDGE_STAMP), else 0: shader cycles per 32-row tile of the
+                                 message kernel's third launch, mean over the 8 waves of workgroup 0:
+                                 prologue | chunks 0-6 | chunk 7 + bias | epilogue                */
+    double slot_cycles[16];   /* diagnostic builds only: summed cycles between consecutive MFMA slots of chunk 3 (wave 0) */
 } dfm_profile;
 
 const char *dfm_last_error(void);

@@ -93,6 +93,15 @@ int64_t ora_param_count(const ora_hparams *hp)
     return w.total;
 }
 
+void ora_set_num_threads(int n)
+{   /* bench.py's cpu_baseline: the all-cores and the 8-thread figures from one process */
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int ora_num_threads(void)
 {
 #ifdef _OPENMP

@@ -68,6 +68,7 @@ typedef struct {
 
 int64_t ora_param_count(const ora_hparams *hp);
 int ora_num_threads(void);
+void ora_set_num_threads(int n);
 
 /* a-3 / a-4: r3_diffuser.py:20-24, so3_diffuser.py:210-227 (float64, as numpy) */
 double ora_r3_sigma(const ora_hparams *hp, double t);

@@ -78,6 +78,10 @@ def lib():
         L.ora_sample.argtypes = [C.POINTER(OraHParams), F32P, C.c_int, C.c_int, F32P, F32P, F32P, F32P,
                                  C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_uint64, C.POINTER(OraInject), C.POINTER(OraTrajOut)]
+        L.ora_modify_coords_all_atom.argtypes = [F32P, C.c_int, F32P, F32P]
+        L.ora_modify_coords_all_atom.restype = None
+        L.ora_set_num_threads.argtypes = [C.c_int]
+        L.ora_set_num_threads.restype = None
         L.ora_set_homomer.argtypes = [C.c_int]
         L.ora_set_homomer.restype = None
         _lib = L
@@ -202,6 +206,13 @@ def rot_compose(r1, r2):
 def modify_coords(x, rot, tr):
     x = _f32(x).copy()
     lib().ora_modify_coords(_p(x), x.shape[0], _p(_f32(rot).reshape(3)), _p(_f32(tr).reshape(3)))
+    return x
+
+
+def modify_coords_all_atom(x, rot, tr):
+    """Second family (src/inference.py:244-254): rotation about the all-backbone-atom centroid."""
+    x = _f32(x).copy()
+    lib().ora_modify_coords_all_atom(_p(x), x.shape[0], _p(_f32(rot).reshape(3)), _p(_f32(tr).reshape(3)))
     return x
 
 

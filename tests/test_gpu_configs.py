@@ -1,0 +1,200 @@
+"""Every BASELINE.json configuration through the C ABI, at the benchmark dtype, against the CPU oracle and the goldens
+captured from the reference (tests/golden/make_golden_r02.py):
+
+  C2  DB5 pair 7CEI, 64 parallel trajectories, bf16 sampler         test_c2_*
+  C3  synthetic 300+300, batch 256, bf16 / fp32 score evaluations   test_c3_*
+  C4  the 24 DB5 test complexes x 40 trajectories on one GPU        test_c4_*   (8-GPU sharding: tests/test_gpu_multiproc.py)
+  C5  synthetic 1000+1000, batch 32                                 test_c5_*
+(C1 = the reference's own CPU case is what the goldens are.)
+
+Gates are SURVEY.md 8(d)'s: fp32 engine <= 1e-4 rel (L-inf / |.|-inf) on tr_score / rot_score / f and <= 1e-4 abs on energy;
+bf16 engine <= 1e-2 rel on scores / f and <= 3e-2 rel on energy; injected rollouts: CA-RMSD <= 0.05 A (fp32) / 0.5 A (bf16)
+over five steps.
+"""
+import csv
+
+import numpy as np
+import pytest
+
+from conftest import complex_for, db5_complex, db5_ids, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def rigid_poses(cx, rng, n, rot_deg=25.0, tr_sigma=5.0):
+    """n rigid perturbations of the native ligand pose about its CA centroid."""
+    from dfmdock_amd.pdbio import axis_angle_to_matrix
+    lig = cx["lig_pos"].astype(np.float64)
+    c = lig[:, 1].mean(0)
+    out = []
+    for _ in range(n):
+        ax = rng.standard_normal(3)
+        ax *= np.deg2rad(rot_deg * rng.uniform(0.1, 1.0)) / np.linalg.norm(ax)
+        out.append(((lig - c) @ axis_angle_to_matrix(ax).T + c + rng.standard_normal(3) * tr_sigma).astype(np.float32))
+    return np.stack(out)
+
+
+@pytest.fixture(scope="module")
+def model(blob):
+    from dfmdock_amd import engine
+    engine.set_device(0)
+    m = engine.Model(blob)
+    yield m
+    m.close()
+
+
+def check_vs(ref, r, b, tol, etol, name):
+    assert rel_inf(r["f"][b], ref["f"]) < tol, (name, "f")
+    assert rel_inf(r["tr_score"][b], np.asarray(ref["tr_score"]).reshape(3)) < tol, (name, "tr_score")
+    assert rel_inf(r["rot_score"][b], np.asarray(ref["rot_score"]).reshape(3)) < tol, (name, "rot_score")
+    e_ref = float(ref["energy"])
+    assert abs(float(r["energy"][b]) - e_ref) < etol * (max(abs(e_ref), 0.1) if etol > 1e-3 else 1.0), (name, "energy")
+    assert int(r["num_clashes"][b]) == int(ref["num_clashes"]), (name, "clashes")
+
+
+# ---- C3 ------------------------------------------------------------------------------------------------------------
+def test_c3_batch256_vs_oracle_and_reference(model, blob):
+    """The bench configuration itself: 300+300, B = 256, the engine's own graphs.  Four spread-out trajectories are replayed
+    through the oracle (same edge lists): bf16 engine at the bf16 gates, fp32 engine at 1e-4; plus the reference's own
+    evaluation of this complex (fwd_c3_300_300.npz)."""
+    from dfmdock_amd import engine
+    from oracle import oracle as ora
+    cx = complex_for("c3_300_300")
+    gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    B = 256
+    poses = rigid_poses(cx, np.random.default_rng(4), B)
+    ts = np.linspace(1.0, 0.001, B).astype(np.float32)
+    r16 = gx.score(poses, ts, seed=9, bf16=True, energy=True, return_edges=True)
+    assert np.isfinite(r16["f"]).all() and np.isfinite(r16["energy"]).all()
+    assert (r16["edges"][0] != r16["edges"][1]).any()
+    r32 = gx.score(poses, ts, edges=r16["edges"], energy=True)
+    rh = gx.score(poses, ts, edges=r16["edges"], energy=True, f16=True)
+    o = ora.Oracle(blob, cx)
+    for b in (0, 85, 170, 255):
+        ref = o.score(poses[b], float(ts[b]), edges=r16["edges"][b])
+        check_vs(ref, r32, b, 1e-4, 1e-4, f"fp32 b={b}")
+        check_vs(ref, r16, b, 1e-2, 3e-2, f"bf16 b={b}")
+        check_vs(ref, rh, b, 3e-3, 5e-3, f"f16 b={b}")
+    g = load_golden("fwd_c3_300_300.npz")
+    e = g["edges"].astype(np.int32)
+    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True), 0, 1e-4, 1e-4, "golden fp32")
+    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, bf16=True), 0, 1e-2, 3e-2, "golden bf16")
+    gx.close()
+
+
+# ---- C2 ------------------------------------------------------------------------------------------------------------
+def test_c2_7cei_batch64_bf16_sampler(model):
+    """64 parallel trajectories on the DB5 pair: with the reference run's draws tiled 64x every row equals the B = 1 row
+    bit for bit and stays within the bf16 rollout gate of the reference's poses; natively drawn trajectories differ."""
+    from dfmdock_amd import engine
+    g = load_golden("rollout_7CEI.npz")
+    cx = complex_for("7CEI")
+    gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    S, B = 6, 64
+    one = dict(R0=g["R0"].astype(np.float32).reshape(1, 9), tr_draw=g["tr_draw"].reshape(1, 3), z_rot=g["z_rot"][None],
+               z_tr=g["z_tr"][None], edges=g["edges"][None])
+    many = {k: np.ascontiguousarray(np.repeat(v, B, 0)) for k, v in one.items()}
+    r1 = gx.sample(B=1, num_steps=S, inject=one, trace=True, bf16=True)
+    rb = gx.sample(B=B, num_steps=S, inject=many, trace=True, bf16=True)
+    for k in ("lig_pos", "trace_pose", "trace_scores", "energy", "rot_update", "tr_update", "num_clashes"):
+        assert (rb[k] == r1[k][0]).all(), k
+    ca, ref = rb["trace_pose"][17][:, :, 1, :], g["poses"][:, :, 1, :]
+    rmsd = np.sqrt(((ca - ref) ** 2).sum(-1).mean(-1))
+    assert rmsd[:5].max() < 0.5 and rmsd.max() < 3.0, rmsd
+    nat = gx.sample(B=B, num_steps=40, seed=42, bf16=True)
+    assert np.isfinite(nat["lig_pos"]).all() and np.isfinite(nat["energy"]).all()
+    assert np.abs(nat["lig_pos"][0] - nat["lig_pos"][1]).max() > 1.0
+    again = gx.sample(B=B, num_steps=40, seed=42, bf16=True)
+    np.testing.assert_array_equal(nat["lig_pos"], again["lig_pos"])            # counter-based RNG: a pure function of the seed
+    half = gx.sample(B=B // 2, num_steps=40, seed=42, bf16=True)
+    np.testing.assert_array_equal(nat["lig_pos"][: B // 2], half["lig_pos"])   # ... and of the trajectory index, not of B
+    gx.close()
+
+
+# ---- C5 ------------------------------------------------------------------------------------------------------------
+def test_c5_large_complex(model, blob):
+    """1000+1000: reference evaluation (injected edges), the native N = 2000 graph build (kNN slots exact against the oracle,
+    sampled slots unique and disjoint), fp32 / bf16 engines against the oracle on the engine's own graph, and a finite 40-step
+    run at B = 32."""
+    from dfmdock_amd import engine
+    from oracle import oracle as ora
+    g = load_golden("fwd_c5_1000_1000.npz")
+    cx = complex_for("c5_1000_1000")
+    gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    e = g["edges"].astype(np.int32)
+    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True), 0, 1e-4, 1e-4, "golden fp32")
+    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, bf16=True), 0, 1e-2, 3e-2, "golden bf16")
+    poses = np.stack([g["lig_pos"], g["lig_pos"] + np.float32(2.0)])
+    r = gx.score(poses, np.array([0.4, 0.9], np.float32), seed=3, energy=True, return_edges=True)
+    for b in range(2):
+        center = poses[b][:, 1].mean(0)
+        ca = np.concatenate([cx["rec_pos"][:, 1] - center, poses[b][:, 1] - center]).astype(np.float32)
+        knn = ora.knn_sample(ca, seed=1)[:, :20]
+        np.testing.assert_array_equal(r["edges"][b][:, :20], knn)
+        srt = np.sort(r["edges"][b], axis=1)
+        assert (np.diff(srt, axis=1) > 0).all()                       # 60 distinct neighbours per node
+        assert r["edges"][b].min() >= 0 and r["edges"][b].max() < 2000
+    o = ora.Oracle(blob, cx)
+    ref = o.score(poses[1], 0.9, edges=r["edges"][1])
+    check_vs(ref, r, 1, 1e-4, 1e-4, "native graph fp32")
+    r16 = gx.score(poses, np.array([0.4, 0.9], np.float32), edges=r["edges"], energy=True, bf16=True)
+    check_vs(ref, r16, 1, 1e-2, 3e-2, "native graph bf16")
+    s = gx.sample(B=32, num_steps=40, seed=5, bf16=True)
+    assert np.isfinite(s["lig_pos"]).all() and np.isfinite(s["energy"]).all() and np.isfinite(s["tr_update"]).all()
+    gx.close()
+
+
+# ---- C4 on one GPU ---------------------------------------------------------------------------------------------------
+def test_c4_db5_set_one_gpu(model, blob, tmp_path):
+    """The full DB5 test set (24 complexes: backbones + sequences of the reference's data/db5_test, seeded node features),
+    40 trajectories x 40 steps each through driver.run_set; two complexes' per-trajectory energies are replayed through the
+    oracle with every draw injected."""
+    from dfmdock_amd import driver, engine
+    from oracle import oracle as ora
+    ids = db5_ids()
+    assert len(ids) == 24
+    cxs = [db5_complex(c) for c in ids]
+    out_csv = tmp_path / "db5.csv"
+    rows, ranked = driver.run_set(model, cxs, num_samples=40, num_steps=40, seed=1, out_csv=str(out_csv))
+    assert len(rows) == 24 * 40 and sorted(ranked) == list(range(24))
+    got = list(csv.DictReader(open(out_csv)))
+    assert len(got) == 960 and list(got[0].keys()) == driver.CSV_FIELDS
+    assert {r["id"] for r in got} == set(ids)
+    for r in got:
+        assert 0.0 <= float(r["DockQ"]) <= 1.0 and np.isfinite(float(r["energy"])) and float(r["l_rmsd"]) >= 0.0
+    for cid in ranked:
+        assert ranked[cid].shape == (40, 10) and (np.diff(ranked[cid][:, 2]) >= 0).all()
+    S, B = 3, 2
+    rng = np.random.default_rng(8)
+    for cid in ("1AVX", "4POU"):
+        cx = db5_complex(cid)
+        gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+        o = ora.Oracle(blob, cx)
+        N = gx.N
+        center = cx["lig_pos"][:, 1].mean(0)
+        ca = np.concatenate([cx["rec_pos"][:, 1] - center, cx["lig_pos"][:, 1] - center]).astype(np.float32)
+        edges = np.stack([np.stack([ora.knn_sample(ca, seed=100 * b + s) for s in range(S + 1)]) for b in range(B)]).astype(np.int32)
+        assert edges.shape == (B, S + 1, N, 60)
+        # near-native starts (identity rotation, draw that cancels the centroid offset up to a few A) keep the energy head live
+        c1, c2 = cx["rec_pos"][:, 1].mean(0), cx["lig_pos"][:, 1].mean(0)
+        inj = dict(R0=np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (B, 1)),
+                   tr_draw=(c2 - c1)[None].astype(np.float32) + rng.standard_normal((B, 3)).astype(np.float32),
+                   z_rot=rng.standard_normal((B, S, 3)).astype(np.float32), z_tr=rng.standard_normal((B, S, 3)).astype(np.float32),
+                   edges=edges)
+        r32 = gx.sample(B=B, num_steps=S, inject=inj, trace=True)
+        r16 = gx.sample(B=B, num_steps=S, inject=inj, trace=True, bf16=True)
+        for b in range(B):
+            ob = o.sample(num_steps=S, inject={k: (v[b].astype(np.float64) if k == "R0" else v[b]) for k, v in inj.items()}, trace=True)
+            rmsd = np.sqrt(((r32["trace_pose"][b][:, :, 1] - ob["trace_pose"][:, :, 1]) ** 2).sum(-1).mean(-1))
+            assert rmsd.max() < 0.05, (cid, b, rmsd)
+            assert abs(float(r32["energy"][b]) - float(ob["energy"])) < 1e-3 * max(1.0, abs(float(ob["energy"]))), (cid, b)
+            assert int(r32["num_clashes"][b]) == int(ob["num_clashes"])
+            rmsd16 = np.sqrt(((r16["trace_pose"][b][:, :, 1] - ob["trace_pose"][:, :, 1]) ** 2).sum(-1).mean(-1))
+            assert rmsd16.max() < 0.5, (cid, b, rmsd16)
+            assert abs(float(r16["energy"][b]) - float(ob["energy"])) < 3e-2 * max(abs(float(ob["energy"])), 0.1) + 0.05, (cid, b)
+        gx.close()

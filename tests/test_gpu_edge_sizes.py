@@ -35,10 +35,11 @@ def test_odd_sizes_fp32_vs_oracle(R, L, family, blob, blob_pair):
     for b in range(2):
         ref = o.score(poses[b], float(t[b]), edges=r["edges"][b])
         assert int(r["num_clashes"][b]) == ref["num_clashes"]
-        assert rel_inf(r["f"][b], ref["f"]) < 2e-4
-        assert rel_inf(r["tr_score"][b], ref["tr_score"].reshape(3)) < 2e-4
-        assert rel_inf(r["rot_score"][b], ref["rot_score"].reshape(3)) < 2e-4 or np.abs(ref["rot_score"]).max() < 1e-6
-        assert abs(float(r["energy"][b]) - float(ref["energy"])) < 2e-4 * max(1.0, abs(float(ref["energy"])))
+        # SURVEY 8(d) gate 1 (measured worst 6.3e-5, the 1+1 complex: tools/tol_report.py)
+        assert rel_inf(r["f"][b], ref["f"]) < 1e-4
+        assert rel_inf(r["tr_score"][b], ref["tr_score"].reshape(3)) < 1e-4
+        assert rel_inf(r["rot_score"][b], ref["rot_score"].reshape(3)) < 1e-4 or np.abs(ref["rot_score"]).max() < 1e-6
+        assert abs(float(r["energy"][b]) - float(ref["energy"])) < 1e-4
     # the 16-bit engine and the sampler run on these shapes too
     s = gx.sample(B=3, num_steps=3, seed=5, bf16=True)
     assert np.isfinite(s["lig_pos"]).all() and np.isfinite(s["energy"]).all()

@@ -1,0 +1,92 @@
+"""The multi-rank path with REAL engine processes: two ranks, one per process, both on GPU 0 of the test box,
+rendezvous over gloo (the 8-GPU node runs the same code over RCCL: backend "nccl" stays the default everywhere).
+
+  * bench.py --gpus 2 under torch.distributed.run: the weak-scaling step (per-rank dfm_sample + one record all_gather +
+    max-over-ranks timing) end to end;
+  * driver.run_set over 3 complexes on 2 ranks: complexes sharded longest-first, disjoint (complex, trajectory) ids, every rank
+    ends with the identical energy-ranked table, rank 0 writes the complete CSV.
+"""
+import csv
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    return 29900 + (os.getpid() % 300)
+
+
+def test_bench_two_ranks_one_gpu():
+    env = dict(os.environ, DFM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "8", "--num-steps", "6", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]            # rank 0 prints ONE json line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 2 and out["warmup"] == 1
+    assert out["value"] > 0 and np.isfinite(out["best_energy"]) and "cpu_baseline" not in out
+    assert out["config"]["trajectories_per_gpu"] == 8
+    assert abs(out["value"] - 2 * 8 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-6 * out["value"]   # whole-job aggregate over both ranks
+
+
+RUN_SET_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    import torch, torch.distributed as dist
+    from dfmdock_amd import distributed as D, driver, engine
+    from dfmdock_amd.synthetic import make_complex
+    from dfmdock_amd.weights import make_random_weights, pack_blob
+    rank, local, world = D.dist_env()
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    engine.set_device(0)                      # both ranks share the one GPU of the test box
+    model = engine.Model(pack_blob(make_random_weights(0)))
+    cxs = []
+    for k, (R, L) in enumerate([(30, 22), (70, 41), (41, 17)]):
+        c = make_complex(R, L, seed=20 + k)
+        c.update(id=f"SYN{{k}}", rec_seq="A" * R, lig_seq="G" * L)
+        cxs.append(c)
+    rows, ranked = driver.run_set(model, cxs, num_samples=5, num_steps=4, seed=3, out_csv=os.path.join({out!r}, "set.csv"), max_batch=3)
+    json.dump({{"rows": [[r["id"], r["index"], r["energy"]] for r in rows],
+               "ranked": {{str(k): v.tolist() for k, v in ranked.items()}}}}, open(os.path.join({out!r}, f"rank{{rank}}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_run_set_two_ranks_one_gpu(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(RUN_SET_WORKER.format(root=ROOT, out=str(tmp_path)))
+    port = _port() + 1
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    a, b = json.load(open(tmp_path / "rank0.json")), json.load(open(tmp_path / "rank1.json"))
+    ids_a, ids_b = {(r[0], r[1]) for r in a["rows"]}, {(r[0], r[1]) for r in b["rows"]}
+    assert ids_a and ids_b and not (ids_a & ids_b)                                  # every rank sampled something, nothing twice
+    assert ids_a | ids_b == {(f"SYN{k}", str(i)) for k in range(3) for i in range(5)}
+    assert {r[0] for r in a["rows"]}.isdisjoint({r[0] for r in b["rows"]})            # sharded by complex
+    assert a["ranked"] == b["ranked"] and sorted(a["ranked"]) == ["0", "1", "2"]    # identical ranked table everywhere
+    for k, tab in a["ranked"].items():
+        e = np.array(tab)[:, 2]
+        assert len(e) == 5 and (np.diff(e) >= 0).all()
+    got = list(csv.DictReader(open(tmp_path / "set.csv")))
+    assert len(got) == 15 and {(r["id"], r["index"]) for r in got} == ids_a | ids_b
+    by_key = {(r[0], r[1]): r[2] for r in a["rows"] + b["rows"]}
+    for r in got:
+        assert abs(float(r["energy"]) - by_key[(r["id"], r["index"])]) < 1e-6

@@ -2,7 +2,7 @@
 through the C ABI, against golden vectors captured from the reference (tests/golden/make_golden_pair.py) and the oracle.
 
 Gates: fp32 engine <= 1e-4 rel on tr_score / rot_score / f, <= 1e-4 (relative to max(1, |E|)) on energy and
-confidence (measured <= 2.4e-6); bf16-MFMA engine <= 2e-2 rel on f / scores, 3e-2 on h_last / energy (measured <= 8.7e-3);
+confidence (measured <= 2.4e-6); bf16-MFMA engine <= 1e-2 rel on f / scores, 3e-2 on h_last / energy (measured <= 9.4e-3);
 fp16-MFMA engine <= 3e-3, 5e-3 on energy (measured <= 9.5e-4).  tools/pair_bench.py prints the table.
 """
 import numpy as np
@@ -57,7 +57,7 @@ def test_pair_family_fp32_vs_reference_golden(case, blob_pair):
 
 
 # (h_last, f, tr_score, rot_score, energy | confidence)
-PAIR_TOL = {"bf16": (3e-2, 2e-2, 2e-2, 2e-2, 3e-2), "f16": (3e-3, 3e-3, 3e-3, 3e-3, 5e-3)}
+PAIR_TOL = {"bf16": (3e-2, 1e-2, 1e-2, 1e-2, 3e-2), "f16": (3e-3, 3e-3, 3e-3, 3e-3, 5e-3)}
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])

@@ -2,7 +2,7 @@
 golden vectors captured from the reference.  Run on the MI355X box with `pytest -m gpu`.
 
 Gates: fp32 path <= 1e-4 rel (L-inf / |.|-inf) on tr_score, rot_score, f and <= 1e-4
-abs on energy; bf16-MFMA path <= 1e-2 rel on tr_score / f, <= 2e-2 on rot_score, <= 3e-2 on energy; fp16-MFMA path <= 3e-3; injected EM update
+abs on energy; bf16-MFMA path <= 1e-2 rel on tr_score / rot_score / f, <= 3e-2 on energy; fp16-MFMA path <= 3e-3; injected EM update
 <= 1e-5 A per step; injected 5-step rollout CA RMSD <= 0.05 A (fp32) / 0.5 A (bf16).
 """
 import numpy as np
@@ -65,10 +65,10 @@ def test_score_fp32_vs_reference_golden(case, model, blob):
             assert abs(float(r["energy"][0]) - float(ref["energy"])) < 1e-4, name
 
 
-# 16-bit MFMA engines: (h_last, f, tr_score, rot_score, energy) gates.  bf16 gates are SURVEY 8(d)'s, except
-# rot_score: the torque mean_q(r_q x f_q) carries a ~15 A lever arm on cancelling terms, measured 4e-4 .. 1.2e-2
-# over the golden cases, so its stated tolerance is 2e-2.  fp16 operands (3 more mantissa bits) measure <= 1.4e-3.
-MFMA_TOL = {"bf16": (3e-2, 1e-2, 1e-2, 2e-2, 3e-2), "f16": (3e-3, 3e-3, 3e-3, 3e-3, 5e-3)}
+# 16-bit MFMA engines: (h_last, f, tr_score, rot_score, energy) gates.  bf16 gates are SURVEY 8(d)'s (1e-2 on f and both
+# scores, 3e-2 on energy); measured worst over the goldens (tools/tol_report.py): f 7.2e-3, tr 3.8e-3, rot 5.2e-3, E 7.9e-3.
+# fp16 operands (3 more mantissa bits) measure <= 2.7e-3.
+MFMA_TOL = {"bf16": (3e-2, 1e-2, 1e-2, 1e-2, 3e-2), "f16": (3e-3, 3e-3, 3e-3, 3e-3, 5e-3)}
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
@@ -117,7 +117,7 @@ def test_sampler_injected_rollout(case, steps, prec, model):
     assert rmsd.max() < (3.0 if bf16 else 0.5), rmsd.max()
     tol = {"fp32": 1e-4, "bf16": 1e-2, "f16": 3e-3}[prec]
     assert rel_inf(r["trace_scores"][0][0, 0:3], g["tr_score"][0]) < tol     # first evaluation = same pose
-    assert rel_inf(r["trace_scores"][0][0, 3:6], g["rot_score"][0]) < 2 * tol
+    assert rel_inf(r["trace_scores"][0][0, 3:6], g["rot_score"][0]) < tol
     if not bf16 and rmsd.max() < 1e-3:
         assert abs(float(r["energy"][0]) - float(g["final_energy"])) < 1e-3
         np.testing.assert_allclose(r["tr_update"], g["tr_update"], atol=2e-3)

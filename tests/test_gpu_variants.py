@@ -1,0 +1,247 @@
+"""GPU parity of the sampler variants and of the optional outputs against goldens captured from the reference
+(tests/golden/make_golden_r02.py), plus regression tests of the drop-in adapter:
+
+  noise annealing            inference_base.py:428-430
+  ODE sampler                inference_mlsb.py:264-350, so3_diffuser.py:367-368
+  second family's sampler    src/inference.py:220-372 (all-atom centroids)
+  sym channel                configs/model/DFMDock.yaml:5 (positional_embed_dim 67)
+  ires                       score_net_mlsb.py:297-303,:383 / egnn_net.py:362-368,:462
+  GraphNorm with |mean| >> std
+  Score_Model.complex_for    a second ligand pose / a re-centred receptor must never be served from a stale complex
+"""
+import numpy as np
+import pytest
+
+from conftest import complex_for, load_golden, pair_hparams
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def ca_rmsd(a, b):
+    return np.sqrt(((a[:, :, 1, :] - b[:, :, 1, :]) ** 2).sum(-1).mean(-1))
+
+
+@pytest.fixture(scope="module")
+def model(blob):
+    from dfmdock_amd import engine
+    engine.set_device(0)
+    m = engine.Model(blob)
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def model_pair(blob_pair):
+    from dfmdock_amd import engine
+    engine.set_device(0)
+    m = engine.Model(blob_pair, pair_hparams())
+    yield m
+    m.close()
+
+
+def _inject(g, with_z=True):
+    inj = dict(R0=g["R0"].astype(np.float32).reshape(1, 9), tr_draw=g["tr_draw"].reshape(1, 3), edges=g["edges"][None])
+    if with_z:
+        inj.update(z_rot=g["z_rot"][None], z_tr=g["z_tr"][None])
+    return inj
+
+
+ROLL_GATE = {"fp32": (0.05, 0.5), "bf16": (0.5, 3.0), "f16": (0.5, 3.0)}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("case,steps", [("rollout_anneal_syn_24_16", 40), ("rollout_anneal_7CEI", 6)])
+def test_noise_annealing_vs_reference(case, steps, prec, model):
+    from dfmdock_amd import engine
+    g = load_golden(case + ".npz")
+    cx = complex_for(case)
+    gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    r = gx.sample(B=1, num_steps=steps, inject=_inject(g), trace=True, noise_annealing=True, bf16=prec == "bf16", f16=prec == "f16")
+    rmsd = ca_rmsd(r["trace_pose"][0], g["poses"])
+    g5, gall = ROLL_GATE[prec]
+    assert rmsd[:5].max() < g5 and rmsd.max() < gall, rmsd
+    if prec == "fp32" and rmsd.max() < 1e-3:
+        assert abs(float(r["energy"][0]) - float(g["final_energy"])) < 1e-3
+        np.testing.assert_allclose(r["tr_update"], g["tr_update"], atol=2e-3)
+    gx.close()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("case,steps", [("rollout_ode_syn_24_16", 40), ("rollout_ode_7CEI", 6)])
+def test_ode_sampler_vs_reference(case, steps, prec, model):
+    """The reference's ODE run comes from inference_mlsb.Sampler, which centres both chains first: its poses are this engine's
+    (inference_base convention) shifted by the receptor CA centroid c1."""
+    from dfmdock_amd import engine
+    g = load_golden(case + ".npz")
+    cx = complex_for(case)
+    gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    r = gx.sample(B=1, num_steps=steps, inject=_inject(g, with_z=False), trace=True, ode=True, bf16=prec == "bf16", f16=prec == "f16")
+    np.testing.assert_allclose(r["init_pose"][0] - g["c1"], g["init_pose"], atol=1e-4)
+    rmsd = ca_rmsd(r["trace_pose"][0] - g["c1"], g["poses"])
+    g5, gall = ROLL_GATE[prec]
+    assert rmsd[:5].max() < g5 and rmsd.max() < gall, rmsd
+    if prec == "fp32" and rmsd.max() < 1e-3:
+        assert abs(float(r["energy"][0]) - float(g["final_energy"])) < 1e-3
+        assert int(r["num_clashes"][0]) == int(g["final_num_clashes"])
+    gx.close()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("case,steps", [("rollout2_syn_24_16", 40), ("rollout2_7CEI", 6)])
+def test_pair_family_sampler_vs_reference(case, steps, prec, model_pair):
+    """src/inference.py's sampler: randomize_pose / modify_coords about the all-backbone-atom centroids."""
+    from dfmdock_amd import engine
+    from oracle import oracle as ora
+    g = load_golden(case + ".npz")
+    cx = complex_for(case)
+    gx = engine.Complex(model_pair, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    r = gx.sample(B=1, num_steps=steps, inject=_inject(g), trace=True, bf16=prec == "bf16", f16=prec == "f16")
+    np.testing.assert_allclose(r["init_pose"][0], g["init_pose"], atol=5e-5)
+    rmsd = ca_rmsd(r["trace_pose"][0], g["poses"])
+    g5, gall = ROLL_GATE[prec]
+    assert rmsd[:5].max() < g5 and rmsd.max() < gall, rmsd
+    if prec == "fp32" and rmsd.max() < 1e-3:
+        assert abs(float(r["energy"][0]) - float(g["final_energy"])) < 1e-3 * max(1.0, abs(float(g["final_energy"])))
+        np.testing.assert_allclose(r["tr_update"], g["tr_update"], atol=2e-3)
+        np.testing.assert_allclose(r["rot_update"], g["rot_update"], atol=2e-4)
+    # rigid-body bookkeeping of this family: final pose = input ligand moved by (rot_update, tr_update) about its ALL-ATOM centroid
+    x = ora.modify_coords_all_atom(cx["lig_pos"], r["rot_update"][0], r["tr_update"][0])
+    assert np.abs(x - r["lig_pos"][0]).max() < 2e-3
+    gx.close()
+
+
+@pytest.mark.parametrize("flag", [0, 1])
+def test_sym_channel_vs_reference(flag):
+    """A 67-channel checkpoint (the stock DFMDock.yaml) loads; the homomer flag adds the sym column's contribution."""
+    from dfmdock_amd import engine
+    from dfmdock_amd.weights import HParams, make_random_weights, pack_blob
+    hp = HParams(family=1, mask_dist=20.0, positional_embed_dim=67)
+    engine.set_device(0)
+    m = engine.Model(pack_blob(make_random_weights(0, hp), hp), hp)
+    g = load_golden(f"fwd2_sym{flag}_syn_24_16.npz")
+    cx = complex_for("syn_24_16")
+    gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    gx.set_homomer(bool(flag))
+    for prec, tol in (("fp32", 1e-4), ("bf16", 1e-2), ("f16", 3e-3)):
+        r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, bf16=prec == "bf16", f16=prec == "f16")
+        assert rel_inf(r["f"][0], g["f"]) < tol and rel_inf(r["tr_score"][0], g["tr_score"].reshape(3)) < tol, prec
+        assert abs(float(r["energy"][0]) - float(g["energy"])) < max(tol, 3e-2 if prec == "bf16" else tol) * max(1.0, abs(float(g["energy"])))
+        assert abs(float(r["confidence"][0]) - float(g["confidence_logits"])) < max(tol, 3e-2 if prec == "bf16" else tol)
+    if flag:     # switching the flag back reproduces the 66-channel behaviour exactly
+        g0 = load_golden("fwd2_sym0_syn_24_16.npz")
+        gx.set_homomer(False)
+        r = gx.score(g0["lig_pos"], float(g0["t"]), edges=g0["edges"], energy=True)
+        assert rel_inf(r["f"][0], g0["f"]) < 1e-4
+    # a 66-channel model refuses the flag
+    m66 = engine.Model(pack_blob(make_random_weights(0, pair_hparams()), pair_hparams()), pair_hparams())
+    gx66 = engine.Complex(m66, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    with pytest.raises(ValueError):
+        gx66.set_homomer(True)
+    gx66.set_homomer(False)
+    gx.close(); gx66.close(); m.close(); m66.close()
+
+
+@pytest.mark.parametrize("case", ["fwd_syn_24_16", "fwd_7CEI_p1", "fwd_c3_300_300"])
+def test_ires_vs_reference(case, model):
+    from dfmdock_amd import engine
+    g = load_golden(case + ".npz")
+    cx = complex_for(case)
+    gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    e = g["edges"].astype(np.int32)
+    r = gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, ires=True)
+    assert r["ires"].shape == (1, gx.N)
+    assert rel_inf(r["ires"][0], g["ires"][:, 0]) < 1e-4
+    r16 = gx.score(np.stack([g["lig_pos"]] * 3), float(g["t"]), edges=np.stack([e] * 3), energy=False, ires=True, bf16=True)
+    assert rel_inf(r16["ires"][2], g["ires"][:, 0]) < 3e-2
+    gx.close()
+
+
+def test_pair_family_ires_vs_reference(model_pair):
+    from dfmdock_amd import engine
+    g = load_golden("fwd2_7CEI_p1.npz")
+    cx = complex_for("7CEI")
+    gx = engine.Complex(model_pair, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, ires=True)
+    assert rel_inf(r["ires"][0], g["ires_logits"]) < 1e-4
+    gx.close()
+
+
+def test_graphnorm_large_mean_channels(blob):
+    """GraphNorm channels whose mean is ~100x their standard deviation (a large node_mlp.0 bias): the fused column
+    statistics of the 16-bit engines must not cancel (torch_geometric graph_norm.py subtracts the mean first)."""
+    from dfmdock_amd import engine
+    from dfmdock_amd.weights import HParams, pack_blob, unpack_blob
+    from oracle import oracle as ora
+    w = {k: v.copy() for k, v in unpack_blob(blob, HParams()).items()}
+    rng = np.random.default_rng(2)
+    for l in range(6):
+        b = w[f"network.EGNN_{l}.egcl.node_mlp.0.bias"]
+        idx = rng.choice(256, 24, replace=False)
+        b[idx] = rng.choice([-1.0, 1.0], 24) * rng.uniform(60.0, 250.0, 24)     # |mean| / std of u is then 100 .. 500
+    blob2 = pack_blob(w)
+    engine.set_device(0)
+    m = engine.Model(blob2)
+    cx = complex_for("syn_64_48")
+    g = load_golden("fwd_syn_64_48_p1.npz")
+    gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    o = ora.Oracle(blob2, cx).score(g["lig_pos"], float(g["t"]), edges=g["edges"])
+    r32 = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, debug=True)
+    assert rel_inf(r32["h_last"][0], o["h_layers"][-1]) < 1e-4 and rel_inf(r32["f"][0], o["f"]) < 1e-4
+    for prec, th, tf in (("f16", 3e-3, 3e-3), ("bf16", 3e-2, 1e-2)):
+        r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, debug=True, bf16=prec == "bf16", f16=prec == "f16")
+        assert rel_inf(r["h_last"][0], o["h_layers"][-1]) < th, prec
+        assert rel_inf(r["f"][0], o["f"]) < tf and rel_inf(r["tr_score"][0], o["tr_score"].reshape(3)) < tf, prec
+    # batched == single stays bit-exact with the new statistics
+    rb = gx.score(np.stack([g["lig_pos"]] * 5), float(g["t"]), edges=np.stack([g["edges"]] * 5), energy=True, bf16=True)
+    r1 = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, bf16=True)
+    for k in ("f", "tr_score", "rot_score", "energy"):
+        np.testing.assert_array_equal(rb[k][3], r1[k][0])
+    gx.close(); m.close()
+
+
+def test_score_model_never_serves_a_stale_complex(blob):
+    """Two sampler calls with the same features and two ligand conformations: each returned (rot_update, tr_update) must move
+    ITS input ligand onto the returned pose (inference_base.py:408-412,:354-364); forward() follows a re-centred receptor."""
+    import torch
+    from dfmdock_amd.score_model import Euler_Maruyama_sampler, Score_Model
+    from oracle import oracle as ora
+    cx = complex_for("7CEI")
+    m = Score_Model(blob, precision="fp32")
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in cx.items()}
+    g = load_golden("fwd_7CEI_p2.npz")
+    lig_a, lig_b = cx["lig_pos"], g["lig_pos"]                     # native and a rigidly displaced conformation
+    assert np.abs(lig_a - lig_b).max() > 1.0
+    for lig in (lig_a, lig_b, lig_a):
+        batch["lig_pos"] = torch.from_numpy(lig.copy())
+        _, lig_pos, rot_update, tr_update, _ = Euler_Maruyama_sampler(m, batch, num_steps=5, device="cuda", seed=7)
+        moved = ora.modify_coords(lig, rot_update.numpy(), tr_update.numpy())
+        assert np.abs(moved - lig_pos.numpy()).max() < 2e-3
+    # in-place edit of the same tensor object must be seen as well
+    with torch.no_grad():
+        batch["lig_pos"] += 3.0
+    _, lig_pos, rot_update, tr_update, _ = Euler_Maruyama_sampler(m, batch, num_steps=5, device="cuda", seed=7)
+    moved = ora.modify_coords(lig_a + np.float32(3.0), rot_update.numpy(), tr_update.numpy())
+    assert np.abs(moved - lig_pos.numpy()).max() < 2e-3
+    # forward(): translating the whole complex leaves energy / scores unchanged, and the features are not re-uploaded
+    batch["lig_pos"] = torch.from_numpy(g["lig_pos"].copy())
+    batch["t"] = torch.tensor([float(g["t"])])
+    m.seed, m._calls = 3, 0
+    a = m(batch)
+    handle = m._cx
+    shift = torch.tensor([11.0, -4.0, 6.5])
+    batch["rec_pos"] = batch["rec_pos"] + shift
+    batch["lig_pos"] = batch["lig_pos"] + shift
+    m._calls = 0                                                   # same Philox stream -> same graph
+    b = m(batch)
+    assert m._cx is handle
+    assert rel_inf(b["tr_score"].numpy(), a["tr_score"].numpy()) < 1e-3 and abs(float(a["energy"]) - float(b["energy"])) < 1e-3
+    assert a["ires"].shape == (214, 1)
+    # new features -> a new complex
+    batch["rec_x"] = batch["rec_x"] * 1.0001
+    m(batch)
+    assert m._cx is not handle

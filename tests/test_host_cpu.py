@@ -41,6 +41,108 @@ def test_lightning_checkpoint_reader(tmp_path):
     assert hp.depth == 6 and hp.cut_off == 20.0
 
 
+def _omegaconf_shaped(tree):
+    """Wrap a plain dict tree into instances of classes NAMED like omegaconf's (omegaconf itself is not installed): the
+    pickle stream then references omegaconf.dictconfig.DictConfig / omegaconf.nodes.AnyNode exactly as a Lightning
+    checkpoint written by the reference does (save_hyperparameters on Hydra configs, score_model_mlsb.py:30)."""
+    import types
+    mods = {}
+    for name in ("omegaconf", "omegaconf.dictconfig", "omegaconf.nodes", "omegaconf.base"):
+        mods[name] = types.ModuleType(name)
+
+    class DictConfig:
+        def __init__(self, content):
+            self.__dict__["_content"] = content
+            self.__dict__["_metadata"] = Metadata()
+
+        def __getstate__(self):
+            return dict(self.__dict__)
+
+        def __setstate__(self, d):
+            self.__dict__.update(d)
+
+    class AnyNode:
+        def __init__(self, val):
+            self._val = val
+            self._metadata = Metadata()
+
+    class Metadata:
+        def __init__(self):
+            self.optional, self.key, self.flags = True, None, {}
+
+    DictConfig.__module__, DictConfig.__qualname__ = "omegaconf.dictconfig", "DictConfig"
+    AnyNode.__module__, AnyNode.__qualname__ = "omegaconf.nodes", "AnyNode"
+    Metadata.__module__, Metadata.__qualname__ = "omegaconf.base", "Metadata"
+    mods["omegaconf.dictconfig"].DictConfig = DictConfig
+    mods["omegaconf.nodes"].AnyNode = AnyNode
+    mods["omegaconf.base"].Metadata = Metadata
+
+    def wrap(x):
+        if isinstance(x, dict):
+            return DictConfig({k: wrap(v) for k, v in x.items()})
+        return AnyNode(x)
+    return mods, wrap(tree)
+
+
+@pytest.mark.parametrize("family", [0, 1])
+def test_lightning_checkpoint_with_omegaconf_hyperparameters(family, tmp_path):
+    """src/inference_base.py:611-614: the real checkpoints carry omegaconf DictConfig hyper-parameters.  The reader must get
+    the hyper-parameters (model dims, agg, diffuser sigmas) and the weights out of such a pickle WITHOUT omegaconf or
+    pytorch_lightning installed, for both model families, and must not execute anything the pickle names."""
+    import torch
+    from dfmdock_amd.weights import HParams, load_lightning_checkpoint, make_random_weights, pack_blob
+    hp0 = HParams(family=1, mask_dist=20.0, positional_embed_dim=67, agg_mean=False) if family else HParams()
+    w = make_random_weights(6, hp0)
+    sd = {"net." + k: torch.from_numpy(v.copy()) for k, v in w.items()}
+    model_cfg = {"lm_embed_dim": 1301, "positional_embed_dim": hp0.positional_embed_dim, "spatial_embed_dim": 100, "node_dim": 256,
+                 "edge_dim": 128, "inner_dim": 128, "depth": 6, "dropout": 0.1, "cut_off": 20.0, "normalize": True}
+    if family:
+        model_cfg["agg"] = "sum"
+    tree = {"model": model_cfg,
+            "diffuser": {"r3": {"min_sigma": 0.2, "max_sigma": 25.0, "schedule": "VE"},
+                         "so3": {"num_omega": 1000, "min_sigma": 0.05, "max_sigma": 1.25, "schedule": "logarithmic"}},
+            "experiment": {"lr": 1e-4, "perturb_tr": True}}
+    mods, hyper = _omegaconf_shaped(tree)
+    path = tmp_path / f"family{family}.ckpt"
+    sys.modules.update(mods)
+    try:
+        torch.save({"state_dict": sd, "hyper_parameters": hyper, "epoch": 7, "pytorch-lightning_version": "2.4.0"}, path)
+    finally:
+        for k in mods:
+            sys.modules.pop(k, None)
+    assert "omegaconf" not in sys.modules
+    out, hp = load_lightning_checkpoint(str(path))
+    np.testing.assert_array_equal(pack_blob(out, hp), pack_blob(w, hp0))
+    assert (hp.family, hp.depth, hp.node_dim, hp.cut_off, hp.positional_embed_dim) == (family, 6, 256, 20.0, hp0.positional_embed_dim)
+    assert (hp.r3_min_sigma, hp.r3_max_sigma, hp.so3_min_sigma, hp.so3_max_sigma) == (0.2, 25.0, 0.05, 1.25)
+    if family:
+        assert hp.agg_mean is False and hp.mask_dist == 20.0
+    # a bare state_dict (no hyper_parameters) still resolves the family from its keys
+    torch.save(sd, tmp_path / "bare.pt")
+    out2, hp2 = load_lightning_checkpoint(str(tmp_path / "bare.pt"))
+    assert hp2.family == family and hp2.positional_embed_dim == hp0.positional_embed_dim
+    np.testing.assert_array_equal(pack_blob(out2, hp2), pack_blob(w, hp0))
+
+
+def test_checkpoint_reader_runs_nothing_from_the_pickle(tmp_path):
+    """Globals outside the allow-list (here: os.system through a __reduce__) are never resolved: they come back as inert
+    attribute bags instead of being called."""
+    import pickle
+    import torch
+    from dfmdock_amd.weights import load_lightning_checkpoint
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+    path = tmp_path / "evil.ckpt"
+    torch.save({"state_dict": {"net.single_embed.weight": torch.zeros(2, 2)}, "hyper_parameters": {"model": Evil()}}, path,
+               pickle_module=pickle)
+    out, hp = load_lightning_checkpoint(str(path))
+    assert not marker.exists()
+    assert "single_embed.weight" in out
+
+
 def test_shard_and_assign():
     from dfmdock_amd.distributed import assign_work, shard_range
     for total, world in ((960, 8), (7, 3), (2, 4), (0, 2)):

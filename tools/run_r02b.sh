@@ -1,0 +1,13 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r02b
+DFM_LIB=$PWD/dfmdock_amd/libdfm_stamp.so timeout 300 python tools/edge_phases.py > gpurun_out/r02b/phases.txt 2>&1; cat gpurun_out/r02b/phases.txt
+export TMPDIR=/tmp
+CMD="python bench.py --steps 1 --warmup 0 --batch 256 --num-steps 2 --no-cpu-baseline"
+OUT=gpurun_out/r02b/pmc; mkdir -p $OUT
+for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
+         "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" \
+         "SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INSTS_VALU_TRANS" \
+         "GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | cut -d' ' -f1-2 | tr ' ' '_')
+  ( cd /tmp && timeout 200 rocprofv3 --pmc $c --kernel-include-regex "k_edge_bf16<0" --output-format csv -d $GRAFT_REPO_ROOT/$OUT -o $n -- $CMD > $GRAFT_REPO_ROOT/$OUT/$n.log 2>&1 ) || echo "pass $c failed"
+done
+python tools/pmc_summary.py $OUT > gpurun_out/r02b/pmc_summary.txt 2>&1; cat gpurun_out/r02b/pmc_summary.txt
