@@ -153,12 +153,13 @@ def main():
         one_step(it)
     barrier()
     t0 = time.perf_counter()
-    edge_ms, edge_launches = 0.0, 0
+    edge_ms, edge_launches, edge_rows = 0.0, 0, 0
     for it in range(args.steps):
         _, allrec = one_step(args.warmup + it, profile=True)
         p = gx.profile()
         edge_ms += p["edge_kernel_ms"]
         edge_launches += p["edge_kernel_launches"]
+        edge_rows += p["edge_rows"]
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -169,9 +170,13 @@ def main():
     if rank == 0:
         total_traj = world * B * args.steps
         N = args.R + args.L
+        # every launch of the message kernel inside the timed region is bracketed by HIP events on the engine's stream; the last
+        # layer runs as several smaller launches (trajectory chunks), so work and time are summed over launches:
+        # achieved = (edge rows processed / K) * FLOP per node and layer / total kernel time
         avg_launch_s = edge_ms / max(edge_launches, 1) * 1e-3
-        flop_per_launch = B * N * FLOP_PER_NODE_LAYER
-        achieved = flop_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        flop_total = edge_rows / K_DEG * FLOP_PER_NODE_LAYER
+        flop_per_launch = flop_total / max(edge_launches, 1)
+        achieved = flop_total / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if mfma16 else PEAK_F32_TFLOPS
         traffic, traffic_src = replayed_traffic(args)
         out = {
@@ -196,7 +201,8 @@ def main():
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
                          "flop_per_launch": flop_per_launch, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_gbps": (traffic / avg_launch_s / 1e9) if traffic else None,
-                         "algorithmic_bytes_per_launch": 8 * B * N * H,
+                         "rows_per_launch": edge_rows / max(edge_launches, 1),
+                         "algorithmic_bytes_per_launch": 8 * H * edge_rows / K_DEG / max(edge_launches, 1),
                          "note": "achieved = B*N*(2*K*H*H + 2*K*H) FLOP / launch time from HIP events on the engine's stream, live; "
                                  "traffic = HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run: see "
                                  "traffic_source; algorithmic bytes per launch = 8*N*H per trajectory (SURVEY 8d)"},

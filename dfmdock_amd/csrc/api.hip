@@ -589,6 +589,16 @@ __global__ void k_fill(float *dst, float v, int n)
     if (i < n) dst[i] = v;
 }
 
+// The bf16 engine runs its LAST layer's message kernel and the coordinate MLP on fp16 operands (same MFMA rate, 3 more mantissa
+// bits): the force f is read directly off that layer, and this alone brings the worst deviation of f / tr_score from the
+// reference from 1.1e-2 / 3.8e-3 to 4.8e-3 / 1.2e-3 at 0.5 % of the time (tools/tol_report.py; DFM_F16_LAST_LAYERS=0 restores
+// pure bf16, =6 is the f16 engine)
+static int f16_last_layers()
+{
+    static const int v = [] { const char *e = getenv("DFM_F16_LAST_LAYERS"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 struct FwdOpts {
     bool bf16 = false, f16 = false, want_energy = false, profile = false;   // bf16: 16-bit MFMA engine; f16: with fp16 operands
     const int32_t *edges_dev = nullptr;   // [B][N][K] already on device (or nullptr = sample natively)
@@ -633,25 +643,35 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         else { e.A = W.A; e.Bm = W.Bm; e.Bmb = W.Bmb; e.ab_bstride = (int64_t)N * H; }
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
         e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = coord; e.fout = W.fvec; e.mbuf = W.mbuf;
-        e.f16 = o.f16 ? 1 : 0;
+        e.f16 = (o.f16 || l >= depth - f16_last_layers()) ? 1 : 0;
         e.stamp = (o.profile && l == 2) ? cx->stamp_dev : nullptr;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (o.profile) {
-            if (cx->ev_used + 2 > cx->ev.size()) {
-                hipEvent_t a, b2;
-                HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b2));
-                cx->ev.push_back(a); cx->ev.push_back(b2);
+        // the per-edge message kernel, bracketed by HIP events on this stream when profiling (dfm_get_profile)
+        auto message_launch = [&](const EdgeArgs &ea) -> int {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (o.profile) {
+                if (cx->ev_used + 2 > cx->ev.size()) {
+                    hipEvent_t a, b2;
+                    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b2));
+                    cx->ev.push_back(a); cx->ev.push_back(b2);
+                }
+                e0 = cx->ev[cx->ev_used++]; e1 = cx->ev[cx->ev_used++];
+                HIPCHK(hipEventRecord(e0, s));
             }
-            e0 = cx->ev[cx->ev_used++]; e1 = cx->ev[cx->ev_used++];
-            HIPCHK(hipEventRecord(e0, s));
+            if (o.bf16) HIPCHK(launch_edge_bf16(ea, s)); else HIPCHK(launch_edge_f32(ea, s));
+            if (o.profile) {
+                HIPCHK(hipEventRecord(e1, s));
+                cx->prof.edge_kernel_launches += 1;
+                cx->prof.edge_rows += (int64_t)ea.B * N * K;
+            }
+            return DFM_OK;
+        };
+        {
+            // (Running the last layer in trajectory chunks so that the stored messages stay in the Infinity Cache was measured and
+            // dropped: 15 extra launch pairs per evaluation cost more - weight refills, partial rounds - than the round trip.)
+            int rc2 = message_launch(e);
+            if (rc2) return rc2;
+            if (coord && o.bf16) HIPCHK(launch_coord_bf16(e, s));
         }
-        if (o.bf16) HIPCHK(launch_edge_bf16(e, s)); else HIPCHK(launch_edge_f32(e, s));
-        if (o.profile) {
-            HIPCHK(hipEventRecord(e1, s));
-            cx->prof.edge_kernel_launches += 1;
-            cx->prof.edge_rows += (int64_t)B * N * K;
-        }
-        if (coord && o.bf16) HIPCHK(launch_coord_bf16(e, s));
         // node_model (egnn.py:106-116): u = Linear(cat[h, agg]); GraphNorm; SiLU; Linear; residual
         GemmArgs g;
         std::memset(&g, 0, sizeof(g));

@@ -126,8 +126,8 @@ struct GemmArgs {
     float *C2;            // [M][256]  (epi 2)
     uint16_t *C2b;        // [M][256]  fp16 copy of C2 (epi 2), may be nullptr
     // optional (k_gemm_split, 64-row tiles, Nout = 256): row tiles aligned to the trajectories (rows_per_graph rows each) and
-    // per-tile column sums of the output for the GraphNorm statistics, [M / rows_per_graph][tiles per trajectory][256][2] =
-    // (sum u, sum u^2); finished by launch_gn_finish
+    // per-tile column statistics of the output for GraphNorm, [M / rows_per_graph][tiles per trajectory][256][2] =
+    // (mean, sum of squared deviations) of the tile's rows; merged by launch_gn_finish
     float *stat_part;
 };
 hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s);
@@ -165,7 +165,7 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s);
 
 // fold_w / fold_b non-null: write the folded affine (den := w/den, shift := b - w*shift/den) for launch_gemm_split
-// GraphNorm statistics from the column sums the node_mlp.0 GEMM left in stat_part (no second pass over u)
+// GraphNorm statistics from the per-tile column statistics the node_mlp.0 GEMM left in stat_part (no second pass over u)
 hipError_t launch_gn_finish(const float *stat_part, int B, int N, const float *mean_scale, float *shift, float *den,
                             const float *fold_w, const float *fold_b, hipStream_t s);
 hipError_t launch_gn_stats(const float *u, int B, int N, const float *mean_scale, float *shift, float *den,

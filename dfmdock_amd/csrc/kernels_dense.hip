@@ -182,10 +182,20 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     // summation order is the same for every trajectory, whatever its position in the batch (batched == single, bitwise)
     int row0 = blockIdx.x * SM, row_end = a.M;
     const int col0 = blockIdx.y * SN;
-    if (MT == 1 && a.stat_part) {
+    // GraphNorm prologue (MT = 1): the folded scale / shift of the tile's trajectory, 2 KiB in LDS for the whole K loop (a load
+    // per K-stage inside the staging code would expose an L2 round trip per stage)
+    __shared__ __attribute__((aligned(16))) float gn_s[MT == 1 ? 2 * H : 4];
+    if (MT == 1 && (a.stat_part || a.pro == 2)) {
         const int tpt = (a.rows_per_graph + SM - 1) / SM, tb = blockIdx.x / tpt;
         row0 = tb * a.rows_per_graph + (blockIdx.x - tb * tpt) * SM;
         row_end = (tb + 1) * a.rows_per_graph;
+        if (a.pro == 2) {
+            if (tid < 128) {
+                const float *src = (tid < 64 ? a.gn_den : a.gn_shift) + (size_t)tb * H + (tid & 63) * 4;
+                *reinterpret_cast<float4 *>(&gn_s[(tid < 64 ? 0 : H) + (tid & 63) * 4]) = *reinterpret_cast<const float4 *>(src);
+            }
+            __syncthreads();
+        }
     }
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -226,9 +236,15 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     auto stage_row = [&](const float4 &v0, const float4 &v1, bool valid, int g, int k, int row) {
         float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         if (a.pro == 2) {   // GraphNorm + SiLU (egnn.py:72-76) as y = x * sc + sh with per-(graph, channel) sc, sh
-            const float *sc = a.gn_den + (size_t)g * H + k, *sh = a.gn_shift + (size_t)g * H + k;
-            const float4 c0 = *reinterpret_cast<const float4 *>(sc), c1 = *reinterpret_cast<const float4 *>(sc + 4);
-            const float4 h0 = *reinterpret_cast<const float4 *>(sh), h1 = *reinterpret_cast<const float4 *>(sh + 4);
+            float4 c0, c1, h0, h1;
+            if constexpr (MT == 1) {     // the tile's trajectory: scale / shift sit in LDS since the start of the kernel
+                c0 = *reinterpret_cast<const float4 *>(&gn_s[k]); c1 = *reinterpret_cast<const float4 *>(&gn_s[k + 4]);
+                h0 = *reinterpret_cast<const float4 *>(&gn_s[H + k]); h1 = *reinterpret_cast<const float4 *>(&gn_s[H + k + 4]);
+            } else {
+                const float *sc = a.gn_den + (size_t)g * H + k, *sh = a.gn_shift + (size_t)g * H + k;
+                c0 = *reinterpret_cast<const float4 *>(sc); c1 = *reinterpret_cast<const float4 *>(sc + 4);
+                h0 = *reinterpret_cast<const float4 *>(sh); h1 = *reinterpret_cast<const float4 *>(sh + 4);
+            }
             const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
             const float hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
@@ -290,7 +306,9 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     // by store issue.  Each wave instead transposes its outputs through a private LDS region (the operand tiles are
     // dead by now) in 32 x 64 passes and stores 16-byte vectors, 256 B per row.
     __syncthreads();
-    float st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0};   // column sums of u and u^2 over this lane's rows (4 columns)
+    // GraphNorm statistics of this lane's rows (4 columns): shifted sums about the lane's first value - no E[u^2] - E[u]^2
+    // cancellation when |mean| >> std - turned into (count, mean, M2) and merged Chan-style across lanes, tiles (k_gn_finish)
+    float st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0}, st_p[4] = {0, 0, 0, 0}, st_n = 0.f;
     constexpr int ELD = 72;                               // floats per staged row (64 + 8: the half-waves, 4 rows apart, hit disjoint banks)
     float *est = reinterpret_cast<float *>(lds) + wave * (32 * ELD);   // 9216 B per wave
     const int er = lane >> 4, ec = (lane & 15) * 4;       // read-back: 4 rows x 16 float4 per instruction
@@ -298,6 +316,16 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jp = 0; jp < NJ / 2; ++jp) {
+            // residual rows of this pass, requested before the transposition below instead of one dependent load per store
+            float4 res[8];
+            if (a.epi == 1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const size_t row = (size_t)row0 + wm * 64 + i * 32 + q * 4 + er;
+                    const int col = col0 + (wn * NJ + jp * 2) * 32 + ec;
+                    res[q] = row < (size_t)row_end ? *reinterpret_cast<const float4 *>(a.R + row * a.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = jp * 2 + jj;
@@ -315,13 +343,16 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
                 const int col = col0 + (wn * NJ + jp * 2) * 32 + ec;
                 if (row >= (size_t)row_end) continue;
                 if constexpr (MT == 1) {
-                    if (a.stat_part) {      // column sums of u for GraphNorm
-                        st_s[0] += v.x; st_s[1] += v.y; st_s[2] += v.z; st_s[3] += v.w;
-                        st_q[0] += v.x * v.x; st_q[1] += v.y * v.y; st_q[2] += v.z * v.z; st_q[3] += v.w * v.w;
+                    if (a.stat_part) {
+                        if (st_n == 0.f) { st_p[0] = v.x; st_p[1] = v.y; st_p[2] = v.z; st_p[3] = v.w; }
+                        const float d0 = v.x - st_p[0], d1 = v.y - st_p[1], d2 = v.z - st_p[2], d3 = v.w - st_p[3];
+                        st_s[0] += d0; st_s[1] += d1; st_s[2] += d2; st_s[3] += d3;
+                        st_q[0] += d0 * d0; st_q[1] += d1 * d1; st_q[2] += d2 * d2; st_q[3] += d3 * d3;
+                        st_n += 1.f;
                     }
                 }
                 if (a.epi == 1) {
-                    const float4 rr = *reinterpret_cast<const float4 *>(a.R + row * a.ldc + col);
+                    const float4 rr = res[q];
                     *reinterpret_cast<float4 *>(a.C + row * a.ldc + col) = make_float4(rr.x + v.x, rr.y + v.y, rr.z + v.z, rr.w + v.w);
                 } else if (a.epi == 2) {
                     if (col0 < H) *reinterpret_cast<float4 *>(a.C + row * H + col) = v;
@@ -343,15 +374,25 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     if constexpr (MT == 1) {
         if (a.stat_part) {
             float *sp = a.stat_part + (size_t)blockIdx.x * (H * 2);
+            const float inv_n = st_n > 0.f ? 1.0f / st_n : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float ss = st_s[e], qq = st_q[e];
-                ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
-                qq += __shfl_xor(qq, 16, 64); qq += __shfl_xor(qq, 32, 64);
-                if (er == 0) {
+                float mean = st_p[e] + st_s[e] * inv_n, M2 = st_q[e] - st_s[e] * st_s[e] * inv_n, ne = st_n;
+#pragma unroll
+                for (int m = 16; m <= 32; m <<= 1) {      // the four row groups (er) of a column, merged in a fixed order (Chan)
+                    const float n2 = __shfl_xor(ne, m, 64), mean2 = __shfl_xor(mean, m, 64), M22 = __shfl_xor(M2, m, 64);
+                    const float nt = ne + n2;
+                    if (nt > 0.f) {
+                        const float d = mean2 - mean, f = n2 / nt;
+                        mean += d * f;
+                        M2 += M22 + d * d * ne * f;
+                    }
+                    ne = nt;
+                }
+                if (er == 0) {       // only this lane's merge order is ever read: deterministic, the same for every trajectory
                     const int c = col0 + wn * 64 + ec + e;
-                    sp[c * 2] = ss;
-                    sp[c * 2 + 1] = qq;
+                    sp[c * 2] = mean;
+                    sp[c * 2 + 1] = M2;
                 }
             }
         }
@@ -374,9 +415,10 @@ hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint1
     static int mt = 0;
     if (!mt) { const char *e = getenv("DFM_GEMM_MT"); mt = e && atoi(e) == 2 ? 2 : 1; }
     if (a.stat_part && (mt != 1 || a.Nout != SN || a.rows_per_graph < 1 || a.M % a.rows_per_graph != 0)) return hipErrorInvalidValue;
+    if (a.pro == 2 && (a.rows_per_graph < 1 || a.M % a.rows_per_graph != 0)) return hipErrorInvalidValue;
     if (mt == 2) hipLaunchKernelGGL(k_gemm_split<2>, dim3((a.M + 127) / 128, a.Nout / SN), dim3(256), 0, s, sa);
-    else if (a.stat_part)
-        hipLaunchKernelGGL(k_gemm_split<1>, dim3((a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64), 1), dim3(256), 0, s, sa);
+    else if (a.stat_part || a.pro == 2)      // row tiles aligned to the trajectories
+        hipLaunchKernelGGL(k_gemm_split<1>, dim3((a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64), a.Nout / SN), dim3(256), 0, s, sa);
     else hipLaunchKernelGGL(k_gemm_split<1>, dim3((a.M + 63) / 64, a.Nout / SN), dim3(256), 0, s, sa);
     return hipGetLastError();
 }
@@ -438,21 +480,25 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float *__restrict__ u, i
     }
 }
 
-// GraphNorm statistics from the per-tile column sums of k_gemm_split (stat_part [B][tiles per trajectory][256][2]); fixed
-// summation order, float64.  var = E[(u - shift)^2] = E[u^2] - 2 shift E[u] + shift^2.
+// GraphNorm statistics from the per-tile column statistics of k_gemm_split (stat_part [B][tiles per trajectory][256][2] =
+// (mean, M2 = sum of squared deviations) over the tile's rows); tiles are merged in a fixed order with Chan's update in
+// float64, then var = E[(u - shift)^2] = M2 / N + (mean - shift)^2 with shift = mean * mean_scale.
 __global__ __launch_bounds__(256) void k_gn_finish(const float *__restrict__ part, int N, const float *__restrict__ mean_scale,
                                                    float *__restrict__ shift, float *__restrict__ den,
                                                    const float *__restrict__ fold_w, const float *__restrict__ fold_b)
 {
     const int b = blockIdx.x, c = threadIdx.x, tpt = (N + 63) / 64;
-    double s = 0, q = 0;
+    double n = 0, mean = 0, M2 = 0;
     for (int t = 0; t < tpt; ++t) {
         const float *pp = part + ((size_t)b * tpt + t) * (H * 2) + c * 2;
-        s += pp[0]; q += pp[1];
+        const double nt = (double)(N - t * 64 < 64 ? N - t * 64 : 64), d = (double)pp[0] - mean, tot = n + nt;
+        mean += d * nt / tot;
+        M2 += (double)pp[1] + d * d * n * nt / tot;
+        n = tot;
     }
-    const double mean = s / N, sft_d = (double)((float)mean * mean_scale[c]);
-    const float sft = (float)sft_d;
-    double var = q / N - 2.0 * sft_d * mean + sft_d * sft_d;
+    const float sft = (float)mean * mean_scale[c];
+    const double dm = mean - (double)sft;
+    double var = M2 / N + dm * dm;
     var = var > 0 ? var : 0;
     const float dn = sqrtf((float)var + 1e-5f);
     if (fold_w) {

@@ -230,8 +230,11 @@ union H8 { uint4 u; __half2 h[4]; };   // eight fp16 values of one gathered 16-b
 #endif
 constexpr int LDS_WF_BYTES = 16 * 8 * 64 * 16;     // 131072: bf16 B-fragments of one 256x256 matrix
 constexpr int LDS_STAGE_BYTES = 32 * 64 * 2;       // 4096 per wave: 32 rows x 64 channels bf16
-constexpr int EDGE_WAVES = 8;                      // waves per workgroup (two per SIMD, 256 registers each)
-constexpr int LDS_EDGE_BYTES = LDS_WF_BYTES + 8 * LDS_STAGE_BYTES;   // 163840 = the whole CU
+#ifndef DFM_EDGE_WAVES
+#define DFM_EDGE_WAVES 8
+#endif
+constexpr int EDGE_WAVES = DFM_EDGE_WAVES;         // waves per workgroup: 8 = two per SIMD (256 registers each), 4 = one per SIMD (512)
+constexpr int LDS_EDGE_BYTES = LDS_WF_BYTES + EDGE_WAVES * LDS_STAGE_BYTES;   // 163840 = the whole CU with 8 waves
 
 typedef float f2 __attribute__((ext_vector_type(2)));   // packed fp32 pair -> v_pk_{mul,add,fma}_f32 (2 results / instr)
 // a + (float)half of a packed fp16 pair in ONE plain-rate instruction (v_fma_mix_f32: f16 source 0 times 1.0 plus f32 source 2);
@@ -340,6 +343,9 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
     const int h = lane >> 5, l31 = lane & 31;
     for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
     __syncthreads();
+#ifdef DFM_EDGE_ONE_WAVE_PER_SIMD      // diagnostic: timing of a wave that has its SIMD to itself (results are incomplete)
+    if (MODE == 0 && wave >= EDGE_WAVES / 2) return;
+#endif
     if constexpr (MODE == 0 && DFM_EDGE_STAGGER > 0) {
         if (wave >= EDGE_WAVES / 2)
             for (int z = 0; z < DFM_EDGE_STAGGER; ++z) __builtin_amdgcn_s_sleep(127);
@@ -649,7 +655,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int rowin = (r & 3) + 8 * (r >> 2) + 4 * h;
-                            Mout[cbase + rowin * 8] = to16<1>(acc[nt][r] * part[r]);     // always fp16: see launch_coord_bf16
+                            Mout[cbase + rowin * 8] = to16<F16>(acc[nt][r] * part[r]);
                         }
                     }
                 }
@@ -777,16 +783,11 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
     return a.f16 ? launch_mfma_t<0, 1>(k, tasks, s) : launch_mfma_t<0, 0>(k, tasks, s);
 }
 
-// The coordinate MLP runs on fp16 operands in BOTH 16-bit engines: it is 4 % of the time, its output IS the force f, and the
-// gated messages it reads are O(1) (no range problem) - three more mantissa bits where they count at no cost.  The bf16
-// engine therefore stores its last layer's messages as fp16 too.
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    EdgeArgs a16 = a;
-    a16.f16 = 1;
-    const EdgeKArgs k = to_kargs_mfma(a16, 1);
+    const EdgeKArgs k = to_kargs_mfma(a, 1);
     const long long tasks = (long long)a.B * (a.N - a.R);
-    return launch_mfma_t<1, 1>(k, tasks, s);
+    return a.f16 ? launch_mfma_t<1, 1>(k, tasks, s) : launch_mfma_t<1, 0>(k, tasks, s);
 }
 
 }  // namespace dfm

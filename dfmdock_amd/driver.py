@@ -117,7 +117,8 @@ def dock_pair(model: engine.Model, rec, lig, rec_x, lig_x, num_samples=120, num_
             best = (float(r["energy"][k]), r["rot_update"][k].copy(), r["tr_update"][k].copy())
         done += b
     gx.close()
-    lig_aa = pdbio.apply_pose_all_atom(lig["aa_coords"], lig["bb_coords"], best[1], best[2])
+    lig_aa = pdbio.apply_pose_all_atom(lig["aa_coords"], lig["bb_coords"], best[1], best[2],
+                                       center="all_atoms" if model.hp.family == 1 else "ca")
     if out_pdb:
         rec_atoms = [a for a in rec["atoms"]]
         pdbio.write_complex_pdb(out_pdb, rec_atoms, lig["atoms"], lig_aa)

@@ -78,9 +78,14 @@ def axis_angle_to_matrix(aa):
                      [two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)]])
 
 
-def apply_pose_all_atom(aa_coords, bb_coords, rot, tr):
-    """Rigid (rot, tr) of the sampler applied to all atoms about the ORIGINAL backbone CA centroid."""
-    center = np.asarray(bb_coords, np.float64)[:, 1].mean(axis=0)
+def apply_pose_all_atom(aa_coords, bb_coords, rot, tr, center="ca"):
+    """Rigid (rot, tr) of the sampler applied to all atoms.  center="ca": about the ORIGINAL backbone CA centroid
+    (modify_aa_coords of src/inference_base.py:354-364, first model family); center="all_atoms": about the mean of the
+    all-atom array itself, which is what the second family's script does (src/inference.py:256-266)."""
+    if center == "all_atoms":
+        center = np.asarray(aa_coords, np.float64).reshape(-1, 3).mean(axis=0)
+    else:
+        center = np.asarray(bb_coords, np.float64)[:, 1].mean(axis=0)
     R = axis_angle_to_matrix(np.asarray(rot).reshape(3))
     return (np.asarray(aa_coords, np.float64) - center) @ R.T + center + np.asarray(tr, np.float64).reshape(3)
 

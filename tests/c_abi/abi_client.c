@@ -47,6 +47,11 @@ int main(int argc, char **argv)
     dfm_complex *cx = dfm_complex_create(m, rec_x, lig_x, rec_pos, lig_pos, R, L);
     if (!cx) { fprintf(stderr, "dfm_complex_create: %s\n", dfm_last_error()); return 3; }
 
+    /* pose / homomer setters: a 66-channel model has no sym channel; re-setting the same poses changes nothing */
+    if (dfm_complex_set_homomer(cx, 1) != DFM_E_INVALID || dfm_complex_set_homomer(cx, 0) != DFM_OK) { fprintf(stderr, "set_homomer\n"); return 4; }
+    if (dfm_complex_set_pose(cx, rec_pos, lig_pos) != DFM_OK || dfm_complex_set_pose(cx, NULL, NULL) != DFM_OK) { fprintf(stderr, "set_pose: %s\n", dfm_last_error()); return 4; }
+    if (dfm_complex_degree(cx) != (R + L < 20 ? R + L : (R + L < 60 ? R + L : 60))) { fprintf(stderr, "degree\n"); return 4; }
+
     float *tr = calloc((size_t)B * 3, 4), *rot = calloc((size_t)B * 3, 4), *en = calloc(B, 4), *f = calloc((size_t)B * L * 3, 4);
     int32_t *cl = calloc(B, 4);
     dfm_score_out out = {0};

@@ -105,10 +105,10 @@ def test_pair_family_batched_and_sampler(blob_pair):
         ro = o.score(out["init_pose"][b], 1.0, edges=dbg["edges"][b], want_energy=False, debug=False)
         assert rel_inf(out["trace_scores"][b, 0, 0:3], ro["tr_score"].reshape(3)) < 2e-4
         assert rel_inf(out["trace_scores"][b, 0, 3:6], ro["rot_score"].reshape(3)) < 2e-4
-    # rigid-body bookkeeping (inference_base.py:446-456,:354-364): final pose = the INPUT ligand moved by the accumulated
-    # (rot_update, tr_update) about its CA centroid - randomize_pose's own move is part of the accumulators
+    # rigid-body bookkeeping of this family (src/inference.py:244-254,:355-358): final pose = the INPUT ligand moved by the
+    # accumulated (rot_update, tr_update) about its ALL-ATOM centroid - randomize_pose's own move is part of the accumulators
     for b in range(B):
-        x = ora.modify_coords(cx["lig_pos"], out["rot_update"][b], out["tr_update"][b])
+        x = ora.modify_coords_all_atom(cx["lig_pos"], out["rot_update"][b], out["tr_update"][b])
         assert np.abs(x - out["lig_pos"][b]).max() < 2e-3
 
 
