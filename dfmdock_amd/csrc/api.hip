@@ -543,17 +543,10 @@ extern "C" int dfm_complex_set_homomer(dfm_complex *cx, int flag)
 extern "C" int dfm_complex_degree(const dfm_complex *cx) { return cx ? cx->K : -1; }
 
 // ------------------------------------------------------------------------------------------------
-// experiment switch: DFM_FUSED_COORD=0 selects the unfused last layer (stored messages + separate coordinate-MLP launch)
-static bool fused_coord()
-{
-    static const bool v = [] { const char *e = getenv("DFM_FUSED_COORD"); return e ? atoi(e) != 0 : true; }();
-    return v;
-}
-
 static int ensure_workspace(dfm_complex *cx, int B, bool bf16)
 {
     Workspace &W = cx->ws;
-    const bool wants_mbuf = bf16 && cx->m->hp.family == 0 && !fused_coord();    // stored gated messages (unfused path only)
+    const bool wants_mbuf = bf16 && cx->m->hp.family == 0;    // gated messages for the coordinate MLP (family 0 only)
     const bool need_mbuf = wants_mbuf && !W.mbuf;
     if (B <= W.Bcap && !need_mbuf) return DFM_OK;
     if (B > W.Bcap) {
@@ -668,19 +661,11 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             if (o.profile) {
                 HIPCHK(hipEventRecord(e1, s));
                 cx->prof.edge_kernel_launches += 1;
-                cx->prof.edge_rows += (int64_t)ea.B * (ea.nodes > 0 ? ea.nodes : N) * K;
+                cx->prof.edge_rows += (int64_t)ea.B * N * K;
             }
             return DFM_OK;
         };
-        if (coord && o.bf16 && fused_coord()) {
-            // last layer of the 16-bit engines: receptor nodes through the plain message kernel, ligand nodes through the
-            // fused messages + coordinate-MLP launch - the gated messages never leave the CU
-            EdgeArgs er = e;
-            er.last = 0; er.nodes = R;
-            int rc2 = message_launch(er);
-            if (rc2) return rc2;
-            HIPCHK(launch_edge_coord_fused(e, s));
-        } else {
+        {
             // (Running the last layer in trajectory chunks so that the stored messages stay in the Infinity Cache was measured and
             // dropped: 15 extra launch pairs per evaluation cost more - weight refills, partial rounds - than the round trip.)
             int rc2 = message_launch(e);

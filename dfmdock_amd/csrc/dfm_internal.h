@@ -152,7 +152,6 @@ struct EdgeArgs {
     const float *radial;   // [B][N][K]
     const float4 *ca4;     // [B][N]
     int B, N, R, K;
-    int nodes;             // launch_edge_bf16: node tasks per trajectory (0 = all N; R = receptor nodes only)
     const LayerDev *lw;    // host copy of the layer's device pointers
     float *agg;            // [B][N][256]
     int last;              // last layer: also the coordinate update for ligand nodes
@@ -164,7 +163,6 @@ struct EdgeArgs {
 hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s);
-hipError_t launch_edge_coord_fused(const EdgeArgs &a, hipStream_t s);   // last layer, ligand nodes: messages + coordinate MLP
 
 // fold_w / fold_b non-null: write the folded affine (den := w/den, shift := b - w*shift/den) for launch_gemm_split
 // GraphNorm statistics from the per-tile column statistics the node_mlp.0 GEMM left in stat_part (no second pass over u)

@@ -51,10 +51,6 @@ struct EdgeKArgs {
     // instead of 128 accumulator moves
     const uint32_t *biasp;
     float inv_s;
-    // MODE 2 (fused last layer for the ligand nodes): fragments / packed bias of the coordinate MLP's contraction
-    const uint4 *Wf2;
-    const uint32_t *biasp2;
-    int nodes0;                  // MODE 0: node tasks per trajectory (N, or R when the ligand nodes go to the fused launch)
     unsigned long long *stamp;   // DFM_EDGE_STAMP builds only: per-phase cycle sums of workgroup 0 (tools/edge_phases.py)
 };
 
@@ -336,22 +332,13 @@ __device__ inline f2 silu2s(f2 x)
     return x * r;
 }
 
-// MODE 0: edge messages of every node (a last-layer launch of the unfused path also stores the ligand nodes' gated messages)
-// MODE 1: coordinate MLP on stored messages (unfused path)
-// MODE 2: FUSED last layer of the ligand nodes - messages AND coordinate MLP without the 2.5 GB round trip through HBM.  The
-//         workgroup advances in lock step: every wave runs one 32-row tile of its node with the edge weights W2 resident, keeps
-//         the tile's gated messages packed in 64 registers, then the workgroup swaps the 128 KiB of LDS weights to the coordinate
-//         MLP's Wc1 (two barriers), every wave contracts its own messages (C layout -> A fragments through its 4 KiB staging
-//         area, 64 channels at a time), and W2 is swapped back.  Four swaps per node (two tiles): ~10 % of these rounds.
-// F16 0: bf16 MFMA operands, 1: fp16 MFMA operands (3 more mantissa bits, same rate)
-template <int MODE, int F16>
+template <int MODE, int F16>   // MODE 0: edge messages (+ store of gated messages on the last layer), 1: coordinate MLP
+                                 // F16 0: bf16 MFMA operands, 1: fp16 MFMA operands (3 more mantissa bits, same rate)
 __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 {
-    constexpr bool MSG = MODE == 0 || MODE == 2;      // the tile runs the message contraction (producer + W2)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *Wf = reinterpret_cast<uint4 *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform for the compiler too (scalar branches, SGPR descriptors)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     char *stage = smem + LDS_WF_BYTES + wave * LDS_STAGE_BYTES;
     const int h = lane >> 5, l31 = lane & 31;
     for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
@@ -367,7 +354,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
     // XCD-aware task order (speed only): workgroup g runs on XCD g % 8; give every XCD whole
     // trajectories so that the gathered rows of Bm stay in that XCD's L2.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
-    const int NT = MODE == 0 ? p.nodes0 : p.L;            // node tasks per trajectory (MODE 1 / 2: the ligand nodes)
+    const int NT = MODE == 0 ? p.N : p.L;                 // node tasks per trajectory
     const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;   // few trajectories: split each over several XCDs
     const int NTc = (NT + nsplit - 1) / nsplit;           // nodes per chunk
     const int U = p.B * nsplit;                           // chunks; chunk u lives on XCD u % 8
@@ -375,11 +362,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
     const unsigned ntask = (unsigned)nb * (unsigned)NTc;
     const unsigned tstride = (unsigned)wg_per_xcd * EDGE_WAVES;
     const int K = p.K, ntile = (K + 31) >> 5;
-    const float *dot_v = MSG ? p.att_w : p.wc2;           // att_w / wc2 (wc2 pre-divided by SILU_S)
-    // cooperative (re)fill of the resident weight fragments
-    auto fill_weights = [&](const uint4 *src) {
-        for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = src[q];
-    };
+    const float *dot_v = MODE == 0 ? p.att_w : p.wc2;     // att_w / wc2 (wc2 pre-divided by SILU_S)
 
     // task tt of this XCD -> (trajectory, node); wave-uniform, kept in SGPRs
     auto task_node = [&](unsigned tt, int &b, int &i) -> bool {
@@ -424,11 +407,9 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 #define STAMP(k)
 #define STAMP0()
 #endif
-    for (unsigned tbase = (unsigned)slot * EDGE_WAVES; tbase < ntask; tbase += tstride) {     // tbase: workgroup-uniform
-        const unsigned tt = tbase + wave;
-        int b = 0, i = 0;
-        const bool valid = tt < ntask && task_node(tt, b, i);
-        if (MODE != 2 && !valid) continue;       // MODE 2 keeps idle waves in the loop: they take part in the barriers
+    for (unsigned tt = (unsigned)slot * EDGE_WAVES + wave; tt < ntask; tt += tstride) {
+        int b, i;
+        if (!task_node(tt, b, i)) continue;
         const size_t node = (size_t)b * p.N + i;
         const size_t ebase = node * K;
         const size_t ab = (size_t)b * p.ab_bstride;
@@ -443,49 +424,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
             float dv[8];        // dot vector of the epilogue, fetched under the last MFMA phase
             uint32_t bp[8];     // packed (hi, lo) bias of this lane's column per n-tile (biasp is [8][64]: lanes 32..63 hold 0)
 
-            uint32_t mreg[MODE == 2 ? 64 : 1];      // MODE 2: this tile's gated messages, 16-bit pairs of rows, C layout
-            // SiLU of a finished 32 x 256 accumulator tile (in place) and its dot product with a per-column vector:
-            // pt[r] = sum over the 256 columns of row r, in every lane of the half
-            auto silu_dot = [&](f32x16 (&a)[8], const float (&vec)[8], float (&pt)[16]) {
-                f2 part2[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) part2[q] = (f2){0.f, 0.f};
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    const f2 vv = {vec[nt], vec[nt]};
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const f2 m = silu2s((f2){a[nt][2 * q], a[nt][2 * q + 1]});
-                        a[nt][2 * q] = m.x; a[nt][2 * q + 1] = m.y;
-                        part2[q] = m * vv + part2[q];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { pt[2 * q] = part2[q].x; pt[2 * q + 1] = part2[q].y; }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pt[r] = half_sum_dpp(pt[r]);   // all 32 lanes of the half hold the row sum
-            };
-            // coord_mlp tail: w = clamp(sum_c silu(.) * wc2, +-2); x_i += mean_s (x_i - x_j)/(|x_i - x_j| + 1) * w
-            // one lane per row (16 rows per half: lane l31 < 16 takes register row r = l31), so the 32 edge-index /
-            // coordinate loads of a tile are issued together instead of as a 16-long dependent chain in one lane
-            auto coord_accumulate = [&](const float (&pt)[16]) {
-                float w = pt[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) w = l31 == r ? pt[r] : w;
-                const int row = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;
-                if (l31 < 16 && row < K) {
-                    const float4 *ca = p.ca4 + (size_t)b * p.N;
-                    const float4 xi = ca[i];
-                    w = fminf(fmaxf(w, -2.0f), 2.0f);
-                    const float4 xj = ca[p.edges[ebase + row]];
-                    const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-                    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f) + 1.0f;
-                    cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;
-                }
-            };
-            do {       // the tile's own work (skipped by idle waves of a MODE 2 round)
-            if (MODE == 2 && !valid) break;
-            if constexpr (MSG) {
+            if constexpr (MODE == 0) {
                 // ---- interleaved form: a chunk is 32 channels (two MFMA k-steps, 16 MFMAs).  Producer layout: four
                 // adjacent lanes = one row's 64-byte half line, 16 rows per pass, two passes per chunk.  The wave's 4 KiB
                 // of staging are two 2 KiB buffers laid out [unit u = 8-channel group][row ^ 4u] x 16 B (conflict-free
@@ -679,16 +618,34 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 
             // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) -------------
             float part[16];
-            silu_dot(acc, dv, part);
+            {
+                f2 part2[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) part2[q] = (f2){0.f, 0.f};
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    const f2 vv = {dv[nt], dv[nt]};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f2 m = silu2s((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
+                        acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
+                        part2[q] = m * vv + part2[q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { part[2 * q] = part2[q].x; part[2 * q + 1] = part2[q].y; }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r] = half_sum_dpp(part[r]);   // all 32 lanes of the half hold the row sum
 
-            if (MSG) {
+            if (MODE == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     // attention gate sigmoid(logit) = 1 / (1 + exp2(S logit)); part = S * (att_w . m2), att_b pre-scaled
                     part[r] = row < K ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(part[r] + p.att_b)) : 0.f;
                 }
-                const bool store_m = MODE == 0 && p.last && i >= p.R;
+                const bool store_m = p.last && i >= p.R;
                 if (store_m) {
                     // A-fragment order of the coordinate-MLP kernel: [k-step 16][lane half 2][row 32][8 channels] per tile
                     uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H);
@@ -706,97 +663,37 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 for (int nt = 0; nt < 8; ++nt) {
                     f2 cs = {0.f, 0.f};
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if constexpr (MODE == 2) {
-                            // keep the gated message (16-bit, two rows per register) for the coordinate contraction; the accumulator dies here
-                            const f2 gm = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){part[2 * q], part[2 * q + 1]};
-                            cs = cs + gm;
-                            mreg[nt * 8 + q] = (uint32_t)to16<F16>(gm.x) | ((uint32_t)to16<F16>(gm.y) << 16);
-                        } else {
-                            cs = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){part[2 * q], part[2 * q + 1]} + cs;
-                        }
-                    }
+                    for (int q = 0; q < 8; ++q) cs = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){part[2 * q], part[2 * q + 1]} + cs;
                     colsum[nt] += cs.x + cs.y;
                 }
             } else {
-                coord_accumulate(part);
-            }
-            } while (0);       // end of the tile's own work
-
-            if constexpr (MODE == 2) {
-                // ---- coordinate MLP of this tile on the messages held in mreg: swap the resident weights W2 -> Wc1 ------------
-                __syncthreads();                         // every wave has issued its last read of W2
-                fill_weights(p.Wf2);
-                __syncthreads();
-                if (valid) {
-                    f32x16 acc2[8];
-                    float dv2[8];
-                    uint32_t bp2[8];
+                // coord_mlp: w = clamp(sum_c silu(.) * wc2, +-2); x_i += mean_s (x_i - x_j)/(|x_i - x_j| + 1) * w
+                // one lane per row (16 rows per half: lane l31 < 16 takes register row r = l31), so the 32 edge-index /
+                // coordinate loads of a tile are issued together instead of as a 16-long dependent chain in one lane
+                float w = part[0];
 #pragma unroll
-                    for (int nt = 0; nt < 8; ++nt) { dv2[nt] = p.wc2[nt * 32 + l31]; bp2[nt] = p.biasp2[nt * 64 + lane]; }
-                    constexpr int CD = 4;                // weight-fragment reads run three ahead in a static register ring
-                    const uint4 *wq = Wf + lane;
-                    Frag bq[CD];
-#pragma unroll
-                    for (int d = 0; d < CD - 1; ++d) bq[d].u = wq[d * 64];
-#pragma unroll
-                    for (int kc = 0; kc < 4; ++kc) {
-                        // message channels 64 kc .. 64 kc + 63 (n-tiles 2 kc, 2 kc + 1 of the message tile) = k-steps 4 kc .. 4 kc + 3:
-                        // C layout (lane = channel, registers = rows) -> staging [8-channel unit u][row ^ 4 (u & 3)] x 16 B
-                        wave_lds_fence();
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int ch = jj * 32 + l31, u = ch >> 3, e = ch & 7;
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const uint32_t v = mreg[(kc * 2 + jj) * 8 + q];
-                                const int ra = ((2 * q) & 3) + 8 * ((2 * q) >> 2) + 4 * h, rb = ((2 * q + 1) & 3) + 8 * ((2 * q + 1) >> 2) + 4 * h;
-                                *reinterpret_cast<uint16_t *>(stage + (((u * 32 + (ra ^ (4 * (u & 3)))) << 4) + e * 2)) = (uint16_t)v;
-                                *reinterpret_cast<uint16_t *>(stage + (((u * 32 + (rb ^ (4 * (u & 3)))) << 4) + e * 2)) = (uint16_t)(v >> 16);
-                            }
-                        }
-                        wave_lds_fence();
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) {
-                            const int un = ks * 2 + h;
-                            Frag af;
-                            af.u = *reinterpret_cast<const uint4 *>(stage + ((un * 32 + (l31 ^ (4 * (un & 3)))) << 4));
-#pragma unroll
-                            for (int nt = 0; nt < 8; ++nt) {
-                                const int m = (kc * 4 + ks) * 8 + nt;
-                                if (m + CD - 1 < 128) bq[(m + CD - 1) % CD].u = wq[(m + CD - 1) * 64];
-                                if (m < 8) acc2[nt] = mfma16<F16>(af, bq[m % CD], zero16);
-                                else acc2[nt] = mfma16<F16>(af, bq[m % CD], acc2[nt]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int nt = 0; nt < 8; ++nt) {
-                        Frag bb;
-                        bb.u = make_uint4(bp2[nt], 0u, 0u, 0u);
-                        acc2[nt] = mfma16<F16>(onef, bb, acc2[nt]);
-                    }
-                    float part2c[16];
-                    silu_dot(acc2, dv2, part2c);
-                    coord_accumulate(part2c);
-                }
-                if (!(mt == ntile - 1 && tbase + tstride >= ntask)) {     // workgroup-uniform: more message tiles follow
-                    __syncthreads();                     // every wave has issued its last read of Wc1
-                    fill_weights(p.Wf);
-                    __syncthreads();
+                for (int r = 1; r < 16; ++r) w = l31 == r ? part[r] : w;
+                const int row = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;
+                if (l31 < 16 && row < K) {
+                    const float4 *ca = p.ca4 + (size_t)b * p.N;
+                    const float4 xi = ca[i];
+                    w = fminf(fmaxf(w, -2.0f), 2.0f);
+                    const float4 xj = ca[p.edges[ebase + row]];
+                    const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f) + 1.0f;
+                    cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;
                 }
             }
             STAMP(3);
         }   // mt
 
-        if (MSG && (MODE != 2 || valid)) {
+        if (MODE == 0) {
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
                 const float t = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
                 if (h == 0) p.agg[node * H + nt * 32 + l31] = t * p.inv_s;
             }
-        }
-        if (MODE == 1 || (MODE == 2 && valid)) {
+        } else {
             cacc0 = wave_sum(cacc0); cacc1 = wave_sum(cacc1); cacc2 = wave_sum(cacc2);
             if (lane == 0) {
                 const float4 xi = p.ca4[node];
@@ -831,7 +728,6 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
     k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.stamp = a.stamp;
-    k.nodes0 = a.nodes > 0 ? a.nodes : a.N;
     return k;
 }
 // the 16-bit MFMA kernels take the -log2(e)-scaled operands (SILU_S, api.hip)
@@ -883,20 +779,8 @@ template <int MODE, int F16> static hipError_t launch_mfma_t(const EdgeKArgs &k,
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
     const EdgeKArgs k = to_kargs_mfma(a, 0);
-    const long long tasks = (long long)a.B * k.nodes0;
+    const long long tasks = (long long)a.B * a.N;
     return a.f16 ? launch_mfma_t<0, 1>(k, tasks, s) : launch_mfma_t<0, 0>(k, tasks, s);
-}
-
-// last layer, ligand nodes: messages + coordinate MLP in one launch (MODE 2); writes agg and f for the ligand nodes
-hipError_t launch_edge_coord_fused(const EdgeArgs &a, hipStream_t s)
-{
-    EdgeKArgs k = to_kargs_mfma(a, 0);
-    const LayerDev *w = a.lw;
-    k.Wf2 = reinterpret_cast<const uint4 *>(a.f16 ? w->Wc1f16 : w->Wc1f);
-    k.biasp2 = a.f16 ? w->bc1p16 : w->bc1p;
-    k.last = 0;
-    const long long tasks = (long long)a.B * (a.N - a.R);
-    return a.f16 ? launch_mfma_t<2, 1>(k, tasks, s) : launch_mfma_t<2, 0>(k, tasks, s);
 }
 
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
