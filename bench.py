@@ -195,8 +195,11 @@ def main():
             "config": {"workload": f"C3: synthetic {args.R}+{args.L}-residue complex, batch={B} trajectories/GPU, "
                                    f"{args.num_steps} steps ({args.num_steps + 1} score evaluations + energy head)",
                        "trajectories_per_gpu": B, "num_steps": args.num_steps, "parallelism": f"traj-shard x{world}",
-                       "weights": "random-init (seeded generator; trained checkpoint not in the reference)"},
-            "roofline": {"bound": "mfma", "kernel": ("k_edge_bf16<0,%d>" % int(f16)) if mfma16 else "k_edge_f32", "achieved": achieved,
+                       "weights": "random-init (seeded generator; trained checkpoint not in the reference)",
+                       "precision": ("bf16 MFMA operands for the per-edge contractions of layers 0-4, fp16 operands (same rate) for the last "
+                                     "layer and the coordinate head, fp32 accumulate; split-bf16 node GEMMs; fp32 geometry / heads / SDE step")
+                                    if bf16 else args.precision},
+            "roofline": {"bound": "mfma", "kernel": ("k_edge_bf16<0,%s>" % ("1" if f16 else "0|1: bf16 operands, last layer fp16")) if mfma16 else "k_edge_f32", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
                          "flop_per_launch": flop_per_launch, "traffic": traffic, "traffic_source": traffic_src,

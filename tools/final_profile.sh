@@ -11,7 +11,7 @@ prof() {   # prof <tag> <cmd...>: rocprofv3 kernel stats of a command, csv -> $O
 }
 if [ -z "$SKIP_TESTS" ]; then timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log; fi
 timeout 600 python bench.py > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log | cut -c1-300
-prof bench python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline; tail -1 $OUT/bench.log | cut -c1-200; head -8 $OUT/bench_kernel_stats.csv | cut -c1-160
+prof bench_prof python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline; tail -1 $OUT/bench_prof.log | cut -c1-200; head -8 $OUT/bench_prof_kernel_stats.csv | cut -c1-160
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch 256 --num-steps 3 --no-cpu-baseline"
 mkdir -p $OUT/pmc
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
