@@ -180,14 +180,23 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     // row tile: plain 64/128-row blocks of the [M] rows, or - when the GraphNorm column sums are wanted - blocks aligned to
     // the trajectory (rows_per_graph rows each, last block partial): every block then belongs to one trajectory and the
     // summation order is the same for every trajectory, whatever its position in the batch (batched == single, bitwise)
-    int row0 = blockIdx.x * SM, row_end = a.M;
-    const int col0 = blockIdx.y * SN;
+    // block -> (row tile, 256-column block).  With two column blocks (the [Wa|Wb] projection, Nout = 512) the launch is 1-D and the
+    // two blocks of a row tile are 8 apart: workgroup g runs on XCD g % 8, so they share an L2 and run close in time - the second
+    // read of the 64 x K activation tile hits L2 instead of HBM
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.y == 1 && a.Nout == 2 * SN) {
+        const int g16 = bx >> 4, j = bx & 15;
+        bx = g16 * 8 + (j & 7); by = j >> 3;
+        if (bx * SM >= a.M) return;          // tail of the last group of 8 tiles
+    }
+    int row0 = bx * SM, row_end = a.M;
+    const int col0 = by * SN;
     // GraphNorm prologue (MT = 1): the folded scale / shift of the tile's trajectory, 2 KiB in LDS for the whole K loop (a load
     // per K-stage inside the staging code would expose an L2 round trip per stage)
     __shared__ __attribute__((aligned(16))) float gn_s[MT == 1 ? 2 * H : 4];
     if (MT == 1 && (a.stat_part || a.pro == 2)) {
-        const int tpt = (a.rows_per_graph + SM - 1) / SM, tb = blockIdx.x / tpt;
-        row0 = tb * a.rows_per_graph + (blockIdx.x - tb * tpt) * SM;
+        const int tpt = (a.rows_per_graph + SM - 1) / SM, tb = bx / tpt;
+        row0 = tb * a.rows_per_graph + (bx - tb * tpt) * SM;
         row_end = (tb + 1) * a.rows_per_graph;
         if (a.pro == 2) {
             if (tid < 128) {
@@ -419,6 +428,8 @@ hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint1
     if (mt == 2) hipLaunchKernelGGL(k_gemm_split<2>, dim3((a.M + 127) / 128, a.Nout / SN), dim3(256), 0, s, sa);
     else if (a.stat_part || a.pro == 2)      // row tiles aligned to the trajectories
         hipLaunchKernelGGL(k_gemm_split<1>, dim3((a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64), a.Nout / SN), dim3(256), 0, s, sa);
+    else if (a.Nout == 2 * SN)                 // paired column blocks, see the block mapping in the kernel
+        hipLaunchKernelGGL(k_gemm_split<1>, dim3((((a.M + 63) / 64 + 7) / 8) * 16, 1), dim3(256), 0, s, sa);
     else hipLaunchKernelGGL(k_gemm_split<1>, dim3((a.M + 63) / 64, a.Nout / SN), dim3(256), 0, s, sa);
     return hipGetLastError();
 }

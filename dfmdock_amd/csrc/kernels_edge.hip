@@ -421,6 +421,8 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
         for (int mt = 0; mt < ntile; ++mt) {
             STAMP0();
             f32x16 acc[8];
+            float4 c_xi = make_float4(0.f, 0.f, 0.f, 0.f), c_xj = c_xi;     // MODE 1: this node / this lane's neighbour
+            int c_j = 0;
             float dv[8];        // dot vector of the epilogue, fetched under the last MFMA phase
             uint32_t bp[8];     // packed (hi, lo) bias of this lane's column per n-tile (biasp is [8][64]: lanes 32..63 hold 0)
 
@@ -583,6 +585,18 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 uint4 a16[16];
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) a16[kk] = Mt[kk * 64];
+                // everything the epilogue needs from memory goes out now too, so that nothing after the MFMAs waits on a load:
+                // bias / dot vector, and the neighbour of this lane's row (edge index first, its coordinates below)
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    dv[nt] = dot_v[nt * 32 + l31];
+                    bp[nt] = p.biasp[nt * 64 + lane];
+                }
+                {
+                    const int row = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;
+                    c_xi = p.ca4[(size_t)b * p.N + i];
+                    c_j = p.edges[ebase + (row < K ? row : 0)];
+                }
                 constexpr int CDEPTH = 4;      // weight-fragment LDS reads run three ahead in a static register ring
                 const uint4 *wq = Wf + lane;
                 Frag bq[CDEPTH];
@@ -599,12 +613,8 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                         if (m < 8) acc[m] = mfma16<F16>(af, bq[m % CDEPTH], zero16);
                         else acc[m & 7] = mfma16<F16>(af, bq[m % CDEPTH], acc[m & 7]);
                     }
+                    if (g == 0) c_xj = p.ca4[(size_t)b * p.N + c_j];     // the edge index has landed under the first 32 MFMAs
                     __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next group's reads (spills)
-                }
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    dv[nt] = dot_v[nt * 32 + l31];
-                    bp[nt] = p.biasp[nt * 64 + lane];
                 }
             }
             // bias k-step: acc += 1 * hi + 1 * lo (the accumulators were opened with C = 0)
@@ -675,10 +685,8 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 for (int r = 1; r < 16; ++r) w = l31 == r ? part[r] : w;
                 const int row = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;
                 if (l31 < 16 && row < K) {
-                    const float4 *ca = p.ca4 + (size_t)b * p.N;
-                    const float4 xi = ca[i];
+                    const float4 xi = c_xi, xj = c_xj;
                     w = fminf(fmaxf(w, -2.0f), 2.0f);
-                    const float4 xj = ca[p.edges[ebase + row]];
                     const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
                     const float nrm = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f) + 1.0f;
                     cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;

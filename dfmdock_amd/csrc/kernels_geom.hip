@@ -83,8 +83,13 @@ __device__ inline uint32_t wave_min_u32(uint32_t v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// kNN(20) + sample(40, p ~ 1/d^3, without replacement) (score_net_mlsb.py:85-135).
-// One 64-lane wave per (trajectory, node).  The lane owns candidates j = 4*(lane + 64*q) + e
+// kNN(20) + sample(40, p ~ 1/d^3, without replacement) (score_net_mlsb.py:85-135): the pairwise C-alpha distance scan and the
+// radial-graph edge build.  One 64-lane wave per (trajectory, node); the candidates' coordinates are read straight from global
+// memory (the C-alpha array of a trajectory is 9.6 KB at N = 600, 32 KB at N = 2000: L1 / L2 resident, and the scan is 3 % of the
+// kernel's instructions).  An LDS-tiled form - the workgroup stages its trajectory's coordinates as a structure of arrays and
+// the four waves read them back in conflict-free 16-byte reads - was built, parity-tested and measured slower (fill + barrier
+// per short-lived workgroup; with 8 / 32 nodes per workgroup also +14 registers and a coarser tail): 948 / 955 vs 880 us at C3,
+// 949 / 1297 vs 827 us at C5 (N = 2000, B = 32) - profiles/r02_exp_knn_lds.txt.  The lane owns candidates j = 4*(lane + 64*q) + e
 // (q < NPL/4, e < 4) in registers.  Top-k by repeated wave-wide arg-min of (value, index):
 // ascending distance, lowest index first on ties, slot 0 = the node itself.  The sampled slots
 // are an exponential race: key_j = Exp(1)_j * d_j^3, the 40 smallest keys = successive sampling
