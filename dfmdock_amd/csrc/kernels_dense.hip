@@ -275,16 +275,25 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
     };
 
     const int wu = tid * SLD;   // weights: thread = output column, q = 8-k group (consecutive lanes -> consecutive LDS rows: conflict-free)
+#ifdef DFM_GEMM_STAMP
+    unsigned long long gs[4] = {0, 0, 0, 0}, gprev = __builtin_amdgcn_s_memtime();
+#define GSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _n = __builtin_amdgcn_s_memtime(); gs[k] += _n - gprev; gprev = _n; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define GSTAMP(k)
+#endif
     GEMM_SPLIT_FETCH(0)
     for (int k0 = 0; k0 < a.K; k0 += SK) {
         if (k0) __syncthreads();   // previous stage fully consumed
+        GSTAMP(0)                  // [0] MFMA phase + barrier wait
         stage_row(xa0, xa1, rv0, g0, k0 + kg, ar);
         if constexpr (MT == 2) stage_row(xa2, xa3, rv1, g1, k0 + kg, ar + 64);
         *reinterpret_cast<uint4 *>(&Wh[wu]) = wh0; *reinterpret_cast<uint4 *>(&Wh[wu + 8]) = wh1;
         *reinterpret_cast<uint4 *>(&Wh[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&Wh[wu + 24]) = wh3;
         *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
         *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
+        GSTAMP(1)                  // [1] waiting for the fetched registers + conversion + LDS stores
         __syncthreads();
+        GSTAMP(2)                  // [2] barrier after staging
         if (k0 + SK < a.K) GEMM_SPLIT_FETCH(k0 + SK)         // flies under the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < SK; ks += 16) {
@@ -311,6 +320,7 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
             }
         }
     }
+    GSTAMP(0)
     // epilogue: the C layout (lane = column, registers = rows) would need scalar stores, and the kernel is then bound
     // by store issue.  Each wave instead transposes its outputs through a private LDS region (the operand tiles are
     // dead by now) in 32 x 64 passes and stores 16-byte vectors, 256 B per row.
@@ -380,6 +390,13 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+#ifdef DFM_GEMM_STAMP
+    GSTAMP(3)                      // [3] epilogue
+    if (blockIdx.x == 7 * 8 && tid == 0 && a.C) {       // one mid-grid workgroup reports (debug buffer = first floats of ... stderr-free: printf)
+        printf("gemm stamp K=%d Nout=%d pro=%d epi=%d: mfma+barrier %llu  fetch-wait+stage %llu  barrier2 %llu  epilogue %llu cycles\n",
+               a.K, a.Nout, a.pro, a.epi, gs[0], gs[1], gs[2], gs[3]);
+    }
+#endif
     if constexpr (MT == 1) {
         if (a.stat_part) {
             float *sp = a.stat_part + (size_t)blockIdx.x * (H * 2);

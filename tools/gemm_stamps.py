@@ -1,0 +1,12 @@
+import os, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+import numpy as np
+from dfmdock_amd import engine
+from dfmdock_amd.synthetic import make_complex
+from dfmdock_amd.weights import make_random_weights, pack_blob
+engine.set_device(0)
+m = engine.Model(pack_blob(make_random_weights(0)))
+cx = make_complex(300, 300, seed=1)
+gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.5, seed=1, bf16=True, energy=False)
