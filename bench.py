@@ -199,7 +199,7 @@ def main():
                        "precision": ("bf16 MFMA operands for the per-edge contractions of layers 0-4, fp16 operands (same rate) for the last "
                                      "layer and the coordinate head, fp32 accumulate; split-bf16 node GEMMs; fp32 geometry / heads / SDE step")
                                     if bf16 else args.precision},
-            "roofline": {"bound": "mfma", "kernel": ("k_edge_bf16<0,%s>" % ("1" if f16 else "0|1: bf16 operands, last layer fp16")) if mfma16 else "k_edge_f32", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": ("k_edge_msg<%s>" % ("1" if f16 else "0|1: bf16 operands, last layer fp16")) if mfma16 else "k_edge_f32", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
                          "flop_per_launch": flop_per_launch, "traffic": traffic, "traffic_source": traffic_src,

@@ -8,7 +8,7 @@
 // contiguously, so scatter_add is a dense K-row reduction: no atomics anywhere.
 //
 //   k_edge_f32  : exact fp32 (VALU) - the parity-reference precision of the engine.
-//   k_edge_bf16 : 256x256 contraction on v_mfma_f32_32x32x16_bf16, fp32 accumulate; A-fragments are
+//   k_edge_msg / k_edge_coord : 256x256 contraction on v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate; A-fragments are
 //                 built in registers straight from the gathers, the weight matrix lives in LDS for the
 //                 whole (persistent) workgroup.
 #include <cstdio>
@@ -52,6 +52,7 @@ struct EdgeKArgs {
     const uint32_t *biasp;
     float inv_s;
     unsigned long long *stamp;   // DFM_EDGE_STAMP builds only: per-phase cycle sums of workgroup 0 (tools/edge_phases.py)
+    int split;                   // k_edge_msg: 1 = a wave task is one TILE (small launches), agg is pre-zeroed and added to atomically
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -192,8 +193,9 @@ __global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
 //             the resident weight fragments by ds_read_b128 (reads one ahead).
 // The producer arithmetic is cut into slices laid between the MFMAs in program order (scheduling barriers keep them
 // there), so a wave's MFMAs run in the shadow of its own VALU work; the gathers of chunk c + 2 are in flight meanwhile.
-// Epilogue in the C layout (lane = column, registers = rows): SiLU (bias is in the accumulator init), attention gate
-// (in-lane dot + DPP row reduction), row mask, 60-row segment sum in registers -> agg; no atomics.
+// The chunk loop wraps around the tile boundary (chunk 6 requests, chunk 7 builds chunk 0 of the wave's next tile), so a tile
+// has no prologue.  Epilogue in the C layout (lane = column, registers = rows): SiLU (bias added by one extra MFMA k-step),
+// attention gate (in-lane dot + DPP row reduction), row mask, 60-row segment sum in registers -> agg; no atomics.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -219,15 +221,6 @@ union H8 { uint4 u; __half2 h[4]; };   // eight fp16 values of one gathered 16-b
 #ifndef DFM_EDGE_GC
 #define DFM_EDGE_GC 14
 #endif
-// Waves w and w + 4 of a workgroup share a SIMD.  Started together they stay in lockstep - both in the latency-bound main loop,
-// then both in the VALU-dense epilogue; delaying the second one by about half a tile at launch puts one wave's epilogue beside
-// the other's main loop (units of 64 cycles per step of s_sleep 127 ~ 8k cycles; 0 = off)
-#ifndef DFM_EDGE_STAGGER
-#define DFM_EDGE_STAGGER 0
-#endif
-#ifndef DFM_EDGE_PERM
-#define DFM_EDGE_PERM 0    // 1: producer slices of a pass in the order (pre 0, pre 1, act 0, act 1, pre 2, pre 3, act 2, act 3)
-#endif
 constexpr int LDS_WF_BYTES = 16 * 8 * 64 * 16;     // 131072: bf16 B-fragments of one 256x256 matrix
 constexpr int LDS_STAGE_BYTES = 32 * 64 * 2;       // 4096 per wave: 32 rows x 64 channels bf16
 #ifndef DFM_EDGE_WAVES
@@ -236,7 +229,13 @@ constexpr int LDS_STAGE_BYTES = 32 * 64 * 2;       // 4096 per wave: 32 rows x 6
 constexpr int EDGE_WAVES = DFM_EDGE_WAVES;         // waves per workgroup: 8 = two per SIMD (256 registers each), 4 = one per SIMD (512)
 constexpr int LDS_EDGE_BYTES = LDS_WF_BYTES + EDGE_WAVES * LDS_STAGE_BYTES;   // 163840 = the whole CU with 8 waves
 
+#ifdef DFM_EDGE_NOPK   // experiment: plain f32 instructions instead of packed pairs (build with -fno-slp-vectorize)
+struct f2 { float x, y; };
+__device__ inline f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ inline f2 operator*(f2 a, f2 b) { return {a.x * b.x, a.y * b.y}; }
+#else
 typedef float f2 __attribute__((ext_vector_type(2)));   // packed fp32 pair -> v_pk_{mul,add,fma}_f32 (2 results / instr)
+#endif
 // a + (float)half of a packed fp16 pair in ONE plain-rate instruction (v_fma_mix_f32: f16 source 0 times 1.0 plus f32 source 2);
 // hipcc otherwise emits v_cvt_f32_f16 x2 + v_pk_add_f32, twice the issue time (tools/ubench/valu_rate.hip)
 __device__ inline float add_half_lo(float a, uint32_t h2)
@@ -332,29 +331,344 @@ __device__ inline f2 silu2s(f2 x)
     return x * r;
 }
 
-template <int MODE, int F16>   // MODE 0: edge messages (+ store of gated messages on the last layer), 1: coordinate MLP
-                                 // F16 0: bf16 MFMA operands, 1: fp16 MFMA operands (3 more mantissa bits, same rate)
-__global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
+// -------------------------------------------------------------------------------------------------
+// Message kernel (edge_mlp + attention gate + segment sum; on the last layer also the store of the gated messages of the ligand
+// nodes in the A-fragment order k_edge_coord reads).  Software-pipelined ACROSS tiles: with a per-tile prologue (wait for the edge
+// indices, gather chunk 0, wait, build it, gather chunk 1, wait - about 2.2 k of the 32 k cycles of a tile,
+// profiles/r02_exp_edge_phases.txt) the last chunk of a tile also ran its MFMAs with no producer work beside them.  Here the chunk
+// loop wraps around the tile boundary: chunk 6 requests chunk 0 of the NEXT tile, chunk 7 builds it into the free staging buffer
+// and requests that tile's chunk 1, which flies under this tile's epilogue; the next tile starts straight at its first MFMA.  The
+// wave walks its (node, tile) sequence with a one-tile lookahead; after the last tile the lookahead repeats that tile (valid
+// addresses, results never used) so that the loop body has no tail variant.
+#ifndef DFM_EDGE_DEFER      // requests of the next tile's chunk 1 issued after the epilogue instead of under chunk 7: 0 none, 1 A_i / w_r, 2 + second pass
+#define DFM_EDGE_DEFER 2
+#endif
+template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg(EdgeKArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *Wf = reinterpret_cast<uint4 *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform BY ANALYSIS too: the tile walk below stays in SGPRs
     char *stage = smem + LDS_WF_BYTES + wave * LDS_STAGE_BYTES;
     const int h = lane >> 5, l31 = lane & 31;
     for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
     __syncthreads();
-#ifdef DFM_EDGE_ONE_WAVE_PER_SIMD      // diagnostic: timing of a wave that has its SIMD to itself (results are incomplete)
-    if (MODE == 0 && wave >= EDGE_WAVES / 2) return;
-#endif
-    if constexpr (MODE == 0 && DFM_EDGE_STAGGER > 0) {
-        if (wave >= EDGE_WAVES / 2)
-            for (int z = 0; z < DFM_EDGE_STAGGER; ++z) __builtin_amdgcn_s_sleep(127);
-    }
 
-    // XCD-aware task order (speed only): workgroup g runs on XCD g % 8; give every XCD whole
-    // trajectories so that the gathered rows of Bm stay in that XCD's L2.
+    // XCD-aware task order (speed only): workgroup g runs on XCD g % 8; give every XCD whole trajectories so that the gathered
+    // rows of Bm stay in that XCD's L2; few trajectories (B < 8): each is split over several XCDs
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
-    const int NT = MODE == 0 ? p.N : p.L;                 // node tasks per trajectory
+    // A wave task is a node (its ceil(K / 32) tiles in sequence, segment sum in registers) or - p.split, launches too small to
+    // give every wave a few nodes - a single tile, whose partial segment sum is added to the pre-zeroed agg atomically.  Both
+    // forms produce bitwise the same agg: per tile x_t = inv_s * (sum over its rows), agg = x_0 + x_1 (two addends: commutative).
+    const int K = p.K, ntile = (K + 31) >> 5;
+    const bool split = p.split != 0;
+    const int NT = split ? p.N * ntile : p.N;
+    const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;
+    const int NTc = (NT + nsplit - 1) / nsplit;
+    const int U = p.B * nsplit;
+    const int nb_x = U > xcd ? (U - xcd + 7) >> 3 : 0;
+    const unsigned ntask = (unsigned)nb_x * (unsigned)NTc;
+    const unsigned tstride = (unsigned)wg_per_xcd * EDGE_WAVES;
+    auto task_tile = [&](unsigned tt, int &b, int &i, int &mt) -> bool {      // first tile of task tt
+        const unsigned tq = tt / (unsigned)NTc, tr = tt - tq * (unsigned)NTc;
+        const int u = xcd + 8 * (int)tq;
+        b = __builtin_amdgcn_readfirstlane(u / nsplit);
+        const int idx = __builtin_amdgcn_readfirstlane((u % nsplit) * NTc + (int)tr);
+        i = split ? idx / ntile : idx;
+        mt = split ? idx - i * ntile : 0;
+        return idx < NT;
+    };
+    auto next_task = [&](unsigned &tt, int &b, int &i, int &mt) -> bool {      // first valid task at or after tt
+        while (tt < ntask) {
+            if (task_tile(tt, b, i, mt)) return true;
+            tt += tstride;
+        }
+        return false;
+    };
+    Frag onef;
+    onef.u = make_uint4(h == 0 ? (F16 ? 0x3c003c00u : 0x3f803f80u) : 0u, 0u, 0u, 0u);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(p.T2b), rs_w = make_rsrc(p.w_r);
+    const __amdgpu_buffer_rsrc_t rs_e = make_rsrc(p.edges), rs_c = make_rsrc(p.codes), rs_r = make_rsrc(p.radial);
+    const int r16 = lane >> 2, c4 = lane & 3;
+    const uint32_t oc4 = c4 * 32;
+
+    unsigned tt = (unsigned)slot * EDGE_WAVES + wave;
+    int b = 0, i = 0, mt = 0;
+    if (!next_task(tt, b, i, mt)) return;
+
+    // raw edge data of the tile in lookahead (rows past K read the node's last edge and are masked in set_tile)
+    int jqn[2]; uint32_t codeqn[2]; float radqn[2];
+    auto load_idx = [&](int tb, int ti, int tm) {
+        const uint32_t ebase = ((uint32_t)tb * (uint32_t)p.N + (uint32_t)ti) * (uint32_t)K;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int s = tm * 32 + q * 16 + r16;
+            const uint32_t off = (ebase + (uint32_t)(s < K ? s : K - 1)) * 4u;
+            jqn[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_e, (int)off, 0, 0);
+            codeqn[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)off, 0, 0);
+            radqn[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)off, 0, 0));
+        }
+    };
+    // producer state: gather offsets / resources of the tile whose operands are being REQUESTED, radial of the tile being BUILT
+    uint32_t obm[2], ot0[2], ot1[2], ot2[2];
+    float radq[2], radq_nx[2];
+    __amdgpu_buffer_rsrc_t rs_bm = rs_t, rs_a = rs_t;
+    auto set_tile = [&](int tb, int ti, int tm) {      // from jqn / codeqn / radqn of that tile
+        const size_t ab = (size_t)tb * p.ab_bstride;
+        rs_bm = make_rsrc(p.Bmb + ab); rs_a = make_rsrc(p.A + ab + (size_t)ti * H);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {      // masked rows (>= K): self edge, zero features -> finite values, gate forced to 0
+            const bool v = tm * 32 + q * 16 + r16 < K;
+            const int j = v ? jqn[q] : ti;
+            const uint32_t code = v ? codeqn[q] : 0u;
+            radq_nx[q] = v ? radqn[q] : 0.f;
+            obm[q] = (uint32_t)j * (H * 2) + c4 * 16;
+            ot0[q] = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * (H * 2) + c4 * 16;
+            ot1[q] = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * (H * 2) + c4 * 16;
+            ot2[q] = (1056u + ((code >> 20) & 127u)) * (H * 2) + c4 * 16;
+        }
+    };
+    float4 a0, a1, w0, w1;
+#ifdef DFM_EDGE_NOGATHER      // diagnostic build: the gathered operands are whatever the registers hold (wrong results, no instruction
+                              // issued for them) - the kernel's time with no gather in it
+#define FAKE4(v) asm volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))
+    auto gather_chunk = [&](int) { FAKE4(a0); FAKE4(a1); FAKE4(w0); FAKE4(w1); };
+    auto gather = [&](int, int, RawP &r) { FAKE4(r.bm); FAKE4(r.t0); FAKE4(r.t1); FAKE4(r.t2); };
+#undef FAKE4
+#else
+    auto gather_chunk = [&](int c) {
+        a0 = bload16f(rs_a, oc4, c * 128); a1 = bload16f(rs_a, oc4, c * 128 + 16);
+        w0 = bload16f(rs_w, oc4, c * 128); w1 = bload16f(rs_w, oc4, c * 128 + 16);
+    };
+    auto gather = [&](int c, int q, RawP &r) {
+        r.bm = bload16(rs_bm, obm[q], c * 64);
+        r.t0 = bload16(rs_t, ot0[q], c * 64);
+        r.t1 = bload16(rs_t, ot1[q], c * 64);
+        r.t2 = bload16(rs_t, ot2[q], c * 64);
+    };
+#endif
+    H8 pt, pbm;
+    f2 pv[4];
+    Frag pf;
+    // The producer arithmetic of one pass (8 channels of one row per lane) cut into eight slices, so that it can be laid between
+    // MFMAs in program order: even slice 2e = pre-activation of channel pair e, odd slice 2e + 1 = its SiLU + conversion; slice 7
+    // also stores the finished 16 bytes.
+    auto slice = [&](int q, int k, const RawP &r, char *buf) {
+        const int e = k >> 1;
+        if (k == 0) {
+            H8 t1, t2;
+            pt.u = r.t0; t1.u = r.t1; t2.u = r.t2; pbm.u = r.bm;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                pt.h[x] = __hadd2(__hadd2(pt.h[x], t1.h[x]), t2.h[x]);
+                if constexpr (!F16) pt.h[x] = __hadd2(pt.h[x], pbm.h[x]);
+            }
+        }
+        if ((k & 1) == 0) {
+            const f2 rad2 = {radq[q], radq[q]};
+            const f2 wv = e == 0 ? (f2){w0.x, w0.y} : (e == 1 ? (f2){w0.z, w0.w} : (e == 2 ? (f2){w1.x, w1.y} : (f2){w1.z, w1.w}));
+            const f2 av = e == 0 ? (f2){a0.x, a0.y} : (e == 1 ? (f2){a0.z, a0.w} : (e == 2 ? (f2){a1.x, a1.y} : (f2){a1.z, a1.w}));
+            pv[e] = wv * rad2 + av;
+            if constexpr (F16) pv[e] = add_half2(pv[e], pbm.h[e]);
+            pv[e] = add_half2(pv[e], pt.h[e]);
+        } else {
+            const f2 m = silu2s(pv[e]);
+            if constexpr (F16) { pf.f[2 * e] = (_Float16)fmaxf(m.x, -65504.f); pf.f[2 * e + 1] = (_Float16)fmaxf(m.y, -65504.f); }
+            else { pf.b[2 * e] = (__bf16)m.x; pf.b[2 * e + 1] = (__bf16)m.y; }
+            if (k == 7) {
+                const int row = q * 16 + r16;
+                *reinterpret_cast<uint4 *>(buf + ((c4 * 32 + (row ^ (4 * c4))) << 4)) = pf.u;
+            }
+        }
+    };
+    auto compute_store = [&](int q, const RawP &r, char *buf) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) slice(q, k, r, buf);
+    };
+#ifdef DFM_EDGE_STAMP
+    unsigned long long st_t[5] = {0, 0, 0, 0, 0}, st_prev = 0;
+#define STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _n = __builtin_amdgcn_s_memtime(); st_t[k] += _n - st_prev; st_prev = _n; __builtin_amdgcn_sched_barrier(0); }
+#define STAMP0() { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP(k)
+#define STAMP0()
+#endif
+
+    // ---- the only prologue of the wave: first tile's chunk 0 built, its chunk 1 requested
+    RawP r0, r1;
+    load_idx(b, i, mt);
+    set_tile(b, i, mt);
+    radq[0] = radq_nx[0]; radq[1] = radq_nx[1];
+    gather_chunk(0);
+    gather(0, 0, r0); gather(0, 1, r1);
+    compute_store(0, r0, stage); gather(1, 0, r0);
+    compute_store(1, r1, stage); gather(1, 1, r1);
+    gather_chunk(1);
+
+    float colsum[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) colsum[nt] = 0.f;
+    const float *dot_v = p.att_w;
+
+    while (true) {
+        STAMP0();
+        // the tile after this one (lookahead); none left: this tile again, requested and built but never consumed
+        unsigned ntt = tt;
+        int nb = b, ni = i, nmt = mt + 1;
+        bool have_next = true;
+        if (split || nmt == ntile) {
+            ntt = tt + tstride;
+            have_next = next_task(ntt, nb, ni, nmt);
+        }
+        if (!have_next) { nb = b; ni = i; nmt = mt; }
+
+        f32x16 acc[8];
+        float dv[8];
+        uint32_t bp[8];
+        // one chunk: 16 MFMAs of chunk c; PRODUCE: the arithmetic of the next chunk (chunk 7: chunk 0 of the next tile), one slice after
+        // every MFMA; the loads of the chunk after that go out at the slots DFM_EDGE_G0 / GC / G1; FIRST: opens the accumulators;
+        // LAST: the epilogue's bias operand is requested instead of the (already built) staging being idle
+        auto chunk = [&](int c, auto first, auto last) {
+            char *bufc = stage + (c & 1) * 2048, *bufn = stage + ((c + 1) & 1) * 2048;
+            const int cg = (c + 2) & 7;
+            wave_lds_fence();
+            Frag af[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int un = ks * 2 + h;
+                af[ks].u = *reinterpret_cast<const uint4 *>(bufc + ((un * 32 + (l31 ^ (4 * un))) << 4));
+            }
+            const uint4 *wq = Wf + (size_t)c * 16 * 64 + lane;
+            constexpr int BD = DFM_EDGE_BD;
+            Frag bq[BD];
+#pragma unroll
+            for (int d = 0; d < BD - 1; ++d) bq[d].u = wq[d * 64];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m + BD - 1 < 16) bq[(m + BD - 1) % BD].u = wq[(m + BD - 1) * 64];
+                if constexpr (decltype(first)::value) {
+                    if (m < 8) acc[m] = mfma16<F16>(af[0], bq[m % BD], zero16);
+                    else acc[m & 7] = mfma16<F16>(af[1], bq[m % BD], acc[m & 7]);
+                } else {
+                    acc[m & 7] = mfma16<F16>(af[m >> 3], bq[m % BD], acc[m & 7]);
+                }
+                if constexpr (decltype(last)::value) {
+                    if (m < 8) bp[m] = p.biasp[m * 64 + lane];      // older than this chunk's gathers: the bias step does not wait for them
+                }
+                if (m < 8) slice(0, m & 7, r0, bufn); else slice(1, m & 7, r1, bufn);
+                if (m == DFM_EDGE_G0) gather(cg, 0, r0);
+                if constexpr (!decltype(last)::value || DFM_EDGE_DEFER < 1) { if (m == DFM_EDGE_GC) gather_chunk(cg); }
+                if constexpr (!decltype(last)::value || DFM_EDGE_DEFER < 2) { if (m == DFM_EDGE_G1) gather(cg, 1, r1); }
+                if ((m + 1) % DFM_EDGE_SB == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        chunk(0, std::true_type{}, std::false_type{});
+        load_idx(nb, ni, nmt);            // lands long before chunk 6 needs it
+#pragma unroll 1
+        for (int c = 1; c < 6; ++c) chunk(c, std::false_type{}, std::false_type{});
+        set_tile(nb, ni, nmt);            // requests switch to the next tile (this tile's last gathers went out in chunk 5)
+        chunk(6, std::false_type{}, std::false_type{});     // builds chunk 7 of this tile, requests chunk 0 of the next
+        STAMP(1);
+        radq[0] = radq_nx[0]; radq[1] = radq_nx[1];
+        chunk(7, std::false_type{}, std::true_type{});      // builds chunk 0 of the next tile, requests its chunk 1
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) dv[nt] = dot_v[nt * 32 + l31];
+        // bias k-step: acc += 1 * hi + 1 * lo (the accumulators were opened with C = 0)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            Frag bb;
+            bb.u = make_uint4(bp[nt], 0u, 0u, 0u);
+            acc[nt] = mfma16<F16>(onef, bb, acc[nt]);
+        }
+        STAMP(2);
+
+        // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) = (r & 3) + 8 (r >> 2) + 4 h
+        float part[16];
+        {
+            f2 part2[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) part2[q] = (f2){0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const f2 vv = {dv[nt], dv[nt]};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const f2 m = silu2s((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
+                    acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
+                    part2[q] = m * vv + part2[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { part[2 * q] = part2[q].x; part[2 * q + 1] = part2[q].y; }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] = half_sum_dpp(part[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            part[r] = row < K ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(part[r] + p.att_b)) : 0.f;
+        }
+        if (p.last && i >= p.R) {
+            uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H);
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const int cbase = (((nt * 2 + (l31 >> 4)) * 2 + ((l31 >> 3) & 1)) * 32) * 8 + (l31 & 7);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowin = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    Mout[cbase + rowin * 8] = to16<F16>(acc[nt][r] * part[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            f2 cs = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){part[2 * q], part[2 * q + 1]} + cs;
+            const float t = cs.x + cs.y;
+            colsum[nt] += (t + __shfl_xor(t, 32, 64)) * p.inv_s;      // this tile's x_t (both lane halves)
+        }
+        if (split || mt == ntile - 1) {
+            float *out = p.agg + ((size_t)b * p.N + i) * H + l31;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                if (h == 0) {
+                    if (split) atomicAdd(out + nt * 32, colsum[nt]); else out[nt * 32] = colsum[nt];
+                }
+                colsum[nt] = 0.f;
+            }
+        }
+        STAMP(3);
+        if (!have_next) break;
+        // the rest of the next tile's chunk 1 (kept out of the epilogue's register budget): the second pass is first used at slot 8
+        if constexpr (DFM_EDGE_DEFER >= 2) gather(1, 1, r1);
+        if constexpr (DFM_EDGE_DEFER >= 1) gather_chunk(1);
+        tt = ntt; b = nb; i = ni; mt = nmt;
+    }
+#ifdef DFM_EDGE_STAMP
+    if (p.stamp && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 4; ++k) p.stamp[wave * 4 + k] = st_t[k];
+#endif
+#undef STAMP
+#undef STAMP0
+}
+
+// Coordinate MLP of the last layer (egnn.py:118-137) over the stored gated messages of the ligand nodes: same tile and epilogue
+// layout as the message kernel, the A operand comes straight from HBM in fragment order (no producer).
+template <int F16>   // F16 0: bf16 MFMA operands, 1: fp16 MFMA operands (3 more mantissa bits, same rate)
+__global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_coord(EdgeKArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *Wf = reinterpret_cast<uint4 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
+    __syncthreads();
+
+    // XCD-aware task order (speed only): workgroup g runs on XCD g % 8; give every XCD whole trajectories
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int NT = p.L;                                   // node tasks per trajectory: the ligand nodes
     const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;   // few trajectories: split each over several XCDs
     const int NTc = (NT + nsplit - 1) / nsplit;           // nodes per chunk
     const int U = p.B * nsplit;                           // chunks; chunk u lives on XCD u % 8
@@ -362,7 +676,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
     const unsigned ntask = (unsigned)nb * (unsigned)NTc;
     const unsigned tstride = (unsigned)wg_per_xcd * EDGE_WAVES;
     const int K = p.K, ntile = (K + 31) >> 5;
-    const float *dot_v = MODE == 0 ? p.att_w : p.wc2;     // att_w / wc2 (wc2 pre-divided by SILU_S)
+    const float *dot_v = p.wc2;                           // wc2 pre-divided by SILU_S
 
     // task tt of this XCD -> (trajectory, node); wave-uniform, kept in SGPRs
     auto task_node = [&](unsigned tt, int &b, int &i) -> bool {
@@ -370,252 +684,61 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
         const int u = xcd + 8 * (int)tq;
         b = __builtin_amdgcn_readfirstlane(u / nsplit);
         const int idx = __builtin_amdgcn_readfirstlane((u % nsplit) * NTc + (int)tr);
-        i = (MODE == 0 ? 0 : p.R) + idx;
+        i = p.R + idx;
         return idx < NT;
     };
     // the constant A operand of the bias k-step: (1, 1, 0 ...) in k = 0, 1 of every row; bias = hi + lo in the B operand
     Frag onef;
     onef.u = make_uint4(h == 0 ? (F16 ? 0x3c003c00u : 0x3f803f80u) : 0u, 0u, 0u, 0u);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(p.T2b), rs_w = make_rsrc(p.w_r);
 
-    // edge indices / feature codes / radial of the tile a wave works on next, requested under the current tile's last MFMA
-    // phase so that the first gathers of the next tile do not wait for them (MODE 0)
-    bool pref = false;
-    int jqn[2] = {0, 0}; uint32_t codeqn[2] = {0u, 0u}; float radqn[2] = {0.f, 0.f};
-    const int r16 = lane >> 2, c4 = lane & 3;
-    const __amdgpu_buffer_rsrc_t rs_e = make_rsrc(p.edges), rs_c = make_rsrc(p.codes), rs_r = make_rsrc(p.radial);
-    // raw loads only (rows past K read the node's last edge; they are masked where the values are used): nothing here
-    // depends on the loaded data, so the wave does not wait on them
-    auto load_idx = [&](uint32_t ebase, int mt, int (&jq)[2], uint32_t (&codeq)[2], float (&radq)[2]) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int s = mt * 32 + q * 16 + r16;
-            const uint32_t off = (ebase + (uint32_t)(s < K ? s : K - 1)) * 4u;
-            jq[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_e, (int)off, 0, 0);
-            codeq[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)off, 0, 0);
-            radq[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)off, 0, 0));
-        }
-    };
-#ifdef DFM_EDGE_STAMP
-    // phase timing (diagnostic build): cycles of [prologue | chunks 0-6 | chunk 7 + bias | epilogue] summed over the tiles of a wave
-    unsigned long long st_t[5] = {0, 0, 0, 0, 0}, st_prev = 0;
-#define STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _n = __builtin_amdgcn_s_memtime(); st_t[k] += _n - st_prev; st_prev = _n; __builtin_amdgcn_sched_barrier(0); }
-#define STAMP0() { __builtin_amdgcn_sched_barrier(0); st_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-    unsigned long long st_slot[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_sprev = 0;
-#else
-#define STAMP(k)
-#define STAMP0()
-#endif
     for (unsigned tt = (unsigned)slot * EDGE_WAVES + wave; tt < ntask; tt += tstride) {
         int b, i;
         if (!task_node(tt, b, i)) continue;
         const size_t node = (size_t)b * p.N + i;
         const size_t ebase = node * K;
-        const size_t ab = (size_t)b * p.ab_bstride;
-        float colsum[8];
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) colsum[nt] = 0.f;
-        float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // MODE 1: sum_s cdiff * w
+        float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // sum_s cdiff * w
 
         for (int mt = 0; mt < ntile; ++mt) {
-            STAMP0();
             f32x16 acc[8];
-            float4 c_xi = make_float4(0.f, 0.f, 0.f, 0.f), c_xj = c_xi;     // MODE 1: this node / this lane's neighbour
-            int c_j = 0;
-            float dv[8];        // dot vector of the epilogue, fetched under the last MFMA phase
+            float dv[8];        // dot vector of the epilogue
             uint32_t bp[8];     // packed (hi, lo) bias of this lane's column per n-tile (biasp is [8][64]: lanes 32..63 hold 0)
-
-            if constexpr (MODE == 0) {
-                // ---- interleaved form: a chunk is 32 channels (two MFMA k-steps, 16 MFMAs).  Producer layout: four
-                // adjacent lanes = one row's 64-byte half line, 16 rows per pass, two passes per chunk.  The wave's 4 KiB
-                // of staging are two 2 KiB buffers laid out [unit u = 8-channel group][row ^ 4u] x 16 B (conflict-free
-                // for the producer's writes and the MFMA A-fragment reads); while the MFMAs of chunk c read buffer c & 1,
-                // the arithmetic of chunk c + 1 fills the other one and the gathers of chunk c + 2 are issued.
-                int jq[2]; uint32_t codeq[2]; float radq[2];
-                if (!pref) load_idx((uint32_t)ebase, mt, jqn, codeqn, radqn);
+            // the stored messages of this tile are already in A-fragment order (see the store in k_edge_msg): one contiguous
+            // 1 KiB per wave instruction; all sixteen k-steps of the tile are requested up front (HBM latency, not
+            // MFMA rate, bounds this kernel); rows >= K were stored as zeros
+            const uint4 *Mt = reinterpret_cast<const uint4 *>(p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H)) + lane;
+            uint4 a16[16];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {     // masked rows (>= K): self edge, zero features -> finite values, gate forced to 0
-                    const bool v = mt * 32 + q * 16 + r16 < K;
-                    jq[q] = v ? jqn[q] : i; codeq[q] = v ? codeqn[q] : 0u; radq[q] = v ? radqn[q] : 0.f;
+            for (int kk = 0; kk < 16; ++kk) a16[kk] = Mt[kk * 64];
+            // everything the epilogue needs from memory goes out now too, so that nothing after the MFMAs waits on a load:
+            // bias / dot vector, and the neighbour of this lane's row (edge index first, its coordinates below)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                dv[nt] = dot_v[nt * 32 + l31];
+                bp[nt] = p.biasp[nt * 64 + lane];
+            }
+            const int lrow = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;    // one lane per row (16 rows per half, lanes l31 < 16)
+            const float4 c_xi = p.ca4[node];
+            const int c_j = p.edges[ebase + (lrow < K ? lrow : 0)];
+            float4 c_xj = c_xi;
+            constexpr int CDEPTH = 4;      // weight-fragment LDS reads run three ahead in a static register ring
+            const uint4 *wq = Wf + lane;
+            Frag bq[CDEPTH];
+#pragma unroll
+            for (int d = 0; d < CDEPTH - 1; ++d) bq[d].u = wq[d * 64];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int mm = 0; mm < 32; ++mm) {
+                    const int m = g * 32 + mm;
+                    if (m + CDEPTH - 1 < 128) bq[(m + CDEPTH - 1) % CDEPTH].u = wq[(m + CDEPTH - 1) * 64];
+                    Frag af;
+                    af.u = a16[m >> 3];
+                    if (m < 8) acc[m] = mfma16<F16>(af, bq[m % CDEPTH], zero16);
+                    else acc[m & 7] = mfma16<F16>(af, bq[m % CDEPTH], acc[m & 7]);
                 }
-                // per-lane byte offsets of the four gathered rows of each pass (one VGPR each); the channel chunk goes in
-                // the scalar offset of the buffer load
-                const __amdgpu_buffer_rsrc_t rs_bm = make_rsrc(p.Bmb + ab), rs_a = make_rsrc(p.A + ab + (size_t)i * H);
-                uint32_t obm[2], ot0[2], ot1[2], ot2[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const uint32_t code = codeq[q];
-                    obm[q] = (uint32_t)jq[q] * (H * 2) + c4 * 16;
-                    ot0[q] = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * (H * 2) + c4 * 16;
-                    ot1[q] = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * (H * 2) + c4 * 16;
-                    ot2[q] = (1056u + ((code >> 20) & 127u)) * (H * 2) + c4 * 16;
-                }
-                const uint32_t oc4 = c4 * 32;
-                float4 a0, a1, w0, w1;
-                auto gather_chunk = [&](int c) {
-                    a0 = bload16f(rs_a, oc4, c * 128); a1 = bload16f(rs_a, oc4, c * 128 + 16);
-                    w0 = bload16f(rs_w, oc4, c * 128); w1 = bload16f(rs_w, oc4, c * 128 + 16);
-                };
-                auto gather = [&](int c, int q, RawP &r) {
-                    r.bm = bload16(rs_bm, obm[q], c * 64);
-                    r.t0 = bload16(rs_t, ot0[q], c * 64);
-                    r.t1 = bload16(rs_t, ot1[q], c * 64);
-                    r.t2 = bload16(rs_t, ot2[q], c * 64);
-                };
-                // The producer arithmetic of one pass (8 channels of one row per lane) cut into eight slices, so that it can
-                // be laid between MFMAs in program order: even slice 2e = pre-activation of channel pair e, odd slice
-                // 2e + 1 = its SiLU + conversion; slice 7 also stores the finished 16 bytes.
-                H8 pt, pbm;
-                f2 pv[4];
-                Frag pf;
-                auto slice = [&](int q, int k, const RawP &r, char *buf) {
-                    const int e = k >> 1;
-                    if (k == 0) {
-                        H8 t1, t2;
-                        pt.u = r.t0; t1.u = r.t1; t2.u = r.t2; pbm.u = r.bm;
-#pragma unroll
-                        for (int x = 0; x < 4; ++x) {
-                            pt.h[x] = __hadd2(__hadd2(pt.h[x], t1.h[x]), t2.h[x]);
-                            if constexpr (!F16) pt.h[x] = __hadd2(pt.h[x], pbm.h[x]);
-                        }
-                    }
-                    if ((k & 1) == 0) {
-                        const f2 rad2 = {radq[q], radq[q]};
-                        const f2 wv = e == 0 ? (f2){w0.x, w0.y} : (e == 1 ? (f2){w0.z, w0.w} : (e == 2 ? (f2){w1.x, w1.y} : (f2){w1.z, w1.w}));
-                        const f2 av = e == 0 ? (f2){a0.x, a0.y} : (e == 1 ? (f2){a0.z, a0.w} : (e == 2 ? (f2){a1.x, a1.y} : (f2){a1.z, a1.w}));
-                        pv[e] = wv * rad2 + av;
-                        if constexpr (F16) pv[e] = add_half2(pv[e], pbm.h[e]);
-                        pv[e] = add_half2(pv[e], pt.h[e]);
-                    } else {
-                        const f2 m = silu2s(pv[e]);
-                        if constexpr (F16) { pf.f[2 * e] = (_Float16)fmaxf(m.x, -65504.f); pf.f[2 * e + 1] = (_Float16)fmaxf(m.y, -65504.f); }
-                        else { pf.b[2 * e] = (__bf16)m.x; pf.b[2 * e + 1] = (__bf16)m.y; }
-                        if (k == 7) {
-                            const int row = q * 16 + r16;
-                            *reinterpret_cast<uint4 *>(buf + ((c4 * 32 + (row ^ (4 * c4))) << 4)) = pf.u;
-                        }
-                    }
-                };
-                auto compute_store = [&](int q, const RawP &r, char *buf) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) slice(q, k, r, buf);
-                };
-                RawP r0, r1;
-                gather_chunk(0);
-                gather(0, 0, r0); gather(0, 1, r1);
-                compute_store(0, r0, stage); gather(1, 0, r0);
-                compute_store(1, r1, stage); gather(1, 1, r1);
-                gather_chunk(1);
-                STAMP(0);
-                // one chunk: 16 MFMAs of chunk c; PRODUCE: the arithmetic of chunk c + 1, one slice after every MFMA in
-                // program order with a scheduling barrier behind it; GATHER: the loads of chunk c + 2; FIRST: the chunk that
-                // opens the accumulators (C operand = 0, no accumulator initialisation on the VALU)
-                auto chunk = [&](int c, auto produce, auto gather_next, auto first) {
-                    char *bufc = stage + (c & 1) * 2048, *bufn = stage + ((c + 1) & 1) * 2048;
-                    wave_lds_fence();
-                    Frag af[2];
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const int un = ks * 2 + h;
-                        af[ks].u = *reinterpret_cast<const uint4 *>(bufc + ((un * 32 + (l31 ^ (4 * un))) << 4));
-                    }
-                    const uint4 *wq = Wf + (size_t)c * 16 * 64 + lane;
-                    constexpr int BD = DFM_EDGE_BD;      // weight-fragment reads run BD - 1 MFMAs ahead
-                    Frag bq[BD];
-#pragma unroll
-                    for (int d = 0; d < BD - 1; ++d) bq[d].u = wq[d * 64];
-#pragma unroll
-                    for (int m = 0; m < 16; ++m) {
-#ifdef DFM_EDGE_STAMP
-                        if (c == 3) {    // per-slot timing of one mid-tile chunk
-                            __builtin_amdgcn_sched_barrier(0);
-                            const unsigned long long _n = __builtin_amdgcn_s_memtime();
-                            if (m > 0) st_slot[m] += _n - st_sprev;
-                            st_sprev = _n;
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-#endif
-                        if (m + BD - 1 < 16) bq[(m + BD - 1) % BD].u = wq[(m + BD - 1) * 64];
-                        if constexpr (decltype(first)::value) {
-                            if (m < 8) acc[m] = mfma16<F16>(af[0], bq[m % BD], zero16);
-                            else acc[m & 7] = mfma16<F16>(af[1], bq[m % BD], acc[m & 7]);
-                        } else {
-                            acc[m & 7] = mfma16<F16>(af[m >> 3], bq[m % BD], acc[m & 7]);
-                        }
-                        if constexpr (decltype(produce)::value) {
-                            constexpr int perm[8] = {0, 2, 1, 3, 4, 6, 5, 7};
-                            const int ks = DFM_EDGE_PERM ? perm[m & 7] : (m & 7);
-                            if (m < 8) slice(0, ks, r0, bufn); else slice(1, ks, r1, bufn);
-                            if constexpr (decltype(gather_next)::value) {
-                                if (m == DFM_EDGE_G0) gather(c + 2, 0, r0);
-                                if (m == DFM_EDGE_GC) gather_chunk(c + 2);
-                                if (m == DFM_EDGE_G1) gather(c + 2, 1, r1);
-                            }
-                        } else {
-                            if (m < 8) {
-                                dv[m] = dot_v[m * 32 + l31];
-                                bp[m] = p.biasp[m * 64 + lane];     // plain loads: nothing waits on them before the bias k-step
-                            }
-                        }
-                        if ((m + 1) % DFM_EDGE_SB == 0) __builtin_amdgcn_sched_barrier(0);
-                    }
-                };
-                chunk(0, std::true_type{}, std::true_type{}, std::true_type{});
-#pragma unroll 1
-                for (int c = 1; c < 6; ++c) chunk(c, std::true_type{}, std::true_type{}, std::false_type{});
-                // indices of the tile this wave works on next (the second tile of this node, or the first tile of its next task),
-                // requested two chunks before anything younger is waited for: by the time the epilogue constants below are
-                // needed (the vector-memory counter is in order) they have landed
-                {
-                    int nb2 = b, ni = i, nmt = mt + 1;
-                    bool nvalid = true;
-                    if (nmt == ntile) { nmt = 0; nvalid = tt + tstride < ntask && task_node(tt + tstride, nb2, ni); }
-                    pref = nvalid;
-                    if (nvalid) load_idx(((uint32_t)nb2 * (uint32_t)p.N + (uint32_t)ni) * (uint32_t)K, nmt, jqn, codeqn, radqn);
-                }
-                chunk(6, std::true_type{}, std::false_type{}, std::false_type{});
-                STAMP(1);
-                chunk(7, std::false_type{}, std::false_type{}, std::false_type{});
-            } else {
-                // the stored messages of this tile are already in A-fragment order (see the store below): one contiguous
-                // 1 KiB per wave instruction; all sixteen k-steps of the tile are requested up front (HBM latency, not
-                // MFMA rate, bounds this kernel); rows >= K were stored as zeros
-                const uint4 *Mt = reinterpret_cast<const uint4 *>(p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H)) + lane;
-                uint4 a16[16];
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) a16[kk] = Mt[kk * 64];
-                // everything the epilogue needs from memory goes out now too, so that nothing after the MFMAs waits on a load:
-                // bias / dot vector, and the neighbour of this lane's row (edge index first, its coordinates below)
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    dv[nt] = dot_v[nt * 32 + l31];
-                    bp[nt] = p.biasp[nt * 64 + lane];
-                }
-                {
-                    const int row = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;
-                    c_xi = p.ca4[(size_t)b * p.N + i];
-                    c_j = p.edges[ebase + (row < K ? row : 0)];
-                }
-                constexpr int CDEPTH = 4;      // weight-fragment LDS reads run three ahead in a static register ring
-                const uint4 *wq = Wf + lane;
-                Frag bq[CDEPTH];
-#pragma unroll
-                for (int d = 0; d < CDEPTH - 1; ++d) bq[d].u = wq[d * 64];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                    for (int mm = 0; mm < 32; ++mm) {
-                        const int m = g * 32 + mm;
-                        if (m + CDEPTH - 1 < 128) bq[(m + CDEPTH - 1) % CDEPTH].u = wq[(m + CDEPTH - 1) * 64];
-                        Frag af;
-                        af.u = a16[m >> 3];
-                        if (m < 8) acc[m] = mfma16<F16>(af, bq[m % CDEPTH], zero16);
-                        else acc[m & 7] = mfma16<F16>(af, bq[m % CDEPTH], acc[m & 7]);
-                    }
-                    if (g == 0) c_xj = p.ca4[(size_t)b * p.N + c_j];     // the edge index has landed under the first 32 MFMAs
-                    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next group's reads (spills)
-                }
+                if (g == 0) c_xj = p.ca4[(size_t)b * p.N + c_j];     // the edge index has landed under the first 32 MFMAs
+                __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next group's reads (spills)
             }
             // bias k-step: acc += 1 * hi + 1 * lo (the accumulators were opened with C = 0)
 #pragma unroll
@@ -624,9 +747,8 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
                 bb.u = make_uint4(bp[nt], 0u, 0u, 0u);
                 acc[nt] = mfma16<F16>(onef, bb, acc[nt]);
             }
-            STAMP(2);
 
-            // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) -------------
+            // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r): w = sum_c silu(.) * wc2
             float part[16];
             {
                 f2 part2[8];
@@ -638,7 +760,6 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const f2 m = silu2s((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
-                        acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
                         part2[q] = m * vv + part2[q];
                     }
                 }
@@ -647,80 +768,31 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_bf16(EdgeKArgs p)
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) part[r] = half_sum_dpp(part[r]);   // all 32 lanes of the half hold the row sum
-
-            if (MODE == 0) {
+            // coord_mlp: w = clamp(sum_c silu(.) * wc2, +-2); x_i += mean_s (x_i - x_j)/(|x_i - x_j| + 1) * w
+            // one lane per row (lane l31 < 16 takes register row r = l31), so the 32 edge-index / coordinate loads of a tile
+            // are issued together instead of as a 16-long dependent chain in one lane
+            float w = part[0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    // attention gate sigmoid(logit) = 1 / (1 + exp2(S logit)); part = S * (att_w . m2), att_b pre-scaled
-                    part[r] = row < K ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(part[r] + p.att_b)) : 0.f;
-                }
-                const bool store_m = p.last && i >= p.R;
-                if (store_m) {
-                    // A-fragment order of the coordinate-MLP kernel: [k-step 16][lane half 2][row 32][8 channels] per tile
-                    uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H);
-#pragma unroll
-                    for (int nt = 0; nt < 8; ++nt) {
-                        const int cbase = (((nt * 2 + (l31 >> 4)) * 2 + ((l31 >> 3) & 1)) * 32) * 8 + (l31 & 7);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int rowin = (r & 3) + 8 * (r >> 2) + 4 * h;
-                            Mout[cbase + rowin * 8] = to16<F16>(acc[nt][r] * part[r]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    f2 cs = {0.f, 0.f};
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) cs = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){part[2 * q], part[2 * q + 1]} + cs;
-                    colsum[nt] += cs.x + cs.y;
-                }
-            } else {
-                // coord_mlp: w = clamp(sum_c silu(.) * wc2, +-2); x_i += mean_s (x_i - x_j)/(|x_i - x_j| + 1) * w
-                // one lane per row (16 rows per half: lane l31 < 16 takes register row r = l31), so the 32 edge-index /
-                // coordinate loads of a tile are issued together instead of as a 16-long dependent chain in one lane
-                float w = part[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) w = l31 == r ? part[r] : w;
-                const int row = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;
-                if (l31 < 16 && row < K) {
-                    const float4 xi = c_xi, xj = c_xj;
-                    w = fminf(fmaxf(w, -2.0f), 2.0f);
-                    const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-                    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f) + 1.0f;
-                    cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;
-                }
+            for (int r = 1; r < 16; ++r) w = l31 == r ? part[r] : w;
+            if (l31 < 16 && lrow < K) {
+                const float4 xi = c_xi, xj = c_xj;
+                w = fminf(fmaxf(w, -2.0f), 2.0f);
+                const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+                const float nrm = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f) + 1.0f;
+                cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;
             }
-            STAMP(3);
         }   // mt
 
-        if (MODE == 0) {
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const float t = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
-                if (h == 0) p.agg[node * H + nt * 32 + l31] = t * p.inv_s;
-            }
-        } else {
-            cacc0 = wave_sum(cacc0); cacc1 = wave_sum(cacc1); cacc2 = wave_sum(cacc2);
-            if (lane == 0) {
-                const float4 xi = p.ca4[node];
-                const float inv = 1.0f / (float)(K > 1 ? K : 1);
-                float *fo = p.fout + ((size_t)b * p.L + (i - p.R)) * 3;
-                fo[0] = (xi.x + cacc0 * inv) - xi.x;
-                fo[1] = (xi.y + cacc1 * inv) - xi.y;
-                fo[2] = (xi.z + cacc2 * inv) - xi.z;
-            }
+        cacc0 = wave_sum(cacc0); cacc1 = wave_sum(cacc1); cacc2 = wave_sum(cacc2);
+        if (lane == 0) {
+            const float4 xi = p.ca4[node];
+            const float inv = 1.0f / (float)(K > 1 ? K : 1);
+            float *fo = p.fout + ((size_t)b * p.L + (i - p.R)) * 3;
+            fo[0] = (xi.x + cacc0 * inv) - xi.x;
+            fo[1] = (xi.y + cacc1 * inv) - xi.y;
+            fo[2] = (xi.z + cacc2 * inv) - xi.z;
         }
     }
-#ifdef DFM_EDGE_STAMP
-    if (p.stamp && blockIdx.x == 0 && lane == 0) {
-        for (int k = 0; k < 4; ++k) p.stamp[wave * 4 + k] = st_t[k];
-        if (wave == 0) for (int k = 0; k < 16; ++k) p.stamp[32 + k] = st_slot[k];
-    }
-#endif
-#undef STAMP
-#undef STAMP0
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -735,7 +807,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.w_r = w->w_r; k.T = w->T; k.W2t = w->W2t; k.b2 = w->b2; k.att_w = w->att_w; k.T2b = w->T2b;
     k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
-    k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.stamp = a.stamp;
+    k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.stamp = a.stamp; k.split = 0;
     return k;
 }
 // the 16-bit MFMA kernels take the -log2(e)-scaled operands (SILU_S, api.hip)
@@ -773,29 +845,54 @@ static int persistent_grid(long long wave_tasks)
     return (int)g;
 }
 
-template <int MODE, int F16> static hipError_t launch_mfma_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
+template <int F16> static hipError_t launch_msg_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
 {
     static std::atomic<bool> attr_done[MAX_DEVICES];
     {
-        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_bf16<MODE, F16>), LDS_EDGE_BYTES, attr_done);
+        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_msg<F16>), LDS_EDGE_BYTES, attr_done);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_edge_bf16<MODE, F16>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
+    hipLaunchKernelGGL((k_edge_msg<F16>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
+    return hipGetLastError();
+}
+template <int F16> static hipError_t launch_coord_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
+{
+    static std::atomic<bool> attr_done[MAX_DEVICES];
+    {
+        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_coord<F16>), LDS_EDGE_BYTES, attr_done);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_edge_coord<F16>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
     return hipGetLastError();
 }
 
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    const EdgeKArgs k = to_kargs_mfma(a, 0);
-    const long long tasks = (long long)a.B * a.N;
-    return a.f16 ? launch_mfma_t<0, 1>(k, tasks, s) : launch_mfma_t<0, 0>(k, tasks, s);
+    EdgeKArgs k = to_kargs_mfma(a, 0);
+    long long tasks = (long long)a.B * a.N;
+    // Small launches: with one node (two tiles) per task the last round of the persistent grid is mostly idle - e.g. B = 8 at
+    // N = 600: 4800 nodes over 2048 waves = 3 rounds of 2 tiles, but 9600 tiles = 5 rounds of 1.  Tile tasks when that saves a round.
+    const int ntile = (a.K + 31) / 32;
+    if (ntile > 1) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        const long long waves = (long long)cus * EDGE_WAVES;
+        const long long rounds_node = (tasks + waves - 1) / waves * ntile, rounds_tile = (tasks * ntile + waves - 1) / waves;
+        static const int env = [] { const char *e = getenv("DFM_EDGE_SPLIT"); return e ? atoi(e) : -1; }();      // diagnostics: 0 / 1 force
+        if (env >= 0 ? env != 0 : rounds_tile < rounds_node) {
+            k.split = 1; tasks *= ntile;
+            hipError_t e = hipMemsetAsync(a.agg, 0, (size_t)a.B * a.N * H * sizeof(float), s);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return a.f16 ? launch_msg_t<1>(k, tasks, s) : launch_msg_t<0>(k, tasks, s);
 }
 
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
 {
     const EdgeKArgs k = to_kargs_mfma(a, 1);
     const long long tasks = (long long)a.B * (a.N - a.R);
-    return a.f16 ? launch_mfma_t<1, 1>(k, tasks, s) : launch_mfma_t<1, 0>(k, tasks, s);
+    return a.f16 ? launch_coord_t<1>(k, tasks, s) : launch_coord_t<0>(k, tasks, s);
 }
 
 }  // namespace dfm

@@ -18,7 +18,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
          "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
          "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1-2 | tr ' ' '_')
-  ( cd /tmp && timeout 240 rocprofv3 --pmc $c --kernel-include-regex 'k_edge_bf16<0' --output-format csv -d $OUT/pmc -o $n -- $CMD > $OUT/pmc/$n.log 2>&1 ) || echo "pass $c failed/timeout"
+  ( cd /tmp && timeout 240 rocprofv3 --pmc $c --kernel-include-regex 'k_edge_msg<' --output-format csv -d $OUT/pmc -o $n -- $CMD > $OUT/pmc/$n.log 2>&1 ) || echo "pass $c failed/timeout"
 done
 python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_edge.txt 2>&1; cat $OUT/pmc_edge.txt
 prof c5 python $GRAFT_REPO_ROOT/bench.py --R 1000 --L 1000 --batch 32 --steps 1 --warmup 1 --no-cpu-baseline; tail -1 $OUT/c5.log | cut -c1-200; head -8 $OUT/c5_kernel_stats.csv | cut -c1-160

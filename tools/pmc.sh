@@ -4,7 +4,7 @@ set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc; mkdir -p $OUT
 CMD="python bench.py --steps 1 --warmup 0 --batch ${PMC_BATCH:-64} --num-steps ${PMC_STEPS:-4} --no-cpu-baseline"
-KR='k_edge_bf16<0'
+KR='k_edge_msg<'
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \

@@ -7,6 +7,6 @@ OUT=gpurun_out/pmc_traffic; rm -rf $OUT; mkdir -p $OUT
 CMD="python bench.py --steps 1 --warmup 0 --batch 256 --num-steps 3 --no-cpu-baseline"
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" GRBM_GUI_ACTIVE; do
   n=$(echo $c | tr ' ' '_')
-  timeout 240 rocprofv3 --pmc $c --kernel-include-regex 'k_edge_bf16<0' --output-format csv -d $OUT -o $n -- $CMD > $OUT/$n.log 2>&1 || echo "pass $c failed/timeout"
+  timeout 240 rocprofv3 --pmc $c --kernel-include-regex 'k_edge_msg<' --output-format csv -d $OUT -o $n -- $CMD > $OUT/$n.log 2>&1 || echo "pass $c failed/timeout"
 done
 python tools/pmc_summary.py $OUT
