@@ -427,6 +427,10 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
             ot0[q] = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * (H * 2) + c4 * 16;
             ot1[q] = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * (H * 2) + c4 * 16;
             ot2[q] = (1056u + ((code >> 20) & 127u)) * (H * 2) + c4 * 16;
+#ifdef DFM_EDGE_SAMEROW      // diagnostic builds: rows gather row 0 (wrong results; loads issued, L1 hits): 1 everything, 2 Bm only, 3 tables only
+            if (DFM_EDGE_SAMEROW != 3) obm[q] = (obm[q] & 1u) + c4 * 16;
+            if (DFM_EDGE_SAMEROW != 2) { ot0[q] = (ot0[q] & 1u) + c4 * 16; ot1[q] = (ot1[q] & 1u) + c4 * 16; ot2[q] = (ot2[q] & 1u) + c4 * 16; }
+#endif
         }
     };
     float4 a0, a1, w0, w1;
@@ -627,7 +631,11 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
 #pragma unroll
             for (int q = 0; q < 8; ++q) cs = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){part[2 * q], part[2 * q + 1]} + cs;
             const float t = cs.x + cs.y;
-            colsum[nt] += (t + __shfl_xor(t, 32, 64)) * p.inv_s;      // this tile's x_t (both lane halves)
+            // this tile's x_t (both lane halves); rounded on its own (the empty asm keeps hipcc from contracting the product into
+            // an fma with the running sum) so that node tasks and tile tasks add the same two numbers
+            float xt = (t + __shfl_xor(t, 32, 64)) * p.inv_s;
+            asm volatile("" : "+v"(xt));
+            colsum[nt] += xt;
         }
         if (split || mt == ntile - 1) {
             float *out = p.agg + ((size_t)b * p.N + i) * H + l31;

@@ -9,10 +9,12 @@
   GraphNorm with |mean| >> std
   Score_Model.complex_for    a second ligand pose / a re-centred receptor must never be served from a stale complex
 """
+import os
+
 import numpy as np
 import pytest
 
-from conftest import complex_for, load_golden, pair_hparams
+from conftest import ROOT, complex_for, load_golden, pair_hparams
 
 pytestmark = pytest.mark.gpu
 
@@ -245,3 +247,34 @@ def test_score_model_never_serves_a_stale_complex(blob):
     batch["rec_x"] = batch["rec_x"] * 1.0001
     m(batch)
     assert m._cx is not handle
+
+
+def test_tile_tasks_equal_node_tasks_bitwise(tmp_path):
+    """k_edge_msg hands a wave whole nodes (segment sum in registers) or - small launches - single tiles (partial sums added
+    atomically to the zeroed agg).  Two addends per element: both forms must give bitwise the same score, also across batch sizes
+    (DFM_EDGE_SPLIT forces the form; it is read once per process, hence the subprocesses)."""
+    import subprocess, sys, textwrap
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {ROOT!r})
+        from dfmdock_amd import engine
+        from dfmdock_amd.synthetic import make_complex
+        from dfmdock_amd.weights import make_random_weights, pack_blob
+        engine.set_device(0)
+        model = engine.Model(pack_blob(make_random_weights(0)))
+        cx = make_complex(120, 94, seed=3)
+        gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+        B = int(sys.argv[2])
+        r = gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.5, seed=5, bf16=True, energy=True, debug=True)
+        np.savez(sys.argv[1], **{{k: r[k][0] for k in ("f", "tr_score", "rot_score", "energy", "edges", "h_first", "h_last")}})
+    """))
+    outs = {}
+    for tag, env, B in (("node1", "0", 1), ("tile1", "1", 1), ("node9", "0", 9), ("tile9", "1", 9)):
+        p = subprocess.run([sys.executable, str(script), str(tmp_path / f"{tag}.npz"), str(B)], env=dict(os.environ, DFM_EDGE_SPLIT=env),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()[-2000:]
+        outs[tag] = np.load(tmp_path / f"{tag}.npz")
+    for tag in ("tile1", "node9", "tile9"):
+        for k in outs["node1"].files:
+            assert (outs[tag][k] == outs["node1"][k]).all(), (tag, k)
