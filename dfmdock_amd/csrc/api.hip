@@ -337,6 +337,21 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
         // merged fp16 tables of the 16-bit MFMA kernel, pre-multiplied by SILU_S like every other SiLU input there
         const double S = (double)SILU_S;
         std::vector<uint16_t> T2b((size_t)NTAB2 * H);
+#if DFM_TAB_MERGE
+        for (int om = 0; om < 24; ++om)
+            for (int th = 0; th < 24; ++th)
+                for (int ph = 0; ph < 12; ++ph) {
+                    uint16_t *row = &T2b[(size_t)((om * 24 + th) * 12 + ph) * H];
+                    const double *a = &Td[(size_t)(40 + om) * H], *b = &Td[(size_t)(64 + th) * H], *c3 = &Td[(size_t)(88 + ph) * H];
+                    for (int c = 0; c < H; ++c) row[c] = f2h((float)(S * (a[c] + b[c] + c3[c])));
+                }
+        for (int rp = 0; rp < 66; ++rp)
+            for (int d = 0; d < 40; ++d) {
+                uint16_t *row = &T2b[(size_t)(6912 + rp * 40 + d) * H];
+                const double *a = &Td[(size_t)(100 + rp) * H], *b = &Td[(size_t)d * H];
+                for (int c = 0; c < H; ++c) row[c] = f2h((float)(S * (a[c] + b[c])));
+            }
+#else
         for (int c = 0; c < H; ++c) {
             for (int om = 0; om < 24; ++om)
                 for (int th = 0; th < 24; ++th)
@@ -346,6 +361,7 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
                     T2b[(size_t)(576 + ph * 40 + d) * H + c] = f2h((float)(S * (Td[(size_t)(88 + ph) * H + c] + Td[(size_t)d * H + c])));
             for (int rp = 0; rp < 66; ++rp) T2b[(size_t)(1056 + rp) * H + c] = f2h((float)(S * Td[(size_t)(100 + rp) * H + c]));
         }
+#endif
         {
             std::vector<float> wrs(H), babs(2 * H), wc2s(H);
             for (int c = 0; c < H; ++c) wrs[c] = SILU_S * w_r[c];

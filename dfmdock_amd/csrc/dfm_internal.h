@@ -28,18 +28,26 @@ __host__ __device__ inline uint32_t pack_code(int d, int om, int th, int ph, int
 // channel handled by (k-step kk, lane-half h, element e) of the bf16 MFMA operands (natural order)
 __host__ __device__ inline int frag_channel(int kk, int h, int e) { return kk * 16 + h * 8 + e; }
 
-// merged edge-feature tables of the bf16-MFMA kernel (stored as fp16): 3 row gathers instead of 5
-//   [0, 576)     omega*24 + theta   = T[40+omega] + T[64+theta]
-//   [576, 1056)  576 + phi*40 + d   = T[88+phi]   + T[d]
-//   [1056, 1122) 1056 + relpos      = T[100+relpos]
-constexpr int NTAB2 = 576 + 480 + 66;
+// merged edge-feature tables of the 16-bit MFMA kernel (stored as fp16): row gathers per edge and 32-channel chunk instead of 5.
+// DFM_TAB_MERGE 1 (two gathers; 4.9 MB per layer, but the angle bins are zeroed beyond 22 A and most sequence offsets saturate,
+// so the rows actually touched are few):
+//   [0, 6912)     (omega*24 + theta)*12 + phi   = T[40+omega] + T[64+theta] + T[88+phi]
+//   [6912, 9552)  6912 + relpos*40 + d          = T[100+relpos] + T[d]
+// DFM_TAB_MERGE 0 (three gathers, 574 KiB per layer):
+//   [0, 576)      omega*24 + theta              = T[40+omega] + T[64+theta]
+//   [576, 1056)   576 + phi*40 + d              = T[88+phi]   + T[d]
+//   [1056, 1122)  1056 + relpos                 = T[100+relpos]
+#ifndef DFM_TAB_MERGE
+#define DFM_TAB_MERGE 1
+#endif
+constexpr int NTAB2 = DFM_TAB_MERGE ? 6912 + 2640 : 576 + 480 + 66;
 
 struct LayerDev {
     float *Wab;       // [512][256]   rows 0..255 = edge_mlp.0.weight[:, 0:256] (h_i), 256..511 = [:, 256:512] (h_j)
     float *bias_ab;   // [512]        [edge_mlp.0.bias ; 0]
     float *w_r;       // [256]        edge_mlp.0.weight[:, 512] (radial column)
     float *T;         // [166][256]   T = ([S|P]^T We^T): per-layer edge-feature lookup table, fp32
-    uint16_t *T2b;    // [1122][256]  merged tables (see NTAB2), fp16
+    uint16_t *T2b;    // [NTAB2][256]  merged tables (see NTAB2), fp16
     float *W2t;       // [256 in][256 out] edge_mlp.2.weight transposed (fp32 kernel)
     uint16_t *W2f;    // [16][8][64][8] bf16 MFMA B-fragments of edge_mlp.2.weight
     uint16_t *W2f16;  // same, fp16

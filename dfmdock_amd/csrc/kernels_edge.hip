@@ -281,7 +281,11 @@ __device__ inline float half_sum_dpp(float v)
 // make every earlier LDS access of this wave visible/ordered before later ones (wave-private staging tile)
 __device__ inline void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-struct RawP { uint4 bm, t0, t1, t2; };        // gathered fp16 operands of one producer pass (8 channels of one row)
+#if DFM_TAB_MERGE
+struct RawP { uint4 bm, t0, t1; };            // gathered fp16 operands of one producer pass (8 channels of one row)
+#else
+struct RawP { uint4 bm, t0, t1, t2; };
+#endif
 
 // one MFMA step on bf16 (F16 = 0) or fp16 (F16 = 1) operands, fp32 accumulate - same rate on gfx950
 template <int F16> __device__ inline f32x16 mfma16(const Frag &a, const Frag &b, f32x16 c)
@@ -411,7 +415,10 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
         }
     };
     // producer state: gather offsets / resources of the tile whose operands are being REQUESTED, radial of the tile being BUILT
-    uint32_t obm[2], ot0[2], ot1[2], ot2[2];
+    uint32_t obm[2], ot0[2], ot1[2];
+#if !DFM_TAB_MERGE
+    uint32_t ot2[2];
+#endif
     float radq[2], radq_nx[2];
     __amdgpu_buffer_rsrc_t rs_bm = rs_t, rs_a = rs_t;
     auto set_tile = [&](int tb, int ti, int tm) {      // from jqn / codeqn / radqn of that tile
@@ -424,12 +431,22 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
             const uint32_t code = v ? codeqn[q] : 0u;
             radq_nx[q] = v ? radqn[q] : 0.f;
             obm[q] = (uint32_t)j * (H * 2) + c4 * 16;
+#if DFM_TAB_MERGE
+            ot0[q] = ((((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * 12u + ((code >> 16) & 15u)) * (H * 2) + c4 * 16;
+            ot1[q] = (6912u + ((code >> 20) & 127u) * 40u + (code & 63u)) * (H * 2) + c4 * 16;
+#else
             ot0[q] = (((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * (H * 2) + c4 * 16;
             ot1[q] = (576u + ((code >> 16) & 15u) * 40u + (code & 63u)) * (H * 2) + c4 * 16;
             ot2[q] = (1056u + ((code >> 20) & 127u)) * (H * 2) + c4 * 16;
+#endif
 #ifdef DFM_EDGE_SAMEROW      // diagnostic builds: rows gather row 0 (wrong results; loads issued, L1 hits): 1 everything, 2 Bm only, 3 tables only
             if (DFM_EDGE_SAMEROW != 3) obm[q] = (obm[q] & 1u) + c4 * 16;
-            if (DFM_EDGE_SAMEROW != 2) { ot0[q] = (ot0[q] & 1u) + c4 * 16; ot1[q] = (ot1[q] & 1u) + c4 * 16; ot2[q] = (ot2[q] & 1u) + c4 * 16; }
+            if (DFM_EDGE_SAMEROW != 2) {
+                ot0[q] = (ot0[q] & 1u) + c4 * 16; ot1[q] = (ot1[q] & 1u) + c4 * 16;
+#if !DFM_TAB_MERGE
+                ot2[q] = (ot2[q] & 1u) + c4 * 16;
+#endif
+            }
 #endif
         }
     };
@@ -438,7 +455,7 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
                               // issued for them) - the kernel's time with no gather in it
 #define FAKE4(v) asm volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))
     auto gather_chunk = [&](int) { FAKE4(a0); FAKE4(a1); FAKE4(w0); FAKE4(w1); };
-    auto gather = [&](int, int, RawP &r) { FAKE4(r.bm); FAKE4(r.t0); FAKE4(r.t1); FAKE4(r.t2); };
+    auto gather = [&](int, int, RawP &r) { FAKE4(r.bm); FAKE4(r.t0); FAKE4(r.t1); };
 #undef FAKE4
 #else
     auto gather_chunk = [&](int c) {
@@ -449,7 +466,9 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
         r.bm = bload16(rs_bm, obm[q], c * 64);
         r.t0 = bload16(rs_t, ot0[q], c * 64);
         r.t1 = bload16(rs_t, ot1[q], c * 64);
+#if !DFM_TAB_MERGE
         r.t2 = bload16(rs_t, ot2[q], c * 64);
+#endif
     };
 #endif
     H8 pt, pbm;
@@ -461,11 +480,18 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
     auto slice = [&](int q, int k, const RawP &r, char *buf) {
         const int e = k >> 1;
         if (k == 0) {
-            H8 t1, t2;
-            pt.u = r.t0; t1.u = r.t1; t2.u = r.t2; pbm.u = r.bm;
+            H8 t1;
+            pt.u = r.t0; t1.u = r.t1; pbm.u = r.bm;
+#if !DFM_TAB_MERGE
+            H8 t2;
+            t2.u = r.t2;
+#endif
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                pt.h[x] = __hadd2(__hadd2(pt.h[x], t1.h[x]), t2.h[x]);
+                pt.h[x] = __hadd2(pt.h[x], t1.h[x]);
+#if !DFM_TAB_MERGE
+                pt.h[x] = __hadd2(pt.h[x], t2.h[x]);
+#endif
                 if constexpr (!F16) pt.h[x] = __hadd2(pt.h[x], pbm.h[x]);
             }
         }
