@@ -293,6 +293,16 @@ template <int F16> __device__ inline f32x16 mfma16(const Frag &a, const Frag &b,
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.f, b.f, c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b, b.b, c, 0, 0, 0);
 }
+// two fp32 -> packed fp16 (round to nearest even), -inf / below -65504 clamped to -65504 by ONE packed max on the converted pair
+// (the values on this path are S * silu(.) [* gate]: bounded above by 0.41, unbounded below; no NaN from finite inputs)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t pack_f16_sat_lo(float a, float b)
+{
+    f16x2 v = {(_Float16)a, (_Float16)b};
+    const f16x2 lo = {(_Float16)-65504.f, (_Float16)-65504.f};
+    v = __builtin_elementwise_max(v, lo);
+    return __builtin_bit_cast(uint32_t, v);
+}
 template <int F16> __device__ inline uint16_t to16(float x)
 {
     if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)fminf(fmaxf(x, -65504.f), 65504.f));
@@ -344,6 +354,9 @@ __device__ inline f2 silu2s(f2 x)
 // and requests that tile's chunk 1, which flies under this tile's epilogue; the next tile starts straight at its first MFMA.  The
 // wave walks its (node, tile) sequence with a one-tile lookahead; after the last tile the lookahead repeats that tile (valid
 // addresses, results never used) so that the loop body has no tail variant.
+#ifndef DFM_EDGE_MSTORE_LDS   // last layer: gated messages transposed through the wave's staging buffer (1) or stored as 2-byte scatters (0)
+#define DFM_EDGE_MSTORE_LDS 1
+#endif
 #ifndef DFM_EDGE_DEFER      // requests of the next tile's chunk 1 issued after the epilogue instead of under chunk 7: 0 none, 1 A_i / w_r, 2 + second pass
 #define DFM_EDGE_DEFER 2
 #endif
@@ -504,7 +517,7 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
             pv[e] = add_half2(pv[e], pt.h[e]);
         } else {
             const f2 m = silu2s(pv[e]);
-            if constexpr (F16) { pf.f[2 * e] = (_Float16)fmaxf(m.x, -65504.f); pf.f[2 * e + 1] = (_Float16)fmaxf(m.y, -65504.f); }
+            if constexpr (F16) { (&pf.u.x)[e] = pack_f16_sat_lo(m.x, m.y); }
             else { pf.b[2 * e] = (__bf16)m.x; pf.b[2 * e + 1] = (__bf16)m.y; }
             if (k == 7) {
                 const int row = q * 16 + r16;
@@ -640,6 +653,42 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
             part[r] = row < K ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(part[r] + p.att_b)) : 0.f;
         }
         if (p.last && i >= p.R) {
+            // Gated messages of a ligand node in the A-fragment order k_edge_coord reads: [k-step 16][lane half 2][row 32][8 channels].
+            // An n-tile (32 channels) is one contiguous 2 KiB of that: 4 units (k-step, half) x 32 rows x 16 B.  A lane owns ONE
+            // channel of 16 rows, so direct stores are 128 two-byte stores per tile (~100 cycles of issue each); instead every n-tile
+            // goes through the wave's free staging buffer (buffer 1: chunk 7 has consumed it, buffer 0 already holds the next tile's
+            // chunk 0): 16 ds_write_b16 (unit u, row ^ u: conflict-free), then two 16-byte reads + fully coalesced 16-byte stores.
+#if DFM_EDGE_MSTORE_LDS
+            char *tb = stage + 2048;
+            uint4 *Mout = reinterpret_cast<uint4 *>(p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H));
+            const int u = l31 >> 3;
+            int wbase[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) wbase[x] = u * 512 + ((x ^ u) + 4 * h) * 16 + (l31 & 7) * 2;
+            int rd[2];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int unit = lane + 64 * k2, uu = unit >> 5, row = unit & 31;
+                rd[k2] = uu * 512 + (row ^ uu) * 16;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float g0 = acc[nt][r] * part[r], g1 = acc[nt][r + 1] * part[r + 1];
+                    uint32_t pk;
+                    if constexpr (F16) pk = pack_f16_sat_lo(g0, g1);
+                    else pk = (uint32_t)to16<0>(g0) | ((uint32_t)to16<0>(g1) << 16);
+                    *reinterpret_cast<uint16_t *>(tb + wbase[r & 3] + (r >> 2) * 128) = (uint16_t)pk;
+                    *reinterpret_cast<uint16_t *>(tb + wbase[(r + 1) & 3] + (r >> 2) * 128) = (uint16_t)(pk >> 16);
+                }
+                wave_lds_fence();
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(tb + rd[0]), v1 = *reinterpret_cast<const uint4 *>(tb + rd[1]);
+                wave_lds_fence();      // the reads have returned before the next n-tile overwrites the buffer
+                Mout[nt * 128 + lane] = v0;
+                Mout[nt * 128 + 64 + lane] = v1;
+            }
+#else
             uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H);
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
@@ -650,6 +699,7 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
                     Mout[cbase + rowin * 8] = to16<F16>(acc[nt][r] * part[r]);
                 }
             }
+#endif
         }
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
