@@ -278,6 +278,37 @@ __device__ inline float half_sum_dpp(float v)
     return v;
 }
 
+// Row sums over the 32 lanes of a half as a REDUCE-SCATTER: v[0..15] are this lane's partial sums of 16 rows; each butterfly step
+// (lane ^ 1, ^ 2 by DPP; ^ 4, ^ 8 by ds_swizzle) halves the values a lane carries - the lane keeps the half its bit selects and
+// sends the other - and a last step (^ 16) adds the two 16-lane rows.  46 VALU instructions instead of the 80 of sixteen
+// all-reduces, and lane l ends with the ONE sum of row index rs_index(l): whatever follows per row (the attention gate's
+// exp / rcp) runs once per lane instead of sixteen times.
+__device__ inline int rs_index(int lane) { return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3); }
+__device__ inline float half_reduce_scatter(const float (&v)[16], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float a8[8], a4[4], a2[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float keep = b0 ? v[8 + j] : v[j], send = b0 ? v[j] : v[8 + j];
+        a8[j] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = b1 ? a8[4 + j] : a8[j], send = b1 ? a8[j] : a8[4 + j];
+        a4[j] = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x4E, 0xF, 0xF, true));
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = b2 ? a4[2 + j] : a4[j], send = b2 ? a4[j] : a4[2 + j];
+        a2[j] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x101F));   // xor 4
+    }
+    const float keep = b3 ? a2[1] : a2[0], send = b3 ? a2[0] : a2[1];
+    float a1 = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x201F));    // xor 8
+    a1 += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, a1), 0x401F));                  // xor 16
+    return a1;
+}
+
 // make every earlier LDS access of this wave visible/ordered before later ones (wave-private staging tile)
 __device__ inline void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -409,6 +440,9 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
     const __amdgpu_buffer_rsrc_t rs_e = make_rsrc(p.edges), rs_c = make_rsrc(p.codes), rs_r = make_rsrc(p.radial);
     const int r16 = lane >> 2, c4 = lane & 3;
     const uint32_t oc4 = c4 * 32;
+    // epilogue constants: the row (inside a tile) whose sum this lane ends up with in half_reduce_scatter; byte address of lane 0 of
+    // this lane's half for ds_bpermute
+    const int rs_j = rs_index(lane), rs_row = (rs_j & 3) + 8 * (rs_j >> 2) + 4 * h, bp_base = (lane & 32) * 4;
 
     unsigned tt = (unsigned)slot * EDGE_WAVES + wave;
     int b = 0, i = 0, mt = 0;
@@ -645,12 +679,17 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
 #pragma unroll
             for (int q = 0; q < 8; ++q) { part[2 * q] = part2[q].x; part[2 * q + 1] = part2[q].y; }
         }
+        {
+            // attention gate sigmoid(logit) = 1 / (1 + exp2(S logit)) (att_b pre-scaled), rows >= K gated off: computed by the lane
+            // that holds the row's sum, then handed to every lane of the half (ds_bpermute: no VALU issue slot)
+            const float logit = half_reduce_scatter(part, lane);
+            const int rown = mt * 32 + rs_row;
+            const float gate = rown < K ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(logit + p.att_b)) : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[r] = half_sum_dpp(part[r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            part[r] = row < K ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(part[r] + p.att_b)) : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int src = ((r & 8) >> 3) | ((r & 4) >> 1) | ((r & 2) << 1) | ((r & 1) << 3);      // the lane (of 16) with rs_index == r
+                part[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_base + src * 4, __builtin_bit_cast(int, gate)));
+            }
         }
         if (p.last && i >= p.R) {
             // Gated messages of a ligand node in the A-fragment order k_edge_coord reads: [k-step 16][lane half 2][row 32][8 channels].
@@ -671,11 +710,16 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
                 const int unit = lane + 64 * k2, uu = unit >> 5, row = unit & 31;
                 rd[k2] = uu * 512 + (row ^ uu) * 16;
             }
+            // (opaque copies of the gates: otherwise hipcc computes all 128 gate * message products once, for this store AND the
+            // segment sums below, and spills them)
+            float ps[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ps[r] = part[r]; asm volatile("" : "+v"(ps[r])); }
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const float g0 = acc[nt][r] * part[r], g1 = acc[nt][r + 1] * part[r + 1];
+                    const float g0 = acc[nt][r] * ps[r], g1 = acc[nt][r + 1] * ps[r + 1];
                     uint32_t pk;
                     if constexpr (F16) pk = pack_f16_sat_lo(g0, g1);
                     else pk = (uint32_t)to16<0>(g0) | ((uint32_t)to16<0>(g1) << 16);
