@@ -152,12 +152,13 @@ hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s)
 // (gn_den := w/den, gn_shift := b - w*shift/den per graph and channel, see k_gn_stats fold=1).
 // Needs K % 32 == 0, Nout % 256 == 0.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-union FragB { uint4 u; bf16x8 b; };
+typedef _Float16 gf16x8 __attribute__((ext_vector_type(8)));
+union FragB { uint4 u; bf16x8 b; gf16x8 f; };
 constexpr int SN = 256, SK = 32, SLD = 40;   // output columns per workgroup; K per stage; LDS row stride in bf16
 
 struct GemmSplitArgs {
     GemmArgs g;
-    const uint16_t *Whi, *Wlo;   // [K/32][4][Nout][8] bf16 (split_bf16 in api.hip)
+    const uint16_t *Whi, *Wlo;   // [K/32][4][Nout][8] bf16 hi / lo (split_bf16 in api.hip); W16 kernels: Whi = the fp16 tile, Wlo unused
 };
 
 __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
@@ -169,11 +170,17 @@ __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
 
 // MT = 64-row groups per workgroup.  MT 2: 128 x 256 tile, waves 2 x 2 of 64 x 128 (60 KiB LDS, 2 workgroups / CU);
 // MT 1: 64 x 256 tile, waves 1 x 4 of 64 x 64 (50 KiB LDS, 3 workgroups / CU: more independent phases in flight).
-template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm_split(GemmSplitArgs sa)
+// W16 = 1 (the bf16 engine): TWO terms on fp16 operands instead of three on bf16 - the weights as ONE fp16 tile (11 mantissa bits:
+// ~3e-4 relative on an output, against ~3e-3 from the bf16 per-edge contractions of the same engine), the activations as fp16
+// hi + lo (hi by one v_cvt_pkrtz per pair - round-to-zero also saturates -, lo = x - hi).  A third less MFMA work, 40 % less
+// staging, 38 KiB of LDS and <= 128 registers: four workgroups per CU instead of three (0.141 vs 0.162 ms per launch).
+template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 ? 4 : 3)) void k_gemm_split(GemmSplitArgs sa)
 {
     constexpr int SM = 64 * MT, WN = 4 / MT, NJ = 8 / WN;      // rows; waves along N; 32-column tiles per wave
     const GemmArgs &a = sa.g;
-    __shared__ __attribute__((aligned(16))) uint16_t lds[(2 * SM + 2 * SN) * SLD];
+    // operand tiles; the epilogue reuses the space as 4 x 9216 B of transposition buffers
+    constexpr int LDS_U16 = W16 ? ((2 * SM + SN) * SLD > 18432 ? (2 * SM + SN) * SLD : 18432) : (2 * SM + 2 * SN) * SLD;
+    __shared__ __attribute__((aligned(16))) uint16_t lds[LDS_U16];
     uint16_t *Ah = lds, *Al = lds + SM * SLD, *Wh = lds + 2 * SM * SLD, *Wl = lds + (2 * SM + SN) * SLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31;
@@ -239,8 +246,10 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
         const uint16_t *ph_ = sa.Whi + wbase_, *pl_ = sa.Wlo + wbase_;                                                \
         wh0 = *reinterpret_cast<const uint4 *>(ph_); wh1 = *reinterpret_cast<const uint4 *>(ph_ + wq_);               \
         wh2 = *reinterpret_cast<const uint4 *>(ph_ + 2 * wq_); wh3 = *reinterpret_cast<const uint4 *>(ph_ + 3 * wq_); \
-        wl0 = *reinterpret_cast<const uint4 *>(pl_); wl1 = *reinterpret_cast<const uint4 *>(pl_ + wq_);               \
-        wl2 = *reinterpret_cast<const uint4 *>(pl_ + 2 * wq_); wl3 = *reinterpret_cast<const uint4 *>(pl_ + 3 * wq_); \
+        if constexpr (!W16) {                                                                                         \
+            wl0 = *reinterpret_cast<const uint4 *>(pl_); wl1 = *reinterpret_cast<const uint4 *>(pl_ + wq_);               \
+            wl2 = *reinterpret_cast<const uint4 *>(pl_ + 2 * wq_); wl3 = *reinterpret_cast<const uint4 *>(pl_ + 3 * wq_); \
+        }                                                                                                             \
     }
     auto stage_row = [&](const float4 &v0, const float4 &v1, bool valid, int g, int k, int row) {
         float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -266,9 +275,15 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x0 = valid ? x[2 * e] : 0.f, x1 = valid ? x[2 * e + 1] : 0.f;
-            const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
-            hi[e] = pack2(h0, h1);
-            lo[e] = pack2((__bf16)(x0 - (float)h0), (__bf16)(x1 - (float)h1));
+            if constexpr (W16) {
+                const auto h2 = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+                hi[e] = __builtin_bit_cast(uint32_t, h2);
+                lo[e] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x0 - (float)h2[0], x1 - (float)h2[1]));
+            } else {
+                const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+                hi[e] = pack2(h0, h1);
+                lo[e] = pack2((__bf16)(x0 - (float)h0), (__bf16)(x1 - (float)h1));
+            }
         }
         *reinterpret_cast<uint4 *>(&Ah[row * SLD + kg]) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         *reinterpret_cast<uint4 *>(&Al[row * SLD + kg]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
@@ -289,8 +304,10 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
         if constexpr (MT == 2) stage_row(xa2, xa3, rv1, g1, k0 + kg, ar + 64);
         *reinterpret_cast<uint4 *>(&Wh[wu]) = wh0; *reinterpret_cast<uint4 *>(&Wh[wu + 8]) = wh1;
         *reinterpret_cast<uint4 *>(&Wh[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&Wh[wu + 24]) = wh3;
-        *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
-        *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
+        if constexpr (!W16) {
+            *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
+            *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
+        }
         GSTAMP(1)                  // [1] waiting for the fetched registers + conversion + LDS stores
         __syncthreads();
         GSTAMP(2)                  // [2] barrier after staging
@@ -310,12 +327,17 @@ template <int MT> __global__ __launch_bounds__(256, MT == 2 ? 2 : 3) void k_gemm
                 const int c = (wn * NJ + j) * 32 + l31;
                 FragB wh, wl;
                 wh.u = *reinterpret_cast<const uint4 *>(&Wh[c * SLD + ko]);
-                wl.u = *reinterpret_cast<const uint4 *>(&Wl[c * SLD + ko]);
+                if constexpr (!W16) wl.u = *reinterpret_cast<const uint4 *>(&Wl[c * SLD + ko]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].b, wh.b, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wl.b, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wh.b, acc[i][j], 0, 0, 0);
+                    if constexpr (W16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].f, wh.f, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].f, wh.f, acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].b, wh.b, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wl.b, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wh.b, acc[i][j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -432,22 +454,28 @@ int gemm_rows_per_tile()
     return v;
 }
 
-hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s)
+hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s, const uint16_t *W16)
 {
     if (a.K % SK != 0 || a.Nout % SN != 0 || (a.pro == 1 && (a.K / 2) % SK != 0) || a.lda % 4 != 0 || a.ldc % 4 != 0)
         return hipErrorInvalidValue;
     GemmSplitArgs sa;
-    sa.g = a; sa.Whi = Whi; sa.Wlo = Wlo;
+    sa.g = a; sa.Whi = W16 ? W16 : Whi; sa.Wlo = Wlo;
     static int mt = 0;
     if (!mt) { const char *e = getenv("DFM_GEMM_MT"); mt = e && atoi(e) == 2 ? 2 : 1; }
     if (a.stat_part && (mt != 1 || a.Nout != SN || a.rows_per_graph < 1 || a.M % a.rows_per_graph != 0)) return hipErrorInvalidValue;
     if (a.pro == 2 && (a.rows_per_graph < 1 || a.M % a.rows_per_graph != 0)) return hipErrorInvalidValue;
-    if (mt == 2) hipLaunchKernelGGL(k_gemm_split<2>, dim3((a.M + 127) / 128, a.Nout / SN), dim3(256), 0, s, sa);
-    else if (a.stat_part || a.pro == 2)      // row tiles aligned to the trajectories
-        hipLaunchKernelGGL(k_gemm_split<1>, dim3((a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64), a.Nout / SN), dim3(256), 0, s, sa);
-    else if (a.Nout == 2 * SN)                 // paired column blocks, see the block mapping in the kernel
-        hipLaunchKernelGGL(k_gemm_split<1>, dim3((((a.M + 63) / 64 + 7) / 8) * 16, 1), dim3(256), 0, s, sa);
-    else hipLaunchKernelGGL(k_gemm_split<1>, dim3((a.M + 63) / 64, a.Nout / SN), dim3(256), 0, s, sa);
+    dim3 grid;
+    if (mt == 2) grid = dim3((a.M + 127) / 128, a.Nout / SN);
+    else if (a.stat_part || a.pro == 2) grid = dim3((a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64), a.Nout / SN);   // row tiles aligned to the trajectories
+    else if (a.Nout == 2 * SN) grid = dim3((((a.M + 63) / 64 + 7) / 8) * 16, 1);      // paired column blocks, see the block mapping in the kernel
+    else grid = dim3((a.M + 63) / 64, a.Nout / SN);
+    if (mt == 2) {
+        if (W16) hipLaunchKernelGGL((k_gemm_split<2, 1>), grid, dim3(256), 0, s, sa);
+        else hipLaunchKernelGGL((k_gemm_split<2, 0>), grid, dim3(256), 0, s, sa);
+    } else {
+        if (W16) hipLaunchKernelGGL((k_gemm_split<1, 1>), grid, dim3(256), 0, s, sa);
+        else hipLaunchKernelGGL((k_gemm_split<1, 0>), grid, dim3(256), 0, s, sa);
+    }
     return hipGetLastError();
 }
 
