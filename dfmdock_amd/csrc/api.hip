@@ -105,6 +105,7 @@ struct dfm_complex {
     float *rec_pos = nullptr, *lig0 = nullptr;
     float *h0 = nullptr, *A0 = nullptr, *Bm0 = nullptr;
     float *A0s = nullptr; uint16_t *Bmb0 = nullptr;   // SILU_S * A0 (fp32), SILU_S * Bm0 (fp16): layer-0 operands of the 16-bit engines
+    uint16_t *A0h = nullptr;                          // SILU_S * A0 as fp16 (bf16-operand message kernel)
     Workspace ws;
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;      // profiling events (pairs)
@@ -376,6 +377,7 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
             for (int c = 0; c < H; ++c) wrs[c] = SILU_S * w_r[c];
             for (int c = 0; c < 2 * H; ++c) babs[c] = SILU_S * bias_ab[c];
             up(&D.w_r_s, wrs.data(), H); up(&D.bias_ab_s, babs.data(), 2 * H);
+            { std::vector<uint16_t> wrh(H); for (int c = 0; c < H; ++c) wrh[c] = f2h(wrs[c]); up16(&D.w_r_h, wrh); }
             up32(&D.b2p, pack_bias(Lw.e2_b, false)); up32(&D.b2p16, pack_bias(Lw.e2_b, true));
             if (Lw.c1_w) {
                 for (int c = 0; c < H; ++c) wc2s[c] = Lw.c2_w[c] / SILU_S;
@@ -464,12 +466,12 @@ extern "C" void dfm_model_destroy(dfm_model *m)
 }
 
 // ------------------------------------------------------------------------------------------------
-// layer-0 operands of the 16-bit MFMA edge kernel: SILU_S * A0 (fp32) and SILU_S * Bm0 (fp16)
+// layer-0 operands of the 16-bit MFMA edge kernel: SILU_S * A0 (fp32 and fp16) and SILU_S * Bm0 (fp16)
 __global__ void k_scale_ab(const float *__restrict__ A0, const float *__restrict__ Bm0, float *__restrict__ A0s,
-                           uint16_t *__restrict__ Bmb0, int n)
+                           uint16_t *__restrict__ A0h, uint16_t *__restrict__ Bmb0, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { A0s[i] = SILU_S * A0[i]; Bmb0[i] = f2h(SILU_S * Bm0[i]); }
+    if (i < n) { A0s[i] = SILU_S * A0[i]; A0h[i] = f2h(SILU_S * A0[i]); Bmb0[i] = f2h(SILU_S * Bm0[i]); }
 }
 
 // layer 0's [Wa|Wb] projection of the node embedding: pose independent, once per complex (again when the homomer flag changes)
@@ -484,7 +486,7 @@ static hipError_t project_layer0(dfm_complex *cx)
     g.Nout = 2 * H; g.epi = 2; g.C = cx->A0; g.ldc = H; g.C2 = cx->Bm0;
     hipError_t e = launch_gemm_f32(g, cx->stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_scale_ab, dim3((N * H + 255) / 256), dim3(256), 0, cx->stream, cx->A0, cx->Bm0, cx->A0s, cx->Bmb0, N * H);
+    hipLaunchKernelGGL(k_scale_ab, dim3((N * H + 255) / 256), dim3(256), 0, cx->stream, cx->A0, cx->Bm0, cx->A0s, cx->A0h, cx->Bmb0, N * H);
     return hipGetLastError();
 }
 
@@ -511,6 +513,7 @@ extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, con
     ok = ok && P.alloc(&cx->h0, (size_t)N * H) == hipSuccess && P.alloc(&cx->A0, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->Bm0, (size_t)N * H) == hipSuccess && P.alloc(&cx->Bmb0, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->A0s, (size_t)N * H) == hipSuccess;
+    ok = ok && P.alloc(&cx->A0h, (size_t)N * H) == hipSuccess;
 #ifdef DFM_EDGE_STAMP
     ok = ok && P.alloc(&cx->stamp_dev, 48) == hipSuccess && hipMemset(cx->stamp_dev, 0, 48 * 8) == hipSuccess;
 #endif
@@ -629,6 +632,14 @@ static int f16_last_layers()
 // Node-level GEMMs of the bf16 engine: two terms on fp16 operands (weights as one fp16 tile, k_gemm_split<.,1>) - ~3e-4 relative per
 // output, an order below the engine's bf16 per-edge contractions, for 13 % less time per launch.  The f16 engine (tighter gates)
 // and DFM_GEMM_TERMS=3 keep the three-term split-bf16 form (~1e-5).
+// bf16-operand message launches read A_i = Wa h_i + b1 and w_r as fp16 (the [Wa|Wb] GEMM writes A that way): half the per-chunk
+// constant loads of the kernel and a third less output of that GEMM; the operand joins Bm_j and the tables, which are fp16 already.
+// fp16-operand launches (the f16 engine, the bf16 engine's last layer) keep fp32.  DFM_EDGE_AW16=0 turns it off.
+static bool edge_aw16()
+{
+    static const bool v = [] { const char *e = getenv("DFM_EDGE_AW16"); return !(e && atoi(e) == 0); }();
+    return v;
+}
 static bool gemm_two_term()
 {
     static const bool v = [] { const char *e = getenv("DFM_GEMM_TERMS"); return !(e && atoi(e) == 3); }();
@@ -678,9 +689,13 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         std::memset(&e, 0, sizeof(e));
         if (l == 0) { e.A = o.bf16 ? cx->A0s : cx->A0; e.Bm = cx->Bm0; e.Bmb = cx->Bmb0; e.ab_bstride = 0; }
         else { e.A = W.A; e.Bm = W.Bm; e.Bmb = W.Bmb; e.ab_bstride = (int64_t)N * H; }
+        auto layer_f16 = [&](int ll) { return o.f16 || ll >= depth - f16_last_layers(); };
+        auto layer_aw16 = [&](int ll) { return o.bf16 && !layer_f16(ll) && edge_aw16(); };
+        e.Ah = nullptr; e.w_r_h = nullptr;
+        if (layer_aw16(l)) { e.Ah = l == 0 ? cx->A0h : reinterpret_cast<const uint16_t *>(W.A); e.w_r_h = Lw.w_r_h; }
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
         e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = coord; e.fout = W.fvec; e.mbuf = W.mbuf;
-        e.f16 = (o.f16 || l >= depth - f16_last_layers()) ? 1 : 0;
+        e.f16 = layer_f16(l) ? 1 : 0;
         e.stamp = (o.profile && l == 2) ? cx->stamp_dev : nullptr;
         // the per-edge message kernel, bracketed by HIP events on this stream when profiling (dfm_get_profile)
         auto message_launch = [&](const EdgeArgs &ea) -> int {
@@ -734,6 +749,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             g.A0 = h; g.lda = H; g.K = H; g.W = Ln.Wab; g.ldw = H; g.M = M; g.Nout = 2 * H;
             g.bias = cx->homomer ? (o.bf16 ? Ln.bias_ab_h_s : Ln.bias_ab_h) : (o.bf16 ? Ln.bias_ab_s : Ln.bias_ab);
             g.epi = 2; g.C = W.A; g.ldc = H; g.C2 = o.bf16 ? nullptr : W.Bm; g.C2b = W.Bmb;   // 16-bit engines gather the fp16 copy only
+            if (layer_aw16(l + 1)) g.Cb = reinterpret_cast<uint16_t *>(W.A);     // ... and, bf16 operands, A as fp16 too (same buffer)
             if (o.bf16) HIPCHK(launch_gemm_split(g, Ln.Wab_hi, Ln.Wab_lo, s, w16 ? Ln.Wab_h : nullptr)); else HIPCHK(launch_gemm_f32(g, s));
         }
     }

@@ -396,8 +396,14 @@ template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 
                     const float4 rr = res[q];
                     *reinterpret_cast<float4 *>(a.C + row * a.ldc + col) = make_float4(rr.x + v.x, rr.y + v.y, rr.z + v.z, rr.w + v.w);
                 } else if (a.epi == 2) {
-                    if (col0 < H) *reinterpret_cast<float4 *>(a.C + row * H + col) = v;
-                    else {
+                    if (col0 < H) {
+                        if (a.Cb) {
+                            uint2 o;
+                            o.x = (uint32_t)f2h(v.x) | ((uint32_t)f2h(v.y) << 16);
+                            o.y = (uint32_t)f2h(v.z) | ((uint32_t)f2h(v.w) << 16);
+                            *reinterpret_cast<uint2 *>(a.Cb + row * H + col) = o;
+                        } else *reinterpret_cast<float4 *>(a.C + row * H + col) = v;
+                    } else {
                         if (a.C2) *reinterpret_cast<float4 *>(a.C2 + row * H + (col - H)) = v;
                         if (a.C2b) {
                             uint2 o;

@@ -52,6 +52,7 @@ struct EdgeKArgs {
     const uint32_t *biasp;
     float inv_s;
     unsigned long long *stamp;   // DFM_EDGE_STAMP builds only: per-phase cycle sums of workgroup 0 (tools/edge_phases.py)
+    const uint16_t *Ah, *w_r_h;  // k_edge_msg<0, 1>: A as fp16 (w_r_h: SILU_S * w_r as fp16, not used by the shipped kernel)
     int split;                   // k_edge_msg: 1 = a wave task is one TILE (small launches), agg is pre-zeroed and added to atomically
 };
 
@@ -250,6 +251,19 @@ __device__ inline float add_half_hi(float a, uint32_t h2)
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(a));
     return r;
 }
+// w * r + (float)a.lo and the .hi counterpart: fp32 sources 0 and 1, fp16 source 2
+__device__ inline float fma_half_lo(float w, float r, uint32_t a2)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=v"(d) : "v"(w), "v"(r), "v"(a2));
+    return d;
+}
+__device__ inline float fma_half_hi(float w, float r, uint32_t a2)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(w), "v"(r), "v"(a2));
+    return d;
+}
 __device__ inline f2 add_half2(f2 a, __half2 h)
 {
     const uint32_t u = __builtin_bit_cast(uint32_t, h);
@@ -363,6 +377,25 @@ __device__ inline float4 bload16f(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint
     const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+// Streams that pass through once (A_i rows, edge data, agg / message stores) carry the non-temporal hint, so that they do not
+// push the lookup tables and the re-gathered Bm rows out of the XCD's 4 MiB L2 (cache-policy bit 1 of the buffer instructions)
+#ifndef DFM_EDGE_NT
+#define DFM_EDGE_NT 1
+#endif
+constexpr int AUX_STREAM = DFM_EDGE_NT ? 2 : 0;
+__device__ inline float4 bload16f_stream(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, AUX_STREAM);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ inline void store_stream(float *p, float v)
+{
+    if constexpr (DFM_EDGE_NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+__device__ inline void store_stream(uint4 *p, uint4 v)
+{
+    if constexpr (DFM_EDGE_NT) __builtin_nontemporal_store((u32x4v){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4v *>(p)); else *p = v;
+}
 __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *base)
 {   // raw buffer (stride 0), 2 GiB window, dword-format descriptor word 3 of gfx9
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00027000);
@@ -391,7 +424,10 @@ __device__ inline f2 silu2s(f2 x)
 #ifndef DFM_EDGE_DEFER      // requests of the next tile's chunk 1 issued after the epilogue instead of under chunk 7: 0 none, 1 A_i / w_r, 2 + second pass
 #define DFM_EDGE_DEFER 2
 #endif
-template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg(EdgeKArgs p)
+// AW16: A_i comes as fp16 (one 16-byte load per chunk instead of two; bf16 operands only).  w_r stays fp32: its product with the
+// radial |x_i - x_j|^2 (thousands of A^2) is the one large term of the pre-activation, and an fp16 w_r moved the worst force
+// deviation of the bf16 engine from 7.2e-3 to 8.8e-3
+template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg(EdgeKArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *Wf = reinterpret_cast<uint4 *>(smem);
@@ -456,9 +492,9 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
         for (int q = 0; q < 2; ++q) {
             const int s = tm * 32 + q * 16 + r16;
             const uint32_t off = (ebase + (uint32_t)(s < K ? s : K - 1)) * 4u;
-            jqn[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_e, (int)off, 0, 0);
-            codeqn[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)off, 0, 0);
-            radqn[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)off, 0, 0));
+            jqn[q] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_e, (int)off, 0, AUX_STREAM);
+            codeqn[q] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)off, 0, AUX_STREAM);
+            radqn[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)off, 0, AUX_STREAM));
         }
     };
     // producer state: gather offsets / resources of the tile whose operands are being REQUESTED, radial of the tile being BUILT
@@ -470,7 +506,8 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
     __amdgpu_buffer_rsrc_t rs_bm = rs_t, rs_a = rs_t;
     auto set_tile = [&](int tb, int ti, int tm) {      // from jqn / codeqn / radqn of that tile
         const size_t ab = (size_t)tb * p.ab_bstride;
-        rs_bm = make_rsrc(p.Bmb + ab); rs_a = make_rsrc(p.A + ab + (size_t)ti * H);
+        rs_bm = make_rsrc(p.Bmb + ab);
+        rs_a = AW16 ? make_rsrc(p.Ah + ab + (size_t)ti * H) : make_rsrc(p.A + ab + (size_t)ti * H);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {      // masked rows (>= K): self edge, zero features -> finite values, gate forced to 0
             const bool v = tm * 32 + q * 16 + r16 < K;
@@ -497,16 +534,17 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
 #endif
         }
     };
-    float4 a0, a1, w0, w1;
+    float4 a0, a1, w0, w1;      // fp32 A_i / w_r of this lane's 8 channels (AW16: a0 holds the 8 fp16 values of A_i, a1 unused)
 #ifdef DFM_EDGE_NOGATHER      // diagnostic build: the gathered operands are whatever the registers hold (wrong results, no instruction
                               // issued for them) - the kernel's time with no gather in it
 #define FAKE4(v) asm volatile("" : "=v"((v).x), "=v"((v).y), "=v"((v).z), "=v"((v).w))
-    auto gather_chunk = [&](int) { FAKE4(a0); FAKE4(a1); FAKE4(w0); FAKE4(w1); };
+    auto gather_chunk = [&](int) { FAKE4(a0); FAKE4(w0); FAKE4(w1); if constexpr (!AW16) FAKE4(a1); };
     auto gather = [&](int, int, RawP &r) { FAKE4(r.bm); FAKE4(r.t0); FAKE4(r.t1); };
 #undef FAKE4
 #else
     auto gather_chunk = [&](int c) {
-        a0 = bload16f(rs_a, oc4, c * 128); a1 = bload16f(rs_a, oc4, c * 128 + 16);
+        if constexpr (AW16) a0 = bload16f_stream(rs_a, c4 * 16, c * 64);
+        else { a0 = bload16f_stream(rs_a, oc4, c * 128); a1 = bload16f_stream(rs_a, oc4, c * 128 + 16); }
         w0 = bload16f(rs_w, oc4, c * 128); w1 = bload16f(rs_w, oc4, c * 128 + 16);
     };
     auto gather = [&](int c, int q, RawP &r) {
@@ -543,10 +581,15 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
             }
         }
         if ((k & 1) == 0) {
-            const f2 rad2 = {radq[q], radq[q]};
             const f2 wv = e == 0 ? (f2){w0.x, w0.y} : (e == 1 ? (f2){w0.z, w0.w} : (e == 2 ? (f2){w1.x, w1.y} : (f2){w1.z, w1.w}));
-            const f2 av = e == 0 ? (f2){a0.x, a0.y} : (e == 1 ? (f2){a0.z, a0.w} : (e == 2 ? (f2){a1.x, a1.y} : (f2){a1.z, a1.w}));
-            pv[e] = wv * rad2 + av;
+            if constexpr (AW16) {      // w * radial (fp32) + a (fp16), one v_fma_mix_f32 per channel
+                const uint32_t ah = __float_as_uint(e == 0 ? a0.x : (e == 1 ? a0.y : (e == 2 ? a0.z : a0.w)));
+                pv[e] = (f2){fma_half_lo(wv.x, radq[q], ah), fma_half_hi(wv.y, radq[q], ah)};
+            } else {
+                const f2 rad2 = {radq[q], radq[q]};
+                const f2 av = e == 0 ? (f2){a0.x, a0.y} : (e == 1 ? (f2){a0.z, a0.w} : (e == 2 ? (f2){a1.x, a1.y} : (f2){a1.z, a1.w}));
+                pv[e] = wv * rad2 + av;
+            }
             if constexpr (F16) pv[e] = add_half2(pv[e], pbm.h[e]);
             pv[e] = add_half2(pv[e], pt.h[e]);
         } else {
@@ -729,8 +772,8 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
                 wave_lds_fence();
                 const uint4 v0 = *reinterpret_cast<const uint4 *>(tb + rd[0]), v1 = *reinterpret_cast<const uint4 *>(tb + rd[1]);
                 wave_lds_fence();      // the reads have returned before the next n-tile overwrites the buffer
-                Mout[nt * 128 + lane] = v0;
-                Mout[nt * 128 + 64 + lane] = v1;
+                store_stream(Mout + nt * 128 + lane, v0);
+                store_stream(Mout + nt * 128 + 64 + lane, v1);
             }
 #else
             uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H);
@@ -762,7 +805,7 @@ template <int F16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
                 if (h == 0) {
-                    if (split) atomicAdd(out + nt * 32, colsum[nt]); else out[nt * 32] = colsum[nt];
+                    if (split) atomicAdd(out + nt * 32, colsum[nt]); else store_stream(out + nt * 32, colsum[nt]);
                 }
                 colsum[nt] = 0.f;
             }
@@ -936,6 +979,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
     k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.stamp = a.stamp; k.split = 0;
+    k.Ah = a.Ah; k.w_r_h = a.w_r_h;
     return k;
 }
 // the 16-bit MFMA kernels take the -log2(e)-scaled operands (SILU_S, api.hip)
@@ -973,14 +1017,14 @@ static int persistent_grid(long long wave_tasks)
     return (int)g;
 }
 
-template <int F16> static hipError_t launch_msg_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
+template <int F16, int AW16> static hipError_t launch_msg_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
 {
     static std::atomic<bool> attr_done[MAX_DEVICES];
     {
-        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_msg<F16>), LDS_EDGE_BYTES, attr_done);
+        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_msg<F16, AW16>), LDS_EDGE_BYTES, attr_done);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_edge_msg<F16>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
+    hipLaunchKernelGGL((k_edge_msg<F16, AW16>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
     return hipGetLastError();
 }
 template <int F16> static hipError_t launch_coord_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
@@ -1013,7 +1057,8 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
             if (e != hipSuccess) return e;
         }
     }
-    return a.f16 ? launch_msg_t<1>(k, tasks, s) : launch_msg_t<0>(k, tasks, s);
+    if (a.f16) return launch_msg_t<1, 0>(k, tasks, s);
+    return (a.Ah && a.w_r_h) ? launch_msg_t<0, 1>(k, tasks, s) : launch_msg_t<0, 0>(k, tasks, s);
 }
 
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
