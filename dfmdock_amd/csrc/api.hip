@@ -377,7 +377,6 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
             for (int c = 0; c < H; ++c) wrs[c] = SILU_S * w_r[c];
             for (int c = 0; c < 2 * H; ++c) babs[c] = SILU_S * bias_ab[c];
             up(&D.w_r_s, wrs.data(), H); up(&D.bias_ab_s, babs.data(), 2 * H);
-            { std::vector<uint16_t> wrh(H); for (int c = 0; c < H; ++c) wrh[c] = f2h(wrs[c]); up16(&D.w_r_h, wrh); }
             up32(&D.b2p, pack_bias(Lw.e2_b, false)); up32(&D.b2p16, pack_bias(Lw.e2_b, true));
             if (Lw.c1_w) {
                 for (int c = 0; c < H; ++c) wc2s[c] = Lw.c2_w[c] / SILU_S;
@@ -632,8 +631,8 @@ static int f16_last_layers()
 // Node-level GEMMs of the bf16 engine: two terms on fp16 operands (weights as one fp16 tile, k_gemm_split<.,1>) - ~3e-4 relative per
 // output, an order below the engine's bf16 per-edge contractions, for 13 % less time per launch.  The f16 engine (tighter gates)
 // and DFM_GEMM_TERMS=3 keep the three-term split-bf16 form (~1e-5).
-// bf16-operand message launches read A_i = Wa h_i + b1 and w_r as fp16 (the [Wa|Wb] GEMM writes A that way): half the per-chunk
-// constant loads of the kernel and a third less output of that GEMM; the operand joins Bm_j and the tables, which are fp16 already.
+// bf16-operand message launches read A_i = Wa h_i + b1 as fp16 (the [Wa|Wb] GEMM writes it that way): one load per chunk less in
+// the kernel and a third less output of that GEMM; the operand joins Bm_j and the tables, which are fp16 already.
 // fp16-operand launches (the f16 engine, the bf16 engine's last layer) keep fp32.  DFM_EDGE_AW16=0 turns it off.
 static bool edge_aw16()
 {
@@ -691,8 +690,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         else { e.A = W.A; e.Bm = W.Bm; e.Bmb = W.Bmb; e.ab_bstride = (int64_t)N * H; }
         auto layer_f16 = [&](int ll) { return o.f16 || ll >= depth - f16_last_layers(); };
         auto layer_aw16 = [&](int ll) { return o.bf16 && !layer_f16(ll) && edge_aw16(); };
-        e.Ah = nullptr; e.w_r_h = nullptr;
-        if (layer_aw16(l)) { e.Ah = l == 0 ? cx->A0h : reinterpret_cast<const uint16_t *>(W.A); e.w_r_h = Lw.w_r_h; }
+        e.Ah = layer_aw16(l) ? (l == 0 ? cx->A0h : reinterpret_cast<const uint16_t *>(W.A)) : nullptr;
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
         e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = coord; e.fout = W.fvec; e.mbuf = W.mbuf;
         e.f16 = layer_f16(l) ? 1 : 0;

@@ -60,7 +60,6 @@ struct LayerDev {
     float *W4;        // [256][256]   node_mlp.3.weight
     float *b4;
     uint16_t *Wab_hi, *Wab_lo, *W3_hi, *W3_lo, *W4_hi, *W4_lo;   // bf16 hi/lo splits for launch_gemm_split
-    uint16_t *w_r_h;                                             // SILU_S * w_r as fp16 (message kernel with fp16 A)
     uint16_t *Wab_h, *W3_h, *W4_h;                               // the same weights as single fp16 tiles (two-term form, bf16 engine)
     float *Wc1t;      // [256 in][256 out] coord_mlp.0.weight transposed (last layer)
     uint16_t *Wc1f;   // bf16 fragments of coord_mlp.0.weight
@@ -159,8 +158,7 @@ struct EdgeArgs {
     const float *A;        // [Ab][N][256]  Wa h_i + b1   (Ab = 1 when a_bstride == 0)
     const float *Bm;       // [Ab][N][256]  Wb h_j        fp32
     const uint16_t *Bmb;   // same, fp16 (gathered operand of the bf16-MFMA kernel)
-    const uint16_t *Ah;    // A as fp16 (bf16-operand message kernel: half the per-chunk constant loads), or nullptr
-    const uint16_t *w_r_h; // SILU_S * w_r as fp16, with Ah
+    const uint16_t *Ah;    // A as fp16 (bf16-operand message kernel: one load per chunk instead of two), or nullptr
     int64_t ab_bstride;    // elements between trajectories (0 for layer 0: pose independent)
     const int32_t *edges;  // [B][N][K]
     const uint32_t *codes; // [B][N][K]

@@ -52,7 +52,7 @@ struct EdgeKArgs {
     const uint32_t *biasp;
     float inv_s;
     unsigned long long *stamp;   // DFM_EDGE_STAMP builds only: per-phase cycle sums of workgroup 0 (tools/edge_phases.py)
-    const uint16_t *Ah, *w_r_h;  // k_edge_msg<0, 1>: A as fp16 (w_r_h: SILU_S * w_r as fp16, not used by the shipped kernel)
+    const uint16_t *Ah;          // k_edge_msg<0, 1>: A as fp16
     int split;                   // k_edge_msg: 1 = a wave task is one TILE (small launches), agg is pre-zeroed and added to atomically
 };
 
@@ -880,7 +880,11 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_coord(EdgeKArgs p)
             const uint4 *Mt = reinterpret_cast<const uint4 *>(p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H)) + lane;
             uint4 a16[16];
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) a16[kk] = Mt[kk * 64];
+            for (int kk = 0; kk < 16; ++kk) {      // read once: non-temporal, like the stores that wrote them
+                const u32x4v v = DFM_EDGE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(Mt + kk * 64))
+                                             : *reinterpret_cast<const u32x4v *>(Mt + kk * 64);
+                a16[kk] = make_uint4(v.x, v.y, v.z, v.w);
+            }
             // everything the epilogue needs from memory goes out now too, so that nothing after the MFMAs waits on a load:
             // bias / dot vector, and the neighbour of this lane's row (edge index first, its coordinates below)
 #pragma unroll
@@ -979,7 +983,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
     k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.stamp = a.stamp; k.split = 0;
-    k.Ah = a.Ah; k.w_r_h = a.w_r_h;
+    k.Ah = a.Ah;
     return k;
 }
 // the 16-bit MFMA kernels take the -log2(e)-scaled operands (SILU_S, api.hip)
@@ -1058,7 +1062,7 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
         }
     }
     if (a.f16) return launch_msg_t<1, 0>(k, tasks, s);
-    return (a.Ah && a.w_r_h) ? launch_msg_t<0, 1>(k, tasks, s) : launch_msg_t<0, 0>(k, tasks, s);
+    return a.Ah ? launch_msg_t<0, 1>(k, tasks, s) : launch_msg_t<0, 0>(k, tasks, s);
 }
 
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
