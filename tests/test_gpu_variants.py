@@ -278,3 +278,39 @@ def test_tile_tasks_equal_node_tasks_bitwise(tmp_path):
     for tag in ("tile1", "node9", "tile9"):
         for k in outs["node1"].files:
             assert (outs[tag][k] == outs["node1"][k]).all(), (tag, k)
+
+
+def test_engine_switches_stay_within_the_bf16_gate(tmp_path):
+    """The bf16 engine's default forms (two-term fp16 node GEMMs, fp16 A_i) against their conservative forms
+    (DFM_GEMM_TERMS=3, DFM_EDGE_AW16=0): same graph, both within the SURVEY bf16 gate of the fp32 engine and close to each other."""
+    import subprocess, sys, textwrap
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {ROOT!r})
+        from dfmdock_amd import engine
+        from dfmdock_amd.synthetic import make_complex
+        from dfmdock_amd.weights import make_random_weights, pack_blob
+        engine.set_device(0)
+        model = engine.Model(pack_blob(make_random_weights(0)))
+        cx = make_complex(150, 110, seed=4)
+        gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+        poses = np.repeat(cx["lig_pos"][None], 3, 0)
+        r = gx.score(poses, 0.4, seed=7, bf16=True, energy=True, return_edges=True)
+        r32 = gx.score(poses, 0.4, edges=r["edges"], energy=True)
+        np.savez(sys.argv[1], **{{k: r[k] for k in ("f", "tr_score", "rot_score", "energy")}}, **{{k + "32": r32[k] for k in ("f", "tr_score", "rot_score", "energy")}})
+    """))
+    outs = {}
+    for tag, env in (("default", {}), ("terms3", {"DFM_GEMM_TERMS": "3"}), ("a32", {"DFM_EDGE_AW16": "0"})):
+        p = subprocess.run([sys.executable, str(script), str(tmp_path / f"{tag}.npz")], env=dict(os.environ, **env),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()[-2000:]
+        outs[tag] = np.load(tmp_path / f"{tag}.npz")
+    ref = outs["default"]
+    for tag, o in outs.items():
+        assert (o["f32"] == ref["f32"]).all()                        # the fp32 engine does not see the switches
+        for k, tol in (("f", 1e-2), ("tr_score", 1e-2), ("rot_score", 1e-2), ("energy", 3e-2)):
+            scale = np.abs(o[k + "32"]).max() + 1e-12
+            assert np.abs(o[k] - o[k + "32"]).max() / scale < tol, (tag, k)
+            assert np.abs(o[k] - ref[k]).max() / scale < 5e-3, (tag, k)
+    assert (outs["terms3"]["f"] != ref["f"]).any() and (outs["a32"]["f"] != ref["f"]).any()     # the switches do switch something
