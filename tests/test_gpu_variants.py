@@ -311,6 +311,7 @@ def test_engine_switches_stay_within_the_bf16_gate(tmp_path):
         assert (o["f32"] == ref["f32"]).all()                        # the fp32 engine does not see the switches
         for k, tol in (("f", 1e-2), ("tr_score", 1e-2), ("rot_score", 1e-2), ("energy", 3e-2)):
             scale = np.abs(o[k + "32"]).max() + 1e-12
+            if k == "energy": scale = max(scale, 0.1)              # the energy gate's convention (test_gpu_configs.check_vs)
             assert np.abs(o[k] - o[k + "32"]).max() / scale < tol, (tag, k)
             assert np.abs(o[k] - ref[k]).max() / scale < 5e-3, (tag, k)
     assert (outs["terms3"]["f"] != ref["f"]).any() and (outs["a32"]["f"] != ref["f"]).any()     # the switches do switch something
