@@ -173,8 +173,12 @@ __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
 // W16 = 1 (the bf16 engine): TWO terms on fp16 operands instead of three on bf16 - the weights as ONE fp16 tile (11 mantissa bits:
 // ~3e-4 relative on an output, against ~3e-3 from the bf16 per-edge contractions of the same engine), the activations as fp16
 // hi + lo (hi by one v_cvt_pkrtz per pair - round-to-zero also saturates -, lo = x - hi).  A third less MFMA work, 40 % less
-// staging, 38 KiB of LDS and <= 128 registers: four workgroups per CU instead of three (0.141 vs 0.162 ms per launch).
-template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 ? 4 : 3)) void k_gemm_split(GemmSplitArgs sa)
+// staging, 38 KiB of LDS (0.138 vs 0.162 ms per launch).  Register target: three workgroups per CU - forcing 128 registers for four
+// costs 9 spills and 6 % (0.146 ms), five 0.159 ms.
+#ifndef DFM_GEMM_W16_WGS
+#define DFM_GEMM_W16_WGS 3
+#endif
+template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 ? DFM_GEMM_W16_WGS : 3)) void k_gemm_split(GemmSplitArgs sa)
 {
     constexpr int SM = 64 * MT, WN = 4 / MT, NJ = 8 / WN;      // rows; waves along N; 32-column tiles per wave
     const GemmArgs &a = sa.g;
