@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
 // weight matrix for the whole launch, 32 KiB are eight wave-private 4 KiB staging areas.  A wave owns one
 // node at a time = two 32-row M-tiles (60 edges + 4 masked rows).  Per M-tile, in eight 32-channel chunks:
 //   producer  (gather layout: 4 adjacent lanes cover one row's 32 channels = a 64-byte half line, 16 rows per pass):
-//             A_i + Bm_j + w_r*radial + 3 merged T rows (fp16 gathers) -> SiLU -> bf16/fp16 -> ds_write_b128 into the
+//             A_i + Bm_j + w_r*radial + 2 merged T rows (fp16 gathers; see NTAB2) -> SiLU -> bf16/fp16 -> ds_write_b128 into the
 //             staging buffer of the NEXT chunk ([8-channel unit][row ^ 4*unit] x 16 B: conflict-free both ways)
 //   consumer  2 k-steps x 8 n-tiles of v_mfma_f32_32x32x16_{bf16,f16} on the CURRENT chunk's buffer, A-fragments and
 //             the resident weight fragments by ds_read_b128 (reads one ahead).
