@@ -40,15 +40,28 @@ __global__ __launch_bounds__(256) void k_pair_head(PairKArgs p)
     const int r = rt * 64 + lane;
     const bool valid = r < p.R;
 
-    // stage the tile: coalesced float4 rows from global, transposed scalar writes to LDS
+    // stage the tile: coalesced float4 rows from global, transposed scalar writes to LDS.  A wave iteration covers one row (64 lanes
+    // x 4 channels), so the row's channel moments sum P, sum P^2, sum P w_d - the LayerNorm statistics below are assembled from
+    // moments and ONE dot product per pair instead of a pass over z - cost three wave reductions per row
+    __shared__ float mom[3][64];
+    const float4 wd4 = *reinterpret_cast<const float4 *>(p.w_d + lane * 4);
     for (int idx = threadIdx.x; idx < 64 * (H / 4); idx += 256) {
         const int row = idx >> 6, c4 = idx & 63, gr = rt * 64 + row;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gr < p.R) v = *reinterpret_cast<const float4 *>(p.P + ((size_t)b * N + gr) * H + c4 * 4);
         Pt[(c4 * 4 + 0) * PT_LD + row] = v.x; Pt[(c4 * 4 + 1) * PT_LD + row] = v.y;
         Pt[(c4 * 4 + 2) * PT_LD + row] = v.z; Pt[(c4 * 4 + 3) * PT_LD + row] = v.w;
+        if (!EXACT) {
+            const float s1 = wave_sum((v.x + v.y) + (v.z + v.w));
+            const float s2 = wave_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+            const float sw = wave_sum((v.x * wd4.x + v.y * wd4.y) + (v.z * wd4.z + v.w * wd4.w));
+            if (lane == 0) { mom[0][row] = s1; mom[1][row] = s2; mom[2][row] = sw; }
+        }
     }
     __syncthreads();
+    const float sum_w = wave_sum((wd4.x + wd4.y) + (wd4.z + wd4.w));
+    const float sum_w2 = wave_sum((wd4.x * wd4.x + wd4.y * wd4.y) + (wd4.z * wd4.z + wd4.w * wd4.w));
+    const float mP = mom[0][lane], mP2 = mom[1][lane], mPw = mom[2][lane];
 
     const float4 xr = p.ca4[(size_t)b * N + (valid ? r : 0)];
     const float *Pl = Pt + lane;
@@ -73,15 +86,22 @@ __global__ __launch_bounds__(256) void k_pair_head(PairKArgs p)
             }
             rstd = 1.0f / sqrtf(v * (1.0f / H) + 1e-5f);
         } else {
-            float s = 0.f, q = 0.f;
+            // sum_c z and sum_c z^2 of z = P + Q + w_d D from the channel moments of the two rows and their dot product:
+            //   sum z   = sP + sQ + D sw
+            //   sum z^2 = sP2 + sQ2 + 2 P.Q + 2 D (sPw + sQw) + D^2 sw2
+            const float4 q4 = *reinterpret_cast<const float4 *>(Ql + lane * 4);
+            const float sQ = wave_sum((q4.x + q4.y) + (q4.z + q4.w));
+            const float sQ2 = wave_sum((q4.x * q4.x + q4.y * q4.y) + (q4.z * q4.z + q4.w * q4.w));
+            const float sQw = wave_sum((q4.x * wd4.x + q4.y * wd4.y) + (q4.z * wd4.z + q4.w * wd4.w));
+            float dot0 = 0.f, dot1 = 0.f;
 #pragma unroll 16
-            for (int c = 0; c < H; ++c) {
-                const float z = fmaf(p.w_d[c], D, Pl[c * PT_LD]) + Ql[c];
-                s += z;
-                q = fmaf(z, z, q);
+            for (int c = 0; c < H; c += 2) {
+                dot0 = fmaf(Pl[c * PT_LD], Ql[c], dot0);
+                dot1 = fmaf(Pl[(c + 1) * PT_LD], Ql[c + 1], dot1);
             }
-            mean = s * (1.0f / H);
-            rstd = __builtin_amdgcn_rsqf(fmaxf(q * (1.0f / H) - mean * mean, 0.f) + 1e-5f);
+            mean = ((mP + sQ) + D * sum_w) * (1.0f / H);
+            const float ez2 = (((mP2 + sQ2) + 2.0f * (dot0 + dot1)) + D * (2.0f * (mPw + sQw) + D * sum_w2)) * (1.0f / H);
+            rstd = __builtin_amdgcn_rsqf(fmaxf(ez2 - mean * mean, 0.f) + 1e-5f);
         }
         float o = 0.f;
         if (EXACT) {
