@@ -160,6 +160,24 @@ def make_random_weights(seed: int = 0, hp: HParams = HParams()) -> "OrderedDict[
     return out
 
 
+# Named weight draws of the parity suite (tests/golden/make_golden_draws.py runs the REFERENCE on each of them):
+# three independent seeds at the generator's scale and one draw at trained-like scale - every Linear of the edge, node and
+# coordinate MLPs (weights and biases) times 3, so pre-activations are O(10), SiLU runs well outside its linear range and the
+# attention gates saturate.  The trained checkpoint is not in the reference tree (.MISSING_LARGE_BLOBS).
+WEIGHT_DRAWS = {"s0": (0, 1.0), "s1": (1, 1.0), "s2": (2, 1.0), "x3": (3, 3.0)}
+_SCALED_LINEARS = ("edge_mlp.0.", "edge_mlp.2.", "node_mlp.0.", "node_mlp.3.", "coord_mlp.0.")
+
+
+def make_weight_draw(draw: str, hp: HParams = HParams()) -> "OrderedDict[str, np.ndarray]":
+    seed, scale = WEIGHT_DRAWS[draw]
+    w = make_random_weights(seed, hp)
+    if scale != 1.0:
+        for name in w:
+            if any(s in name for s in _SCALED_LINEARS):
+                w[name] = (w[name] * np.float32(scale)).astype(np.float32)
+    return w
+
+
 def pack_blob(weights, hp: HParams = HParams()) -> np.ndarray:
     """state_dict-like mapping (optionally ``net.``-prefixed) -> flat float32 blob."""
     parts = []

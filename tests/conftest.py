@@ -39,6 +39,39 @@ def blob_pair():
     return pack_blob(make_random_weights(0, hp), hp)
 
 
+# further weight draws (dfmdock_amd/weights.py: WEIGHT_DRAWS; fixtures tests/golden/draws_f<family>_<draw>.npz produced by
+# tests/golden/make_golden_draws.py running the reference on the seed-0 goldens' poses and edge lists)
+DRAWS = ("s1", "s2", "x3")
+DRAW_CASES = {0: ["fwd_syn_9_7", "fwd_syn_24_16", "fwd_syn_64_48_p0", "fwd_syn_64_48_p1", "fwd_syn_64_48_p2", "fwd_7CEI_p0",
+                  "fwd_7CEI_p1", "fwd_7CEI_p2", "fwd_7CEI_p3", "fwd_c3_300_300", "fwd_db5_1AVX"],
+              1: ["fwd2_syn_9_7", "fwd2_syn_24_16", "fwd2_syn_64_48_p0", "fwd2_syn_64_48_p1", "fwd2_syn_64_48_p2",
+                  "fwd2_7CEI_p0", "fwd2_7CEI_p1", "fwd2_7CEI_p2", "fwd_c3_300_300", "fwd_db5_1AVX"]}
+_draw_blobs = {}
+
+
+def draw_hparams(family):
+    from dfmdock_amd.weights import HParams
+    return pair_hparams() if family else HParams()
+
+
+def draw_blob(family, draw):
+    from dfmdock_amd.weights import make_weight_draw, pack_blob
+    if (family, draw) not in _draw_blobs:
+        hp = draw_hparams(family)
+        _draw_blobs[(family, draw)] = pack_blob(make_weight_draw(draw, hp), hp)
+    return _draw_blobs[(family, draw)]
+
+
+def draw_golden(family, draw, case):
+    """Outputs of the reference on weight draw `draw` for `case` (inputs = the seed-0 golden's pose, t and edge list)."""
+    d = load_golden(f"draws_f{family}_{draw}.npz")
+    g = load_golden(("rollout2_syn_24_16" if family else "rollout_syn_24_16") + ".npz") if case == "rollout" else \
+        {k: v for k, v in load_golden(case + ".npz").items() if k in ("lig_pos", "t", "edges")}
+    g = dict(g)
+    g.update({k.split("/", 1)[1]: v for k, v in d.items() if k.startswith(case + "/")})
+    return g
+
+
 _db5 = None
 
 

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Round-3 golden vectors: the REFERENCE run on further weight draws (dfmdock_amd/weights.py: WEIGHT_DRAWS = two more seeds
+and one draw with every edge / node / coordinate MLP Linear times 3), both model families.  Same rules as make_golden.py
+(imported for its stand-ins of the absent third-party modules): runs only in the build container, only the .npz travel.
+
+Every evaluation REPLAYS the edge list (and, for the rollouts, R0 / the N(0,30^2) draw / every z) of the seed-0 golden of
+the same case, so that a new fixture holds outputs only:
+
+  draws_f<family>_<draw>.npz   keys "<case>/<field>": tr_score, rot_score, energy, f, num_clashes, ires, h_absmean, h_absmax
+                               (+ confidence_logits for the second family) for the forward cases
+                               syn_9_7, syn_24_16, syn_64_48_p0..2, 7CEI_p0..3 (p0..2 second family), c3_300_300, db5_1AVX
+                               and "rollout/<field>": a 40-step sampler run on syn_24_16 (poses after every step, scores)
+
+Usage:  python tests/golden/make_golden_draws.py [draw ...]
+"""
+import os
+import sys
+from types import SimpleNamespace as NS
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation as SciRotation
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, ".."))
+import make_golden as mg  # noqa: E402
+import make_golden_pair as mgp  # noqa: E402
+
+import inference as inf1  # noqa: E402
+import inference_base as ib  # noqa: E402
+import models.egnn_net as en  # noqa: E402
+import models.score_net_mlsb as snm  # noqa: E402
+from utils.crop import get_position_matrix  # noqa: E402
+
+from conftest import complex_for, load_golden  # noqa: E402
+from dfmdock_amd.weights import HParams, WEIGHT_DRAWS, make_weight_draw  # noqa: E402
+
+inf1.tqdm = lambda x: x
+HP = {0: HParams(), 1: HParams(family=1, mask_dist=20.0)}
+
+FWD = {0: ["fwd_syn_9_7", "fwd_syn_24_16", "fwd_syn_64_48_p0", "fwd_syn_64_48_p1", "fwd_syn_64_48_p2", "fwd_7CEI_p0",
+           "fwd_7CEI_p1", "fwd_7CEI_p2", "fwd_7CEI_p3", "fwd_c3_300_300", "fwd_db5_1AVX"],
+       # the second family has no C3 / 1AVX golden of its own: it replays the first family's poses and edge lists there
+       1: ["fwd2_syn_9_7", "fwd2_syn_24_16", "fwd2_syn_64_48_p0", "fwd2_syn_64_48_p1", "fwd2_syn_64_48_p2", "fwd2_7CEI_p0",
+           "fwd2_7CEI_p1", "fwd2_7CEI_p2", "fwd_c3_300_300", "fwd_db5_1AVX"]}
+
+
+def build_net(family, draw):
+    hp = HP[family]
+    net = (mgp.build_net(0, hp) if family else mg.build_net(0))
+    w = make_weight_draw(draw, hp)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()}, strict=True)
+    return net.eval()
+
+
+def split_edges(e, hp):
+    e = e.astype(np.int64)
+    if e.shape[1] <= hp.knn:
+        return e, None
+    return e[:, :hp.knn], e[:, hp.knn:]
+
+
+def forward(family, net, case):
+    g = load_golden(case + ".npz")
+    cx = complex_for(case)
+    hp = HP[family]
+    batch = {k: torch.from_numpy(np.ascontiguousarray(cx[k])).float() for k in ("rec_x", "lig_x", "rec_pos", "lig_pos")}
+    batch["lig_pos"] = torch.from_numpy(g["lig_pos"]).float()
+    batch = get_position_matrix(batch) if family else ib.get_position_matrix(batch)
+    batch["t"] = torch.tensor([float(g["t"])], dtype=torch.float32)
+    recd = mg.EdgeRecorder(replay=[split_edges(g["edges"], hp)])
+    mod = en if family else snm
+    mod.get_knn_and_sample = recd
+    hs = []
+    hooks = [net.network._modules[f"EGNN_{l}"].register_forward_hook(lambda m, i, o: hs.append(o[0].detach().numpy().copy()))
+             for l in range(hp.depth)]
+    try:
+        out = mgp.Wrapper(net).forward(batch) if family else net(batch, predict=True)
+    finally:
+        for h in hooks:
+            h.remove()
+        mod.get_knn_and_sample = mgp._orig_knn if family else mg._orig_knn
+    assert recd.i == 1
+    r = {"tr_score": out["tr_score"].detach().numpy().reshape(3), "rot_score": out["rot_score"].detach().numpy().reshape(3),
+         "energy": np.float32(out["energy"].item()), "f": out["f"].detach().numpy(),
+         "num_clashes": np.int64(out["num_clashes"].item()),
+         "h_absmean": np.array([np.abs(h).mean() for h in hs]), "h_absmax": np.array([np.abs(h).max() for h in hs])}
+    if family:
+        r["confidence_logits"] = np.float32(out["confidence_logits"].item())
+        r["ires"] = out["ires_logits"].detach().numpy()[:, 0]
+    else:
+        r["ires"] = out["ires"].detach().numpy()[:, 0]
+    return r
+
+
+class Replayer:
+    """Patches the random sources of one sampler module so that they return recorded draws."""
+
+    def __init__(self, mod, g):
+        self.mod, self.g, self.iz = mod, g, 0
+
+    def __enter__(self):
+        g = self.g
+        self.o_rot, self.o_normal, self.o_randn = self.mod.Rotation, torch.normal, torch.randn
+        z = np.stack([g["z_rot"], g["z_tr"]], 1).reshape(-1, 3)      # call order: so3 then r3 per step
+
+        def randn(*a, **k):
+            v = torch.from_numpy(z[self.iz:self.iz + 1].copy())
+            self.iz += 1
+            return v
+
+        self.mod.Rotation = NS(random=lambda *a, **k: SciRotation.from_matrix(g["R0"]))
+        torch.normal = lambda *a, **k: torch.from_numpy(g["tr_draw"].copy())
+        torch.randn = randn
+        return self
+
+    def __exit__(self, *a):
+        self.mod.Rotation = self.o_rot
+        torch.normal, torch.randn = self.o_normal, self.o_randn
+
+
+def rollout(family, net, base_model):
+    case = "rollout2_syn_24_16" if family else "rollout_syn_24_16"
+    g = load_golden(case + ".npz")
+    cx = complex_for(case)
+    hp = HP[family]
+    steps = int(g["num_steps"])
+    batch = {k: torch.from_numpy(np.ascontiguousarray(cx[k])).float() for k in ("rec_x", "lig_x", "rec_pos", "lig_pos")}
+    batch = get_position_matrix(batch) if family else ib.get_position_matrix(batch)
+    recd = mg.EdgeRecorder(replay=[split_edges(e, hp) for e in g["edges"]])
+    mod, smod = (en, inf1) if family else (snm, ib)
+    mod.get_knn_and_sample = recd
+    poses = []
+    orig_modify = smod.modify_coords
+
+    def modify(x, rot, tr):
+        y = orig_modify(x, rot, tr)
+        poses.append(y.numpy().copy())
+        return y
+
+    import make_golden_r02 as m2
+    if family:
+        pm = m2.PairModel(net, base_model)
+        wm = m2.Wrapped(pm, keys=("tr_score", "rot_score", "energy", "f"))
+    else:
+        mm = mg.Model(net).eval()
+        wm = m2.Wrapped(mm)
+    smod.modify_coords = modify
+    try:
+        with Replayer(smod, g) as rp:
+            _, lig_pos, rot_update, tr_update, output = smod.Euler_Maruyama_sampler(
+                model=wm, batch=dict(batch), num_steps=steps, device="cpu")
+    finally:
+        smod.modify_coords = orig_modify
+        mod.get_knn_and_sample = mgp._orig_knn if family else mg._orig_knn
+    assert recd.i == steps + 1 and rp.iz == 2 * steps
+    return {"poses": np.stack(poses).astype(np.float32), "tr_score": np.stack([o["tr_score"][0] for o in wm.outs]),
+            "rot_score": np.stack([o["rot_score"][0] for o in wm.outs]), "energy": np.array([o["energy"] for o in wm.outs]),
+            "final_lig_pos": lig_pos.numpy(), "rot_update": rot_update.numpy(), "tr_update": tr_update.numpy(),
+            "final_energy": np.float32(output["energy"].item()), "final_num_clashes": np.int64(output["num_clashes"].item())}
+
+
+def main(draws):
+    base = mg.Model(mg.build_net(0)).eval()          # only its two diffusers are used by the second family's sampler
+    for draw in draws:
+        for family in (0, 1):
+            net = build_net(family, draw)
+            arrs = {}
+            for case in FWD[family]:
+                r = forward(family, net, case)
+                arrs.update({f"{case}/{k}": v for k, v in r.items()})
+                print(f"  f{family} {draw} {case}: |h| mean {r['h_absmean'][-1]:.3g} max {r['h_absmax'][-1]:.3g} "
+                      f"|tr| {np.abs(r['tr_score']).max():.3g} E {float(r['energy']):.4g}")
+            arrs.update({f"rollout/{k}": v for k, v in rollout(family, net, base).items()})
+            mg.save(f"draws_f{family}_{draw}.npz", draw=draw, **arrs)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or [d for d in WEIGHT_DRAWS if d != "s0"])

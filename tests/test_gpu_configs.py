@@ -105,7 +105,7 @@ def test_c2_7cei_batch64_bf16_sampler(model):
         assert (rb[k] == r1[k][0]).all(), k
     ca, ref = rb["trace_pose"][17][:, :, 1, :], g["poses"][:, :, 1, :]
     rmsd = np.sqrt(((ca - ref) ** 2).sum(-1).mean(-1))
-    assert rmsd[:5].max() < 0.5 and rmsd.max() < 3.0, rmsd
+    assert rmsd.max() < 0.5, rmsd
     nat = gx.sample(B=B, num_steps=40, seed=42, bf16=True)
     assert np.isfinite(nat["lig_pos"]).all() and np.isfinite(nat["energy"]).all()
     assert np.abs(nat["lig_pos"][0] - nat["lig_pos"][1]).max() > 1.0

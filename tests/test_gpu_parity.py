@@ -114,7 +114,7 @@ def test_sampler_injected_rollout(case, steps, prec, model):
     rmsd = np.sqrt(((ca - ref) ** 2).sum(-1).mean(-1))
     n5 = min(5, steps)
     assert rmsd[:n5].max() < (0.5 if bf16 else 0.05), rmsd[:n5]          # gate 3
-    assert rmsd.max() < (3.0 if bf16 else 0.5), rmsd.max()
+    assert rmsd.max() < 0.5, rmsd.max()      # all 40 steps, every engine (measured: 3.4e-2 A bf16, 3.1e-3 A f16)
     tol = {"fp32": 1e-4, "bf16": 1e-2, "f16": 3e-3}[prec]
     assert rel_inf(r["trace_scores"][0][0, 0:3], g["tr_score"][0]) < tol     # first evaluation = same pose
     assert rel_inf(r["trace_scores"][0][0, 3:6], g["rot_score"][0]) < tol

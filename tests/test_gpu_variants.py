@@ -53,7 +53,7 @@ def _inject(g, with_z=True):
     return inj
 
 
-ROLL_GATE = {"fp32": (0.05, 0.5), "bf16": (0.5, 3.0), "f16": (0.5, 3.0)}
+ROLL_GATE = {"fp32": (0.05, 0.5), "bf16": (0.5, 0.5), "f16": (0.5, 0.5)}
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])

@@ -307,3 +307,44 @@ def test_score_matches_reference_large(case, blob):
     assert rel_inf(r["rot_score"], g["rot_score"]) < 1e-4
     assert abs(float(r["energy"]) - float(g["energy"])) < 1e-4
     assert rel_inf(r["ires"], g["ires"][:, 0]) < 1e-4
+
+
+# ---- further weight draws (two more seeds + one 3x-scaled draw), both families: the reference run on each -----------------
+from conftest import DRAWS, DRAW_CASES, draw_blob, draw_golden, draw_hparams  # noqa: E402
+
+
+@pytest.mark.parametrize("draw", DRAWS)
+@pytest.mark.parametrize("family", [0, 1])
+def test_score_matches_reference_on_other_weight_draws(family, draw):
+    hp = draw_hparams(family)
+    bl = draw_blob(family, draw)
+    for case in DRAW_CASES[family]:
+        g = draw_golden(family, draw, case)
+        o = ora.Oracle(bl, complex_for(case), hp)
+        r = o.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32))
+        assert r["num_clashes"] == int(g["num_clashes"]), case
+        habs = np.abs(r["h_layers"]).reshape(hp.depth, -1)
+        np.testing.assert_allclose(habs.mean(1), g["h_absmean"], rtol=2e-5, err_msg=case)
+        assert rel_inf(r["f"], g["f"]) < 1e-4, case
+        assert rel_inf(r["tr_score"], g["tr_score"]) < 1e-4, case
+        assert rel_inf(r["rot_score"], g["rot_score"]) < 1e-4, case
+        assert abs(float(r["energy"]) - float(g["energy"])) < 1e-4 * max(1.0, abs(float(g["energy"]))), case
+        assert rel_inf(r["ires"], g["ires"]) < 1e-4, case
+        if family:
+            assert abs(float(r["confidence"]) - float(g["confidence_logits"])) < 1e-4, case
+
+
+@pytest.mark.parametrize("draw", DRAWS)
+@pytest.mark.parametrize("family", [0, 1])
+def test_sampler_rollout_on_other_weight_draws(family, draw):
+    """40 reference sampler steps per draw with R0 / the N(0,30^2) draw / z / edge lists of the seed-0 rollout replayed."""
+    g = draw_golden(family, draw, "rollout")
+    o = ora.Oracle(draw_blob(family, draw), complex_for("syn_24_16"), draw_hparams(family))
+    inj = dict(R0=g["R0"], tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"])
+    r = o.sample(num_steps=40, inject=inj, trace=True)
+    rmsd = _ca_rmsd(r["trace_pose"], g["poses"])
+    assert rmsd[:5].max() < 0.05 and rmsd.max() < 0.5, rmsd
+    if rmsd.max() < 1e-3:
+        assert abs(float(r["energy"]) - float(g["final_energy"])) < 1e-3 * max(1.0, abs(float(g["final_energy"])))
+        np.testing.assert_allclose(r["tr_update"], g["tr_update"], atol=2e-3)
+        np.testing.assert_allclose(r["rot_update"], g["rot_update"], atol=2e-4)
