@@ -8,13 +8,20 @@ the timed region; one call returns only ~40 B per trajectory.  With N > 1 GPUs e
 B trajectories (weak scaling, no data-path collective) and one tiny all_gather of energy-ranked
 records closes the step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16|fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16|f16|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with no RANK in the environment starts the N ranks itself (one process per GPU, rendezvous on
+127.0.0.1) and still prints ONE JSON line.  The record gather runs over RCCL ("nccl") when every rank's RCCL probe succeeds,
+else over gloo, else over files (dfmdock_amd/distributed.py); the line says which ("backend", "backend_fallback").
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,7 +33,7 @@ sys.path.insert(0, ROOT)
 # per node and layer 2*K*H*H (edge_mlp.2) + 2*K*H (attention gate)
 H, K_DEG = 256, 60
 FLOP_PER_NODE_LAYER = 2 * K_DEG * H * H + 2 * K_DEG * H
-PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_MFMA16_TFLOPS = 2500.0   # dense MFMA bf16 / fp16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3       # fp32 vector / f32-input MFMA
 
 
@@ -44,8 +51,8 @@ def cpu_baseline(blob, cx, num_steps, repeats=3):
     """Oracle (plain-C port of the reference as written, OpenMP) timed on the host cores of this box on a bounded sample:
     a few score evaluations of ONE trajectory of the same complex, extrapolated to the 41 evaluations of a trajectory.
     Threads are pinned (OMP_PROC_BIND / OMP_PLACES, set in main() before the OpenMP runtime starts), one untimed
-    evaluation warms the pages, and the reported value is the MEDIAN of `repeats` samples; the same is measured with 8
-    threads."""
+    evaluation warms the pages, every thread count is sampled `repeats` times (median kept) and `value` is the BEST of the
+    thread counts tried - the port does not scale to all the cores of a large host, so "all cores" understates the CPU."""
     import statistics
     from oracle import oracle as ora
     L = ora.lib()
@@ -63,30 +70,80 @@ def cpu_baseline(blob, cx, num_steps, repeats=3):
             vals.append(1.0 / (dt / max(res["forwards"], 1) * (num_steps + 1)))
         return vals
 
-    full = sample(all_cores, 6)
-    eight = sample(min(8, all_cores), 2)
+    counts = sorted({min(8, all_cores), min(32, all_cores), all_cores})
+    runs = {n: sample(n, 6 if n >= 32 else 2) for n in counts}
     L.ora_set_num_threads(all_cores)
-    return {"value": statistics.median(full), "unit": "trajectories/s", "cores": all_cores, "kind": "port",
-            "repeats": [round(v, 5) for v in full], "value_8_threads": statistics.median(eight),
-            "repeats_8_threads": [round(v, 5) for v in eight], "cpu_model": cpu_model(),
-            "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
-            "sample": f"median of {repeats} x 6 (all {all_cores} threads) / {repeats} x 2 (8 threads) score evaluations of 1 trajectory "
-                      f"of the same complex, after one warm-up evaluation, extrapolated to {num_steps + 1} evaluations per trajectory"}
+    med = {n: statistics.median(v) for n, v in runs.items()}
+    best = max(med, key=med.get)
+    return {"value": med[best], "unit": "trajectories/s", "cores": best, "kind": "port", "host_cores": all_cores,
+            "by_threads": {str(n): {"median": med[n], "repeats": [round(v, 5) for v in runs[n]]} for n in counts},
+            "cpu_model": cpu_model(), "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
+            "sample": f"per thread count: median of {repeats} x (6 score evaluations at >= 32 threads, 2 below) of 1 trajectory of the "
+                      f"same complex after one warm-up evaluation, extrapolated to {num_steps + 1} evaluations per trajectory; "
+                      f"value = the best thread count ({best})"}
 
 
-def replayed_traffic(args):
-    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process: the number is
-    REPLAYED from the committed rocprofv3 --pmc run of this exact configuration (profiles/*_traffic.json, collected as
-    MI355X_MICROARCH.md prescribes: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2) and is absent otherwise."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+def replayed_counters(args):
+    """HBM bytes per launch and pipe-busy fractions of the dominant kernel.  PMC counters cannot be read from inside this
+    process: the numbers are REPLAYED from the committed rocprofv3 --pmc run of this exact configuration (profiles/*_traffic.json,
+    collected as MI355X_MICROARCH.md prescribes: separate passes, FETCH_SIZE x 2 + WRITE_SIZE) and absent otherwise."""
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
             continue
         c = t["config"]
         if (c["R"], c["L"], c["batch"], c["precision"]) == (args.R, args.L, args.batch, args.precision):
-            return t["traffic_bytes_per_launch"], "replayed profiles/" + name
+            return t, "replayed profiles/" + name
     return None, None
+
+
+def workload_label(a):
+    shape = f"synthetic {a.R}+{a.L}-residue complex, batch={a.batch} trajectories/GPU, {a.num_steps} steps ({a.num_steps + 1} score evaluations + energy head)"
+    if (a.R, a.L, a.batch, a.num_steps) == (300, 300, 256, 40):
+        return "C3: " + shape
+    if (a.R, a.L, a.batch, a.num_steps) == (1000, 1000, 32, 40):
+        return "C5: " + shape
+    return "custom: " + shape
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (this same command line, one process per GPU) with a
+    loopback rendezvous, wait for them, pass rank 0's JSON line through.  A rank that dies takes the others down."""
+    port = free_port()
+    gather_dir = tempfile.mkdtemp(prefix="dfm_gather_")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DFM_GATHER_DIR=gather_dir, DFM_BENCH_SELF_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs and rc == 0:
+            for p in list(procs):
+                code = p.poll()
+                if code is not None:
+                    procs.remove(p)
+                    rc = rc or code
+            time.sleep(0.05)
+    finally:
+        for p in procs:      # exact PIDs of the children started above
+            p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
 
 
 def main():
@@ -99,35 +156,33 @@ def main():
     ap.add_argument("--L", type=int, default=300)
     ap.add_argument("--num-steps", type=int, default=40, help="diffusion steps per trajectory")
     ap.add_argument("--precision", choices=["bf16", "f16", "fp32"], default="bf16",
-                    help="bf16 / f16: 16-bit MFMA operands for the per-edge contractions (fp32 accumulate); fp32: exact")
+                    help="bf16: the 16-bit MFMA engine as shipped (DFM_F_MFMA16; dfm_config_string() in the JSON line says what "
+                         "that is); f16: the same with fp32 A_i; fp32: exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    # pin the CPU baseline's OpenMP threads (must be in the environment before the oracle library starts its runtime)
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     from dfmdock_amd import distributed as D
+    rank, local_rank, world = D.dist_env()
+    if world == 1:
+        # pin the CPU baseline's OpenMP threads (must be in the environment before the oracle library starts its runtime);
+        # only where the baseline is measured: N ranks pinned to the same places would share cores
+        os.environ.setdefault("OMP_PROC_BIND", "close")
+        os.environ.setdefault("OMP_PLACES", "cores")
+    import torch
     from dfmdock_amd import engine
     from dfmdock_amd.synthetic import make_complex
     from dfmdock_amd.weights import make_random_weights, pack_blob
 
-    rank, local_rank, world = D.dist_env()
     ndev = max(torch.cuda.device_count(), 1)
-    dev = local_rank % ndev            # one process per GPU; the modulo only matters for single-GPU dry runs
-    backend = os.environ.get("DFM_DIST_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" for dry runs on one GPU
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(dev)
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(backend=backend)
+    dev = local_rank % ndev            # one process per GPU; the modulo only matters for dry runs with more ranks than GPUs
+    torch.cuda.set_device(dev)
+    grp = D.init(device_index=dev)     # nccl (= RCCL) -> gloo -> files, whatever works on every rank
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     engine.set_device(dev)
-    torch.cuda.set_device(dev)
 
     blob = pack_blob(make_random_weights(0))
     cx = make_complex(args.R, args.L, seed=1)
@@ -140,13 +195,12 @@ def main():
 
     def one_step(it, profile=False):
         r = gx.sample(B=B, num_steps=args.num_steps, seed=1000 * (rank + 1) + it, bf16=bf16, f16=f16, profile=profile)
-        rec = D.make_records(0, np.arange(rank * B, (rank + 1) * B), r)
+        rec = D.make_records(rank, np.arange(rank * B, (rank + 1) * B), r)      # record id = the rank that sampled it
         allrec = D.gather_records(rec)            # the only collective: ranked energies (RCCL all_gather)
         return r, allrec
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     for it in range(args.warmup):
@@ -154,6 +208,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     edge_ms, edge_launches, edge_rows = 0.0, 0, 0
+    allrec = None
     for it in range(args.steps):
         _, allrec = one_step(args.warmup + it, profile=True)
         p = gx.profile()
@@ -162,23 +217,22 @@ def main():
         edge_rows += p["edge_rows"]
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    per_rank = D.allgather_scalars([elapsed, float(dev)])      # max over ranks of the time; which device every rank ran on
+    elapsed = float(per_rank[:, 0].max())
 
     if rank == 0:
         total_traj = world * B * args.steps
-        N = args.R + args.L
-        # every launch of the message kernel inside the timed region is bracketed by HIP events on the engine's stream; the last
-        # layer runs as several smaller launches (trajectory chunks), so work and time are summed over launches:
+        ranks_seen = sorted(set(allrec[:, 0].astype(int).tolist())) if allrec is not None else []
+        assert allrec is None or allrec.shape[0] == world * B, f"record gather returned {allrec.shape[0]} records, expected {world * B}"
+        # every launch of the message kernel inside the timed region is bracketed by HIP events on the engine's stream:
         # achieved = (edge rows processed / K) * FLOP per node and layer / total kernel time
         avg_launch_s = edge_ms / max(edge_launches, 1) * 1e-3
         flop_total = edge_rows / K_DEG * FLOP_PER_NODE_LAYER
         flop_per_launch = flop_total / max(edge_launches, 1)
         achieved = flop_total / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
-        peak = PEAK_BF16_TFLOPS if mfma16 else PEAK_F32_TFLOPS
-        traffic, traffic_src = replayed_traffic(args)
+        peak = PEAK_MFMA16_TFLOPS if mfma16 else PEAK_F32_TFLOPS
+        ctr, ctr_src = replayed_counters(args)
+        traffic = ctr["traffic_bytes_per_launch"] if ctr else None
         out = {
             "metric": "docking trajectories/sec (N_res~300+300, 40 steps)",
             "value": total_traj / elapsed,
@@ -190,33 +244,38 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": args.precision if mfma16 else "f32",
+            "dtype": "f16" if mfma16 else "f32",
             "data": "synthetic",
-            "config": {"workload": f"C3: synthetic {args.R}+{args.L}-residue complex, batch={B} trajectories/GPU, "
-                                   f"{args.num_steps} steps ({args.num_steps + 1} score evaluations + energy head)",
+            "backend": grp.backend,
+            "backend_fallback": grp.fallback_reason,
+            "ranks_in_gather": len(ranks_seen) if world > 1 else 1,
+            "distinct_devices": len(set(per_rank[:, 1].astype(int).tolist())),
+            "config": {"workload": workload_label(args),
                        "trajectories_per_gpu": B, "num_steps": args.num_steps, "parallelism": f"traj-shard x{world}",
                        "weights": "random-init (seeded generator; trained checkpoint not in the reference)",
-                       "precision": ("bf16 MFMA operands for the per-edge contractions of layers 0-4, fp16 operands (same rate) for the last "
-                                     "layer and the coordinate head, fp32 accumulate; split-bf16 node GEMMs; fp32 geometry / heads / SDE step")
-                                    if bf16 else args.precision},
-            "roofline": {"bound": "mfma", "kernel": ("k_edge_msg<%s>" % ("1" if f16 else "0|1: bf16 operands, last layer fp16")) if mfma16 else "k_edge_f32", "achieved": achieved,
+                       "precision": (("16-bit MFMA engine" + (" with fp32 A_i (DFM_F_F16)" if f16 else "") + ": ") if mfma16 else "fp32 engine; library plan: ")
+                                    + engine.config_string(),
+                       "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DFM_") and k not in
+                                        ("DFM_GATHER_DIR", "DFM_BENCH_SELF_SPAWNED")}},
+            "roofline": {"bound": "mfma", "kernel": "k_edge_msg<1,%d> (fp16 operands, all six layers)" % (0 if f16 else 1) if mfma16 else "k_edge_f32",
+                         "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
-                         "flop_per_launch": flop_per_launch, "traffic": traffic, "traffic_source": traffic_src,
+                         "flop_per_launch": flop_per_launch, "traffic": traffic, "traffic_source": ctr_src,
                          "traffic_gbps": (traffic / avg_launch_s / 1e9) if traffic else None,
+                         "mfma_busy": ctr.get("mfma_busy") if ctr else None, "valu_busy": ctr.get("valu_busy") if ctr else None,
                          "rows_per_launch": edge_rows / max(edge_launches, 1),
                          "algorithmic_bytes_per_launch": 8 * H * edge_rows / K_DEG / max(edge_launches, 1),
                          "note": "achieved = B*N*(2*K*H*H + 2*K*H) FLOP / launch time from HIP events on the engine's stream, live; "
-                                 "traffic = HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE), not measured in this run: see "
-                                 "traffic_source; algorithmic bytes per launch = 8*N*H per trajectory (SURVEY 8d)"},
-            "best_energy": float(D.rank_by_energy(allrec)[0][0, 2]),
+                                 "traffic = HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE), mfma_busy / valu_busy = pipe-busy fractions "
+                                 "(SQ_VALU_MFMA_BUSY_CYCLES, SQ_ACTIVE_INST_VALU x 4 per SIMD over GRBM_GUI_ACTIVE): not measured in this "
+                                 "run, see traffic_source; algorithmic bytes per launch = 8*N*H per trajectory (SURVEY 8d)"},
+            "best_energy": float(allrec[:, 2].min()),
         }
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(blob, cx, args.num_steps)
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    D.shutdown()
 
 
 if __name__ == "__main__":

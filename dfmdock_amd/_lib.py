@@ -15,7 +15,8 @@ F32P = C.POINTER(C.c_float)
 I32P = C.POINTER(C.c_int32)
 U32P = C.POINTER(C.c_uint32)
 
-DFM_F_BF16 = 1 << 0
+DFM_F_MFMA16 = 1 << 0
+DFM_F_BF16 = DFM_F_MFMA16      # name of rounds 1-2
 DFM_F_ENERGY = 1 << 1
 DFM_F_NOISE_ANNEALING = 1 << 2
 DFM_F_CLASH_FORCE = 1 << 3
@@ -24,9 +25,10 @@ DFM_F_PROFILE = 1 << 5
 DFM_F_STEP_ENERGY = 1 << 6
 DFM_F_F16 = 1 << 7
 DFM_F_IRES = 1 << 8
+DFM_F_BF16_OPS = 1 << 9
 
 EXPORTS = [
-    "dfm_last_error", "dfm_device_count", "dfm_set_device", "dfm_default_hparams", "dfm_param_count",
+    "dfm_last_error", "dfm_config_string", "dfm_device_count", "dfm_set_device", "dfm_default_hparams", "dfm_param_count",
     "dfm_model_create", "dfm_model_destroy", "dfm_complex_create", "dfm_complex_destroy", "dfm_complex_degree",
     "dfm_complex_set_pose", "dfm_complex_set_homomer",
     "dfm_score", "dfm_sample", "dfm_get_profile", "dfm_diffusion_coef",
@@ -76,6 +78,7 @@ def lib():
             "__graft_entry__ as g; g.build()'` (or `make -C dfmdock_amd/csrc`). There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
     L.dfm_last_error.restype = C.c_char_p
+    L.dfm_config_string.restype = C.c_char_p
     L.dfm_device_count.argtypes = [C.POINTER(C.c_int)]
     L.dfm_set_device.argtypes = [C.c_int]
     L.dfm_default_hparams.argtypes = [C.POINTER(HParamsC)]

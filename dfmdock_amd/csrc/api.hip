@@ -94,6 +94,7 @@ struct Workspace {
     float *fvec = nullptr, *en_part = nullptr; int32_t *clash_part = nullptr;
     float *fpart = nullptr, *cpart = nullptr, *conf = nullptr;    // family 1: force partials per receptor tile, confidence
     float *scores = nullptr, *lig_cur = nullptr, *tr_update = nullptr, *rot_update = nullptr, *t_dev = nullptr;
+    float *ir1 = nullptr, *ir2 = nullptr, *ir3 = nullptr;      // to_ires scratch, allocated on the first DFM_F_IRES call
 };
 
 struct dfm_complex {
@@ -563,9 +564,18 @@ extern "C" int dfm_complex_set_homomer(dfm_complex *cx, int flag)
         return fail(DFM_E_INVALID, "the model has no sym channel (positional_embed_dim is 66)");
     if (flag == cx->homomer) return DFM_OK;
     DEVICE_SCOPE(cx->device);
+    // the flag is committed only once the layer-0 projections that depend on it are rebuilt: a failed call leaves the old state
+    // usable and a retry with the same flag does the work again instead of returning DFM_OK on stale operands
+    const int old = cx->homomer;
     cx->homomer = flag;
-    HIPCHK(project_layer0(cx));
-    HIPCHK(hipStreamSynchronize(cx->stream));
+    hipError_t e = project_layer0(cx);
+    if (e == hipSuccess) e = hipStreamSynchronize(cx->stream);
+    if (e != hipSuccess) {
+        cx->homomer = old;
+        (void)project_layer0(cx);                      // best effort: put the old projection back
+        (void)hipStreamSynchronize(cx->stream);
+        return fail(DFM_E_HIP, hipGetErrorString(e));
+    }
     return DFM_OK;
 }
 
@@ -575,6 +585,10 @@ extern "C" int dfm_complex_degree(const dfm_complex *cx) { return cx ? cx->K : -
 static int ensure_workspace(dfm_complex *cx, int B, bool bf16)
 {
     Workspace &W = cx->ws;
+    // the 16-bit message kernel addresses edges / codes / radial through buffer descriptors rooted at the whole [B][N][K] arrays with
+    // 32-bit byte offsets: past 2 GiB the loads would silently return 0
+    if ((unsigned long long)B * (unsigned long long)cx->N * (unsigned long long)cx->K * 4ull >= (1ull << 31))
+        return fail(DFM_E_INVALID, "B * N * K * 4 must stay below 2^31: split the batch");
     const bool wants_mbuf = bf16 && cx->m->hp.family == 0;    // gated messages for the coordinate MLP (family 0 only)
     const bool need_mbuf = wants_mbuf && !W.mbuf;
     if (B <= W.Bcap && !need_mbuf) return DFM_OK;
@@ -618,35 +632,46 @@ __global__ void k_fill(float *dst, float v, int n)
     if (i < n) dst[i] = v;
 }
 
-// The bf16 engine runs its LAST layer's message kernel and the coordinate MLP on fp16 operands (same MFMA rate, 3 more mantissa
-// bits): the force f is read directly off that layer, and this alone brings the worst deviation of f / tr_score from the
-// reference from 1.1e-2 / 3.8e-3 to 4.8e-3 / 1.2e-3 at 0.5 % of the time (tools/tol_report.py; DFM_F16_LAST_LAYERS=0 restores
-// pure bf16, =6 is the f16 engine)
-static int f16_last_layers()
+// Precision plan of the 16-bit MFMA engine (DFM_F_MFMA16).  Chosen on FOUR weight draws run through the reference - three
+// seeds and one draw with every edge / node / coordinate MLP Linear times 3 (tests/golden/make_golden_draws.py,
+// profiles/r03_exp_draw_knobs*.txt) - at SURVEY 8(d)'s gates (1e-2 on f / scores, 3e-2 on energy):
+//   * per-edge contractions: fp16 operands in EVERY layer (same MFMA rate as bf16, 3 more mantissa bits).  With bf16 operands in
+//     layers 0..4 (the r02 plan, now opt-in: DFM_F_BF16_OPS) the 3x-scaled draw reaches 1.5e-2 on f and 1.4e-2 on rot_score: the
+//     rounding of the 256 x 256 weights to 8 bits is coherent over all edges and does not average out.  fp16 has no range cost
+//     here: the gathered operands (Wb h_j, the lookup tables) are stored as fp16 in either plan.
+//   * A_i = Wa h_i + b1 is read as fp16 in every layer (it joins Bm_j and the tables; fp32 A_i changes no worst case); the f16
+//     engine (DFM_F_F16) keeps fp32.
+//   * node-level GEMMs: three terms on split-bf16 operands (~1e-5).  The two-term fp16 form (weights as ONE fp16 tile, r02) is
+//     13 % faster per launch but its 2.4e-4 weight rounding is again coherent: 9.2e-3 on tr_score of the second family (seed 1).
+// DFM_GEMM_TERMS=2 (diagnostic, echoed by dfm_config_string) restores the two-term form for A/B runs.
+static bool gemm_two_term()
 {
-    static const int v = [] { const char *e = getenv("DFM_F16_LAST_LAYERS"); return e ? atoi(e) : 1; }();
+    static const bool v = [] { const char *e = getenv("DFM_GEMM_TERMS"); return e && atoi(e) == 2; }();
     return v;
 }
 
-// Node-level GEMMs of the bf16 engine: two terms on fp16 operands (weights as one fp16 tile, k_gemm_split<.,1>) - ~3e-4 relative per
-// output, an order below the engine's bf16 per-edge contractions, for 13 % less time per launch.  The f16 engine (tighter gates)
-// and DFM_GEMM_TERMS=3 keep the three-term split-bf16 form (~1e-5).
-// bf16-operand message launches read A_i = Wa h_i + b1 as fp16 (the [Wa|Wb] GEMM writes it that way): one load per chunk less in
-// the kernel and a third less output of that GEMM; the operand joins Bm_j and the tables, which are fp16 already.
-// fp16-operand launches (the f16 engine, the bf16 engine's last layer) keep fp32.  DFM_EDGE_AW16=0 turns it off.
-static bool edge_aw16()
+extern "C" const char *dfm_config_string(void)
 {
-    static const bool v = [] { const char *e = getenv("DFM_EDGE_AW16"); return !(e && atoi(e) == 0); }();
-    return v;
-}
-static bool gemm_two_term()
-{
-    static const bool v = [] { const char *e = getenv("DFM_GEMM_TERMS"); return !(e && atoi(e) == 3); }();
-    return v;
+    static const std::string v = [] {
+        std::string c = "mfma16: per-edge operands fp16 in every layer (DFM_F_BF16_OPS: bf16 in layers 0..depth-2), A_i fp16 "
+                        "(DFM_F_F16: fp32), gathered Bm / tables fp16, node GEMMs ";
+        c += gemm_two_term() ? "TWO-term fp16 (DFM_GEMM_TERMS=2)" : "three-term split-bf16";
+        c += ", fp32 accumulate / geometry / GraphNorm statistics / heads / SDE step";
+        c += "; build: TAB_MERGE=" + std::to_string((int)DFM_TAB_MERGE);
+        std::string env;
+        for (const char *k : {"DFM_GEMM_TERMS", "DFM_GEMM_MT", "DFM_EDGE_SPLIT", "DFM_LIB"}) {
+            const char *e = getenv(k);
+            if (e) env += std::string(env.empty() ? "" : " ") + k + "=" + e;
+        }
+        c += "; env: " + (env.empty() ? std::string("none") : env);
+        return c;
+    }();
+    return v.c_str();
 }
 
 struct FwdOpts {
-    bool bf16 = false, f16 = false, want_energy = false, profile = false;   // bf16: 16-bit MFMA engine; f16: with fp16 operands
+    bool bf16 = false, f16 = false, want_energy = false, profile = false;   // bf16: 16-bit MFMA engine; f16: ... with fp32 A_i
+    bool bf16_ops = false;                // bf16 MFMA operands in every layer but the last (DFM_F_BF16_OPS)
     const int32_t *edges_dev = nullptr;   // [B][N][K] already on device (or nullptr = sample natively)
     int64_t edges_pitch = 0;              // elements between trajectories in edges_dev
     uint64_t seed = 0;
@@ -688,8 +713,8 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         std::memset(&e, 0, sizeof(e));
         if (l == 0) { e.A = o.bf16 ? cx->A0s : cx->A0; e.Bm = cx->Bm0; e.Bmb = cx->Bmb0; e.ab_bstride = 0; }
         else { e.A = W.A; e.Bm = W.Bm; e.Bmb = W.Bmb; e.ab_bstride = (int64_t)N * H; }
-        auto layer_f16 = [&](int ll) { return o.f16 || ll >= depth - f16_last_layers(); };
-        auto layer_aw16 = [&](int ll) { return o.bf16 && !layer_f16(ll) && edge_aw16(); };
+        auto layer_f16 = [&](int ll) { return o.f16 || !o.bf16_ops || ll >= depth - 1; };
+        auto layer_aw16 = [&](int) { return o.bf16 && !o.f16; };
         e.Ah = layer_aw16(l) ? (l == 0 ? cx->A0h : reinterpret_cast<const uint16_t *>(W.A)) : nullptr;
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
         e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = coord; e.fout = W.fvec; e.mbuf = W.mbuf;
@@ -847,7 +872,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
 {
     if (!cx || !lig_pos || !t || !out || !out->tr_score || !out->rot_score) return fail(DFM_E_INVALID, "NULL argument");
     if (B < 1) return fail(DFM_E_INVALID, "B must be >= 1");
-    const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_BF16) || f16, want_energy = flags & DFM_F_ENERGY;
+    const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_MFMA16) || f16, want_energy = flags & DFM_F_ENERGY;
     const bool want_ires = (flags & DFM_F_IRES) && out->ires;
     DEVICE_SCOPE(cx->device);
     int rc = ensure_workspace(cx, B, bf16);
@@ -868,13 +893,13 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
         HIPCHK(hipMemcpyAsync(edges_dev, edges, (size_t)B * N * K * 4, hipMemcpyHostToDevice, s));
     }
     if (out->h_first) HIPCHK(tmp.alloc(&h_first_dev, (size_t)B * N * H));
-    float *ir1 = nullptr, *ir2 = nullptr, *ir3 = nullptr;
-    if (want_ires) {
-        HIPCHK(tmp.alloc(&ir1, (size_t)B * N * 2 * H)); HIPCHK(tmp.alloc(&ir2, (size_t)B * N * 2 * H));
-        HIPCHK(tmp.alloc(&ir3, (size_t)B * N));
+    if (want_ires && !W.ir1) {      // kept with the workspace: a forward() loop does not pay three hipMalloc / hipFree pairs per call
+        HIPCHK(W.pool.alloc(&W.ir1, (size_t)W.Bcap * N * 2 * H)); HIPCHK(W.pool.alloc(&W.ir2, (size_t)W.Bcap * N * 2 * H));
+        HIPCHK(W.pool.alloc(&W.ir3, (size_t)W.Bcap * N));
     }
+    float *ir1 = W.ir1, *ir2 = W.ir2, *ir3 = W.ir3;
     FwdOpts o;
-    o.bf16 = bf16; o.f16 = f16; o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
+    o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
     o.edges_pitch = (int64_t)N * K; o.seed = seed; o.h_first_out = h_first_dev;
     HIPCHK(hipEventRecord(cx->ev_total[0], s));
     rc = enqueue_forward(cx, B, o);
@@ -934,7 +959,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
 {
     if (!cx || !out) return fail(DFM_E_INVALID, "NULL argument");
     if (B < 1 || num_steps < 2) return fail(DFM_E_INVALID, "need B >= 1 and num_steps >= 2");
-    const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_BF16) || f16;
+    const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_MFMA16) || f16;
     DEVICE_SCOPE(cx->device);
     int rc = ensure_workspace(cx, B, bf16);
     if (rc) return rc;
@@ -983,7 +1008,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
         HIPCHK(hipMemcpyAsync(ip_d, W.lig_cur, (size_t)B * L * 9 * 4, hipMemcpyDeviceToDevice, s));
     }
     FwdOpts o;
-    o.bf16 = bf16; o.f16 = f16; o.profile = flags & DFM_F_PROFILE; o.seed = seed; o.edges_pitch = (int64_t)(S + 1) * N * K;
+    o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.profile = flags & DFM_F_PROFILE; o.seed = seed; o.edges_pitch = (int64_t)(S + 1) * N * K;
     const bool step_energy = (flags & DFM_F_STEP_ENERGY) != 0;
     for (int i = 0; i < num_steps; ++i) {
         const bool is_last = (i == num_steps - 1);

@@ -1061,7 +1061,7 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
             if (e != hipSuccess) return e;
         }
     }
-    if (a.f16) return launch_msg_t<1, 0>(k, tasks, s);
+    if (a.f16) return a.Ah ? launch_msg_t<1, 1>(k, tasks, s) : launch_msg_t<1, 0>(k, tasks, s);
     return a.Ah ? launch_msg_t<0, 1>(k, tasks, s) : launch_msg_t<0, 0>(k, tasks, s);
 }
 

@@ -6,6 +6,12 @@ path shards with NO data-path collective: rank r samples its own block of
 trajectories and ONE small all_gather of fixed-size records
 (complex id, trajectory id, energy, num_clashes, rot_update[3], tr_update[3])
 happens at the end - RCCL over xGMI on GPUs (backend "nccl"), gloo in CPU tests.
+
+`init()` brings the process group up so that a broken RCCL never kills a job whose data path needs no collective at all: a gloo
+group (TCP on the loopback) is the control plane, the RCCL group is probed with one small all_reduce and used for the record
+gather only if EVERY rank's probe succeeded; otherwise the gather runs over gloo, and with no torch.distributed rendezvous at
+all (independent replicas started with RANK / WORLD_SIZE / DFM_GATHER_DIR) over files - SURVEY.md 8(e)'s last row.  What was
+actually used is returned and ends up in bench.py's JSON line.
 """
 from __future__ import annotations
 
@@ -20,6 +26,111 @@ def dist_env():
     """(rank, local_rank, world_size) from the torchrun environment (1-process default)."""
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
             int(os.environ.get("WORLD_SIZE", 1)))
+
+
+class Group:
+    """What init() settled on: `backend` in {"single", "nccl", "gloo", "file"}, the group handle the record gather uses, the
+    reason a preferred backend was not used (or None)."""
+
+    def __init__(self, backend, rank=0, world=1, data_group=None, fallback_reason=None, gather_dir=None):
+        self.backend, self.rank, self.world = backend, rank, world
+        self.data_group, self.fallback_reason, self.gather_dir = data_group, fallback_reason, gather_dir
+        self._file_round = 0
+
+
+_group = Group("single")
+
+
+def current_group() -> Group:
+    return _group
+
+
+def init(device_index: int | None = None, prefer: str | None = None, timeout_s: float = 120.0) -> Group:
+    """Bring up the collective layer for this rank (see the module docstring).  `prefer`: "nccl" (default on a GPU box; env
+    DFM_DIST_BACKEND overrides), "gloo" or "file"."""
+    global _group
+    import datetime
+    rank, _, world = dist_env()
+    prefer = prefer or os.environ.get("DFM_DIST_BACKEND", "nccl")
+    if world == 1:
+        _group = Group("single")
+        return _group
+    gather_dir = os.environ.get("DFM_GATHER_DIR")
+    if prefer == "file" or "MASTER_PORT" not in os.environ:
+        if not gather_dir:
+            raise RuntimeError("WORLD_SIZE > 1 without a torch.distributed rendezvous needs DFM_GATHER_DIR for the file gather")
+        _group = Group("file", rank, world, gather_dir=gather_dir,
+                       fallback_reason=None if prefer == "file" else "no MASTER_PORT: independent replicas")
+        return _group
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    try:
+        if not dist.is_initialized():
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+    except Exception as e:      # no control plane either: replicas + files, if a directory was provided
+        if not gather_dir:
+            raise
+        _group = Group("file", rank, world, gather_dir=gather_dir, fallback_reason=f"gloo init failed: {e}")
+        return _group
+    reason, data_group, ok = None, None, 0
+    if prefer == "nccl":
+        try:
+            if not torch.cuda.is_available():
+                raise RuntimeError("no GPU visible to torch")
+            if device_index is not None:
+                torch.cuda.set_device(device_index)
+            data_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe, group=data_group)
+            torch.cuda.synchronize()
+            ok = int(round(float(probe.item()))) == world
+            if not ok:
+                reason = f"nccl probe all_reduce returned {float(probe.item())} on {world} ranks"
+        except Exception as e:
+            reason = f"nccl failed: {type(e).__name__}: {str(e).splitlines()[0][:200]}"
+            ok = 0
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # over gloo: do ALL ranks have a working RCCL group?
+        if int(flag.item()) == 1:
+            _group = Group("nccl", rank, world, data_group=data_group)
+            return _group
+        reasons = [None] * world
+        dist.all_gather_object(reasons, reason)
+        reason = next((r for r in reasons if r), "nccl failed on another rank")
+    _group = Group("gloo", rank, world, data_group=None, fallback_reason=reason)
+    return _group
+
+
+def shutdown():
+    global _group
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+    finally:
+        _group = Group("single")
+
+
+def _file_gather(records: np.ndarray, g: Group, poll_s: float = 0.02, timeout_s: float = 600.0) -> np.ndarray:
+    """SURVEY 8(e) last row: every rank drops its block into a shared directory (atomic rename), then reads all of them."""
+    import time
+    g._file_round += 1
+    tag = f"round{g._file_round:06d}"
+    os.makedirs(g.gather_dir, exist_ok=True)
+    tmp = os.path.join(g.gather_dir, f".{tag}_rank{g.rank}.tmp.npy")
+    np.save(tmp, np.ascontiguousarray(records, np.float32))
+    os.replace(tmp, os.path.join(g.gather_dir, f"{tag}_rank{g.rank}.npy"))
+    out, t0 = [], time.time()
+    for r in range(g.world):
+        path = os.path.join(g.gather_dir, f"{tag}_rank{r}.npy")
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"file gather: rank {r} never wrote {path}")
+            time.sleep(poll_s)
+        out.append(np.load(path).reshape(-1, RECORD_WIDTH))
+    return np.concatenate(out, 0)
 
 
 def shard_range(total: int, world: int, rank: int):
@@ -59,22 +170,92 @@ def make_records(complex_id: int, traj_ids, result) -> np.ndarray:
 
 def gather_records(records: np.ndarray, device=None) -> np.ndarray:
     """all_gather variable-length record blocks from every rank; returns the concatenation (rank order)."""
+    g = _group
+    if g.backend == "file":
+        return _file_gather(records, g)
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return records
     world = dist.get_world_size()
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    grp = g.data_group if g.backend == "nccl" else None          # None = the default group (gloo when init() made it)
+    backend = dist.get_backend(grp) if grp is not None else dist.get_backend()
+    dev = device if device is not None else ("cuda" if backend == "nccl" else "cpu")
     n = torch.tensor([records.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
+    dist.all_gather(counts, n, group=grp)
     nmax = int(max(c.item() for c in counts))
     pad = torch.zeros((nmax, RECORD_WIDTH), dtype=torch.float32, device=dev)
     if records.shape[0]:
         pad[: records.shape[0]] = torch.from_numpy(records).to(dev)
     bufs = [torch.zeros_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)
+    dist.all_gather(bufs, pad, group=grp)
     return np.concatenate([b[: int(c.item())].cpu().numpy() for b, c in zip(bufs, counts)], 0)
+
+
+def allgather_scalars(values) -> np.ndarray:
+    """[world, len(values)] float64 table of a few host scalars per rank (timings, device ids), on the control plane."""
+    v = np.atleast_1d(np.asarray(values, np.float64))
+    g = _group
+    if g.backend == "single":
+        return v[None]
+    if g.backend == "file":
+        assert v.size <= RECORD_WIDTH // 2
+        rec = np.zeros((1, RECORD_WIDTH), np.float32)
+        rec[0, : 2 * v.size] = v.astype(np.float64).view(np.float32)      # bit-exact float64 through the float32 records
+        out = _file_gather(rec, g)
+        return np.ascontiguousarray(out[:, : 2 * v.size]).view(np.float64)
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(v.copy())
+    bufs = [torch.zeros_like(t) for _ in range(g.world)]
+    dist.all_gather(bufs, t)
+    return np.stack([b.numpy() for b in bufs])
+
+
+def allreduce_max(value: float) -> float:
+    """max over ranks of a host scalar (the bench's max-over-ranks time), on the control plane."""
+    return float(allgather_scalars([value])[:, 0].max())
+
+
+def gather_objects(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (small host objects: the CSV rows of driver.run_set)."""
+    g = _group
+    if g.backend == "file":
+        import json
+        import time
+        g._file_round += 1
+        tag = f"obj{g._file_round:06d}"
+        os.makedirs(g.gather_dir, exist_ok=True)
+        tmp = os.path.join(g.gather_dir, f".{tag}_rank{g.rank}.tmp")
+        json.dump(obj, open(tmp, "w"), default=float)
+        os.replace(tmp, os.path.join(g.gather_dir, f"{tag}_rank{g.rank}.json"))
+        out, t0 = [], time.time()
+        for r in range(g.world):
+            path = os.path.join(g.gather_dir, f"{tag}_rank{r}.json")
+            while not os.path.exists(path):
+                if time.time() - t0 > 600.0:
+                    raise TimeoutError(f"file gather: rank {r} never wrote {path}")
+                time.sleep(0.02)
+            out.append(json.load(open(path)))
+        return out
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def barrier():
+    g = _group
+    if g.backend == "single":
+        return
+    if g.backend == "file":
+        _file_gather(np.zeros((0, RECORD_WIDTH), np.float32), g)
+        return
+    import torch.distributed as dist
+    dist.barrier()
 
 
 def rank_by_energy(records: np.ndarray):

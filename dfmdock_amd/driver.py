@@ -8,8 +8,11 @@
   dock_pair    <- inference() (src/inference_base.py:601-670): num_samples trajectories, keep the minimum energy,
                   apply its (rot, tr) to the all-atom ligand, write output.pdb
 
-Work is sharded over ranks by complexes (longest first, distributed.assign_work); the energy-ranked records are
-gathered with the single collective of distributed.gather_records.
+Work is sharded over ranks by complexes (longest first, distributed.assign_work) - or, with fewer than two complexes per
+rank, by TRAJECTORIES: every rank then samples its block of each complex's trajectories (all ranks hold all complexes: weights
+7 MB + <= 3.6 MB of features per complex), so that a short list of complexes still fills every GPU with one large batch
+instead of leaving ranks idle.  The energy-ranked records are gathered with the single collective of
+distributed.gather_records.
 """
 from __future__ import annotations
 
@@ -51,20 +54,28 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
     returns the metric rows of this rank's share; rank 0 writes the gathered CSV when `out_csv` is given."""
     rank, _, world = D.dist_env()
     complexes = list(complexes)
-    share = D.assign_work([c["rec_x"].shape[0] + c["lig_x"].shape[0] for c in complexes], world)[rank]
+    split_trajectories = world > 1 and len(complexes) < 2 * world
+    if split_trajectories:      # (complex, trajectory block) work items: rank r takes block r of every complex
+        share = list(range(len(complexes)))
+        t_lo, t_hi = D.shard_range(num_samples, world, rank)
+    else:
+        share = D.assign_work([c["rec_x"].shape[0] + c["lig_x"].shape[0] for c in complexes], world)[rank]
+        t_lo, t_hi = 0, num_samples
     rng = np.random.default_rng(seed)
     rots = [rng.integers(0, 2 ** 31) for _ in complexes]      # per-complex streams, identical on every rank
     rows, records = [], []
     for ci in share:
+        if t_hi <= t_lo:
+            break
         c = complexes[ci]
         rec_pos, lig_pos = np.asarray(c["rec_pos"], np.float32), np.asarray(c["lig_pos"], np.float32)
         if global_rotation:
             rec_pos, lig_pos = random_rotation(rec_pos, lig_pos, np.random.default_rng(rots[ci]))
         gx = engine.Complex(model, c["rec_x"], c["lig_x"], rec_pos, lig_pos)
         native = NativeContext((rec_pos, lig_pos))
-        done = 0
-        while done < num_samples:
-            b = min(max_batch, num_samples - done)
+        done = t_lo
+        while done < t_hi:
+            b = min(max_batch, t_hi - done)
             r = gx.sample(B=b, num_steps=num_steps, seed=seed * 100003 + ci * 1009 + done, bf16=precision == "bf16",
                           f16=precision == "f16", trace=traj_dir is not None, **sampler_kw)
             for k in range(b):
@@ -96,10 +107,7 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
 def _gather_rows(rows, world):
     if world == 1:
         return rows
-    import torch.distributed as dist
-    out = [None] * world
-    dist.all_gather_object(out, rows)
-    return [r for part in out for r in part]
+    return [r for part in D.gather_objects(rows) for r in part]
 
 
 def dock_pair(model: engine.Model, rec, lig, rec_x, lig_x, num_samples=120, num_steps=40, seed=0, precision="bf16",

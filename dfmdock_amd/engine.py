@@ -26,6 +26,11 @@ def set_device(index: int = 0):
     L.check(L.lib().dfm_set_device(int(index)), "dfm_set_device")
 
 
+def config_string() -> str:
+    """The precision plan and every diagnostic switch in force in this process (dfm_config_string)."""
+    return L.lib().dfm_config_string().decode()
+
+
 def device_count() -> int:
     n = C.c_int(0)
     rc = L.lib().dfm_device_count(C.byref(n))
@@ -110,7 +115,7 @@ class Complex:
         L.check(L.lib().dfm_complex_set_homomer(self._h, int(bool(flag))), "dfm_complex_set_homomer")
 
     def score(self, lig_pos, t, edges=None, seed=0, bf16=False, energy=True, debug=False, profile=False, f16=False,
-              ires=False, return_edges=False):
+              ires=False, return_edges=False, bf16_ops=False):
         """B score evaluations.  lig_pos [B,L,3,3] (or [L,3,3]), t [B] (or scalar)."""
         lig_pos = _f32(lig_pos)
         if lig_pos.ndim == 3:
@@ -144,7 +149,7 @@ class Complex:
             if e.shape != (B, N, K):
                 raise ValueError(f"edges must be [B,N,K] = {(B, N, K)}, got {e.shape}")
         flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_ENERGY if energy else 0) | (L.DFM_F_PROFILE if profile else 0) | \
-                (L.DFM_F_F16 if f16 else 0) | (L.DFM_F_IRES if ires else 0)
+                (L.DFM_F_F16 if f16 else 0) | (L.DFM_F_IRES if ires else 0) | (L.DFM_F_BF16_OPS if bf16_ops else 0)
         rc = L.lib().dfm_score(self._h, B, _p(lig_pos), _p(t), _p(e, L.I32P), int(seed), flags, C.byref(out))
         L.check(rc, "dfm_score")
         if debug:
@@ -154,7 +159,7 @@ class Complex:
         return o
 
     def sample(self, B=1, num_steps=40, eps=1e-3, tr_noise_scale=0.5, rot_noise_scale=0.5, noise_annealing=False,
-               use_clash_force=False, ode=False, seed=0, bf16=False, inject=None, trace=False, profile=False, f16=False):
+               use_clash_force=False, ode=False, seed=0, bf16=False, inject=None, trace=False, profile=False, f16=False, bf16_ops=False):
         """B independent Euler-Maruyama trajectories (inference_base.py:390-468 batched)."""
         Lg, N, K, S = self.L, self.N, self.K, int(num_steps)
         o = dict(lig_pos=np.zeros((B, Lg, 3, 3), np.float32), rot_update=np.zeros((B, 3), np.float32),
@@ -183,7 +188,8 @@ class Complex:
                 inj.edges = _p(a, L.I32P)
         flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_NOISE_ANNEALING if noise_annealing else 0) | \
                 (L.DFM_F_CLASH_FORCE if use_clash_force else 0) | (L.DFM_F_ODE if ode else 0) | \
-                (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if trace else 0) | (L.DFM_F_F16 if f16 else 0)
+                (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if trace else 0) | (L.DFM_F_F16 if f16 else 0) | \
+                (L.DFM_F_BF16_OPS if bf16_ops else 0)
         rc = L.lib().dfm_sample(self._h, int(B), S, float(eps), float(tr_noise_scale), float(rot_noise_scale), flags,
                                 int(seed), C.byref(inj) if inj is not None else None, C.byref(out))
         L.check(rc, "dfm_sample")

@@ -93,11 +93,14 @@ class Score_Model:
     batch: {rec_x [R,1301], lig_x [L,1301], rec_pos [R,3,3], lig_pos [L,3,3], t [1]} (position_matrix is
     accepted and ignored: relpos is derived from (R, L) on the GPU).  Output keys / shapes follow
     score_net_mlsb.py:413-425: tr_score [1,3], rot_score [1,3], energy [], f [L,3], num_clashes [] (int64),
-    ires [N,1].
+    ires [N,1].  `with_ires=False` skips the interface-residue head (three fp32 GEMMs on [N,512] per call that no sampler
+    reads) and leaves the key out.
     """
 
-    def __init__(self, weights, hp: HParams | None = None, precision: str = "bf16", device_index: int = 0, seed: int = 0):
+    def __init__(self, weights, hp: HParams | None = None, precision: str = "bf16", device_index: int = 0, seed: int = 0,
+                 with_ires: bool = True):
         self.hp = hp or HParams()
+        self.with_ires = bool(with_ires)
         blob = weights if isinstance(weights, np.ndarray) and weights.ndim == 1 else pack_blob(weights, self.hp)
         engine.set_device(device_index)
         self.model = engine.Model(blob, self.hp)
@@ -169,11 +172,12 @@ class Score_Model:
             raise ValueError("batch['t'] must hold one time value (the reference runs batch_size=1)")
         self._calls += 1
         r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, bf16=self.precision == "bf16",
-                     f16=self.precision == "f16", energy=True, ires=True)
+                     f16=self.precision == "f16", energy=True, ires=self.with_ires)
         out = {"tr_score": torch.from_numpy(r["tr_score"]), "rot_score": torch.from_numpy(r["rot_score"]),
                "energy": torch.tensor(float(r["energy"][0]), dtype=torch.float32), "f": torch.from_numpy(r["f"][0]),
-               "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64),
-               self._ires_key: torch.from_numpy(r["ires"][0].reshape(-1, 1).copy())}
+               "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64)}
+        if self.with_ires:
+            out[self._ires_key] = torch.from_numpy(r["ires"][0].reshape(-1, 1).copy())
         return out, r
 
     def forward(self, batch):
@@ -194,11 +198,12 @@ class DFMDock(Score_Model):
     Score_Model, so ``Euler_Maruyama_sampler(model, batch)`` / ``sample_trajectories`` accept this class too.
     """
 
-    def __init__(self, weights, hp: HParams | None = None, precision: str = "bf16", device_index: int = 0, seed: int = 0):
+    def __init__(self, weights, hp: HParams | None = None, precision: str = "bf16", device_index: int = 0, seed: int = 0,
+                 with_ires: bool = True):
         hp = hp or HParams(family=1, mask_dist=20.0)
         if hp.family != 1:
             raise ValueError("DFMDock needs HParams(family=1)")
-        super().__init__(weights, hp=hp, precision=precision, device_index=device_index, seed=seed)
+        super().__init__(weights, hp=hp, precision=precision, device_index=device_index, seed=seed, with_ires=with_ires)
 
     _ires_key = "ires_logits"       # egnn_net.py:486-495
 

@@ -76,15 +76,24 @@ typedef struct {
 
 /* flags for dfm_score / dfm_sample */
 enum {
-    DFM_F_BF16 = 1u << 0,            /* per-edge contractions on bf16 MFMA (default without flag: exact fp32) */
+    DFM_F_MFMA16 = 1u << 0,          /* the 16-bit MFMA engine (default without flag: exact fp32): per-edge 256 x 256
+                                        contractions on v_mfma_f32_32x32x16 with fp16 operands and fp32 accumulation in every
+                                        layer, gathered operands (Wb h_j, lookup tables, A_i) stored as fp16, node-level GEMMs
+                                        as three split-bf16 terms (~1e-5), geometry / GraphNorm statistics / heads / SDE step
+                                        fp32.  dfm_config_string() describes the plan in force.                         */
+    DFM_F_BF16 = DFM_F_MFMA16,       /* name of rounds 1-2 (the engine then took bf16 operands in layers 0..depth-2)    */
     DFM_F_ENERGY = 1u << 1,          /* dfm_score: also evaluate the energy head                 */
     DFM_F_NOISE_ANNEALING = 1u << 2, /* inference_base.py:428-430                                */
     DFM_F_CLASH_FORCE = 1u << 3,     /* inference_base.py:458-461                                */
     DFM_F_ODE = 1u << 4,             /* so3_diffuser.py:367-368                                  */
     DFM_F_PROFILE = 1u << 5,         /* time the dominant kernel with HIP events (dfm_get_profile) */
     DFM_F_STEP_ENERGY = 1u << 6,     /* dfm_sample: evaluate the energy head on every step (traces) */
-    DFM_F_F16 = 1u << 7,             /* like DFM_F_BF16 but with fp16 MFMA operands (11-bit mantissa, same rate) */
-    DFM_F_IRES = 1u << 8             /* dfm_score: also evaluate the interface-residue head (score_net_mlsb.py:383) */
+    DFM_F_F16 = 1u << 7,             /* like DFM_F_MFMA16 but A_i = Wa h_i + b1 stays fp32 (one more load per chunk)     */
+    DFM_F_IRES = 1u << 8,            /* dfm_score: also evaluate the interface-residue head (score_net_mlsb.py:383) */
+    DFM_F_BF16_OPS = 1u << 9         /* with DFM_F_MFMA16: bf16 instead of fp16 MFMA operands in layers 0..depth-2 (the r02
+                                        plan; ~3 % faster).  OUTSIDE SURVEY 8(d)'s 1e-2 gate: measured up to 1.5e-2 on f /
+                                        tr_score / rot_score over four weight draws (profiles/r03_tol_report.txt) - an opt-in
+                                        for callers who accept that; tested at 2e-2                                      */
 };
 
 /* Output of dfm_score.  Required: tr_score, rot_score.  Any other pointer may be NULL. */
@@ -138,6 +147,10 @@ typedef struct {
 } dfm_profile;
 
 const char *dfm_last_error(void);
+/* One line describing the precision plan and every diagnostic environment switch / build knob in force in this process
+ * (DFM_GEMM_TERMS, DFM_GEMM_MT, DFM_EDGE_SPLIT, DFM_LIB is the loader's): benches and tests print it, so that a run under
+ * a stray variable cannot pass for the shipped engine.  The pointer stays valid for the life of the process. */
+const char *dfm_config_string(void);
 int dfm_device_count(int *count);
 int dfm_set_device(int device);
 /* fills hp with the reference configuration */
@@ -154,11 +167,15 @@ void dfm_complex_destroy(dfm_complex *cx);
 /* Replace the poses stored by dfm_complex_create (either pointer may be NULL = keep): rec_pos [R,9] is what every later
  * dfm_score / dfm_sample call sees as the receptor, lig_pos [L,9] is the start pose of dfm_sample.  The node features and
  * everything derived from them stay resident - a caller that re-centres the complex every step (DFMDock.move_to_lig_center,
- * src/models/DFMDock.py:254-257) or docks several ligand conformations does not pay the feature upload again. */
+ * src/models/DFMDock.py:254-257) or docks several ligand conformations does not pay the feature upload again.  On an error
+ * return the stored poses are unspecified (one of the two may have been replaced): call again. */
 int dfm_complex_set_pose(dfm_complex *cx, const float *rec_pos_or_null, const float *lig_pos_or_null);
 /* positional_embed_dim = 67 only: value of the 67th ("sym") position channel for this complex - 1 when receptor and ligand
  * have the same sequence (is_homomer, src/datasets/docking_dataset.py:129), 0 otherwise (the default).  DFM_E_INVALID for a
- * 66-channel model and flag != 0. */
+ * 66-channel model and flag != 0.  ASSUMPTION: the reference tree has no producer of a 67-channel position matrix
+ * (utils/crop.get_position_matrix returns 66 channels and nothing concatenates is_homomer); the layout taken here is
+ * [relpos one-hot 66 | flag], the same constant on every residue pair.  A checkpoint trained with another layout of that
+ * channel needs this entry point revisited. */
 int dfm_complex_set_homomer(dfm_complex *cx, int flag);
 /* edges per node for this complex: min(N,20) + min(40, N-20) */
 int dfm_complex_degree(const dfm_complex *cx);

@@ -554,9 +554,9 @@ void ora_knn_sample(const ora_hparams *hp, const float *ca, int N, uint64_t seed
 /* ------------------------------------------------------------------------- */
 /* a-5: Score_Net.forward(predict=True) (score_net_mlsb.py:343-425) */
 /* positional_embed_dim = 67 (configs/model/DFMDock.yaml:5): the 67th position channel is the homomer flag of the complex
- * (`is_homomer`, datasets/docking_dataset.py:129), the same value on every residue pair */
-static int g_homomer = 0;
-void ora_set_homomer(int flag) { g_homomer = flag ? 1 : 0; }
+ * (`is_homomer`, datasets/docking_dataset.py:129), the same value on every residue pair: ora_hparams.homomer.  The reference
+ * tree has NO producer that appends this channel (utils/crop.get_position_matrix returns 66): the layout [relpos66 | flag] is this
+ * build's assumption, shared by the engine and the fwd2_sym goldens */
 
 int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const float *rec_x, const float *lig_x,
               const float *rec_pos, const float *lig_pos, float t, const int32_t *edges_in, uint64_t seed,
@@ -632,7 +632,7 @@ int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const floa
                 const float *ws = w.spatial_embed + (int64_t)c * Sd;
                 float sp = ((ws[b[0]] + ws[40 + b[1]]) + ws[64 + b[2]]) + ws[88 + b[3]];
                 float pe = w.positional_embed[(int64_t)c * Pd + rp];
-                if (Pd == 67 && g_homomer) pe += w.positional_embed[(int64_t)c * Pd + 66];
+                if (Pd == 67 && hp->homomer) pe += w.positional_embed[(int64_t)c * Pd + 66];
                 eattr[e * He + c] = sp + pe;
             }
             /* egnn.py:139-148 coord2radial, normalize=True */

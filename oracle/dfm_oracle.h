@@ -27,6 +27,7 @@ typedef struct {
     double r3_min_sigma, r3_max_sigma, so3_min_sigma, so3_max_sigma;   /* Python floats in the reference */
     int family;    /* 0: Score_Net (score_net_mlsb.py); 1: EGNN_Net behind DFMDock.forward (egnn_net.py, DFMDock.py:68-75) */
     int agg_mean;  /* family 1: `agg` == 'mean' (1) or 'sum' (0) */
+    int homomer;   /* positional_embed_dim = 67: value of the 67th ("sym") position channel of this complex (default 0) */
 } ora_hparams;
 
 typedef struct {
@@ -89,7 +90,6 @@ void ora_matrix_to_axis_angle(const float R[9], float aa[3]);
 void ora_rot_compose(const float r1[3], const float r2[3], float out[3]);
 void ora_modify_coords(float *x /*[n,9] in/out*/, int n, const float rot[3], const float tr[3]);
 void ora_modify_coords_all_atom(float *x /*[n,9] in/out*/, int n, const float rot[3], const float tr[3]);  /* inference.py:244-254 */
-void ora_set_homomer(int flag);   /* 67th position channel (configs/model/DFMDock.yaml:5); test-time global, default 0 */
 /* a-17: inference_base.py:366-384 (closed-form gradient of the reference's autograd) */
 void ora_clash_force(const float *rec /*[R,9]*/, int R, const float *lig /*[L,9]*/, int L, float out[3]);
 

@@ -25,7 +25,7 @@ class OraHParams(C.Structure):
                                        "node_dim", "edge_dim", "inner_dim", "depth", "knn", "n_sample")] + \
                [(n, C.c_float) for n in ("cut_off", "mask_dist")] + \
                [(n, C.c_double) for n in ("r3_min_sigma", "r3_max_sigma", "so3_min_sigma", "so3_max_sigma")] + \
-               [("family", C.c_int), ("agg_mean", C.c_int)]
+               [("family", C.c_int), ("agg_mean", C.c_int), ("homomer", C.c_int)]
 
 
 class OraScoreOut(C.Structure):
@@ -82,8 +82,6 @@ def lib():
         L.ora_modify_coords_all_atom.restype = None
         L.ora_set_num_threads.argtypes = [C.c_int]
         L.ora_set_num_threads.restype = None
-        L.ora_set_homomer.argtypes = [C.c_int]
-        L.ora_set_homomer.restype = None
         _lib = L
     return _lib
 
@@ -99,14 +97,15 @@ def _p(a, t=F32P):
 def hparams(hp=None) -> OraHParams:
     from dfmdock_amd.weights import HParams
     hp = hp or HParams()
-    return OraHParams(**hp.as_dict())
+    return OraHParams(homomer=0, **hp.as_dict())
 
 
 class Oracle:
     """Convenience wrapper: one model (blob) + one complex."""
 
-    def __init__(self, blob, cx, hp=None):
+    def __init__(self, blob, cx, hp=None, homomer=False):
         self.hp = hparams(hp)
+        self.hp.homomer = int(bool(homomer))      # 67-channel position matrix only: the complex's "sym" flag
         self.blob = _f32(blob)
         assert lib().ora_param_count(C.byref(self.hp)) == self.blob.size
         self.rec_x, self.lig_x = _f32(cx["rec_x"]), _f32(cx["lig_x"])

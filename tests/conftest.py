@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """The engine's precision plan and any diagnostic switch in force (dfm_config_string): printed on top of every run."""
+    try:
+        from dfmdock_amd import engine
+        return "dfmdock_amd engine: " + engine.config_string()
+    except Exception as e:      # library not built: the ABI tests say so
+        return f"dfmdock_amd engine: unavailable ({e})"
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 

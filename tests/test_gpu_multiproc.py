@@ -3,8 +3,13 @@ rendezvous over gloo (the 8-GPU node runs the same code over RCCL: backend "nccl
 
   * bench.py --gpus 2 under torch.distributed.run: the weak-scaling step (per-rank dfm_sample + one record all_gather +
     max-over-ranks timing) end to end;
-  * driver.run_set over 3 complexes on 2 ranks: complexes sharded longest-first, disjoint (complex, trajectory) ids, every rank
-    ends with the identical energy-ranked table, rank 0 writes the complete CSV.
+  * plain `python bench.py --gpus 2`: no launcher, bench.py starts its two ranks itself; RCCL cannot serve two ranks on ONE GPU,
+    so the probe fails and the gather falls back to gloo - the JSON line says so;
+  * driver.run_set over 4 complexes on 2 ranks: complexes sharded longest-first, disjoint (complex, trajectory) ids, every rank
+    ends with the identical energy-ranked table, rank 0 writes the complete CSV; over 1 complex on 2 ranks: its trajectories
+    are split between the ranks instead.
+
+RCCL itself is not executed by any test here (one GPU); the 8-GPU node is the driver's.
 """
 import csv
 import json
@@ -41,6 +46,27 @@ def test_bench_two_ranks_one_gpu():
     assert abs(out["value"] - 2 * 8 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-6 * out["value"]   # whole-job aggregate over both ranks
 
 
+def test_bench_self_spawns_its_ranks_and_survives_a_broken_rccl():
+    """`python bench.py --gpus 2 --batch 8`: the driver's command shape with no torchrun around it.  Both ranks land on the one
+    GPU of the test box, where RCCL refuses to build a communicator: the line must still come out, with n_gpus = 2, the backend
+    that carried the gather and the reason RCCL was dropped."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "DFM_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--num-steps", "6", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_in_gather"] == 2 and out["config"]["trajectories_per_gpu"] == 8
+    assert out["backend"] in ("nccl", "gloo", "file")
+    if out["distinct_devices"] == 1:      # two ranks on one GPU: RCCL cannot have worked
+        assert out["backend"] != "nccl" and out["backend_fallback"] and "nccl" in out["backend_fallback"].lower()
+    assert abs(out["value"] - 2 * 8 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-6 * out["value"]
+
+
 RUN_SET_WORKER = textwrap.dedent("""
     import json, os, sys
     import numpy as np
@@ -54,7 +80,7 @@ RUN_SET_WORKER = textwrap.dedent("""
     engine.set_device(0)                      # both ranks share the one GPU of the test box
     model = engine.Model(pack_blob(make_random_weights(0)))
     cxs = []
-    for k, (R, L) in enumerate([(30, 22), (70, 41), (41, 17)]):
+    for k, (R, L) in enumerate({shapes!r}):
         c = make_complex(R, L, seed=20 + k)
         c.update(id=f"SYN{{k}}", rec_seq="A" * R, lig_seq="G" * L)
         cxs.append(c)
@@ -66,27 +92,42 @@ RUN_SET_WORKER = textwrap.dedent("""
 """)
 
 
-def test_run_set_two_ranks_one_gpu(tmp_path):
+def _run_set_two_ranks(tmp_path, shapes, port):
     script = tmp_path / "worker.py"
-    script.write_text(RUN_SET_WORKER.format(root=ROOT, out=str(tmp_path)))
-    port = _port() + 1
+    script.write_text(RUN_SET_WORKER.format(root=ROOT, out=str(tmp_path), shapes=shapes))
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
-    a, b = json.load(open(tmp_path / "rank0.json")), json.load(open(tmp_path / "rank1.json"))
+    return json.load(open(tmp_path / "rank0.json")), json.load(open(tmp_path / "rank1.json"))
+
+
+def test_run_set_two_ranks_one_gpu(tmp_path):
+    a, b = _run_set_two_ranks(tmp_path, [(30, 22), (70, 41), (41, 17), (25, 25)], _port() + 1)
     ids_a, ids_b = {(r[0], r[1]) for r in a["rows"]}, {(r[0], r[1]) for r in b["rows"]}
     assert ids_a and ids_b and not (ids_a & ids_b)                                  # every rank sampled something, nothing twice
-    assert ids_a | ids_b == {(f"SYN{k}", str(i)) for k in range(3) for i in range(5)}
+    assert ids_a | ids_b == {(f"SYN{k}", str(i)) for k in range(4) for i in range(5)}
     assert {r[0] for r in a["rows"]}.isdisjoint({r[0] for r in b["rows"]})            # sharded by complex
-    assert a["ranked"] == b["ranked"] and sorted(a["ranked"]) == ["0", "1", "2"]    # identical ranked table everywhere
+    assert a["ranked"] == b["ranked"] and sorted(a["ranked"]) == ["0", "1", "2", "3"]    # identical ranked table everywhere
     for k, tab in a["ranked"].items():
         e = np.array(tab)[:, 2]
         assert len(e) == 5 and (np.diff(e) >= 0).all()
     got = list(csv.DictReader(open(tmp_path / "set.csv")))
-    assert len(got) == 15 and {(r["id"], r["index"]) for r in got} == ids_a | ids_b
+    assert len(got) == 20 and {(r["id"], r["index"]) for r in got} == ids_a | ids_b
     by_key = {(r[0], r[1]): r[2] for r in a["rows"] + b["rows"]}
     for r in got:
         assert abs(float(r["energy"]) - by_key[(r["id"], r["index"])]) < 1e-6
+
+
+def test_run_set_splits_trajectories_when_complexes_are_few(tmp_path):
+    """One complex on two ranks: fewer than two complexes per rank, so each rank samples its block of the complex's trajectories
+    (3 + 2 of 5) and the gathered table holds all five exactly once."""
+    a, b = _run_set_two_ranks(tmp_path, [(70, 41)], _port() + 2)
+    ids_a, ids_b = {(r[0], r[1]) for r in a["rows"]}, {(r[0], r[1]) for r in b["rows"]}
+    assert ids_a == {("SYN0", str(i)) for i in range(3)} and ids_b == {("SYN0", str(i)) for i in (3, 4)}
+    assert a["ranked"] == b["ranked"] and list(a["ranked"]) == ["0"] and len(a["ranked"]["0"]) == 5
+    assert sorted(int(r[1]) for r in a["ranked"]["0"]) == [0, 1, 2, 3, 4]
+    got = list(csv.DictReader(open(tmp_path / "set.csv")))
+    assert [(r["id"], r["index"]) for r in got] == [("SYN0", str(i)) for i in range(5)]

@@ -129,11 +129,11 @@ def test_sym_channel_vs_reference(flag):
     cx = complex_for("syn_24_16")
     gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
     gx.set_homomer(bool(flag))
-    for prec, tol in (("fp32", 1e-4), ("bf16", 1e-2), ("f16", 3e-3)):
+    for prec, tol in (("fp32", 1e-4), ("bf16", 1e-2), ("f16", 1e-2)):
         r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, bf16=prec == "bf16", f16=prec == "f16")
         assert rel_inf(r["f"][0], g["f"]) < tol and rel_inf(r["tr_score"][0], g["tr_score"].reshape(3)) < tol, prec
-        assert abs(float(r["energy"][0]) - float(g["energy"])) < max(tol, 3e-2 if prec == "bf16" else tol) * max(1.0, abs(float(g["energy"])))
-        assert abs(float(r["confidence"][0]) - float(g["confidence_logits"])) < max(tol, 3e-2 if prec == "bf16" else tol)
+        assert abs(float(r["energy"][0]) - float(g["energy"])) < max(tol, 3e-2 if prec != "fp32" else tol) * max(1.0, abs(float(g["energy"])))
+        assert abs(float(r["confidence"][0]) - float(g["confidence_logits"])) < max(tol, 3e-2 if prec != "fp32" else tol)
     if flag:     # switching the flag back reproduces the 66-channel behaviour exactly
         g0 = load_golden("fwd2_sym0_syn_24_16.npz")
         gx.set_homomer(False)
@@ -194,7 +194,7 @@ def test_graphnorm_large_mean_channels(blob):
     o = ora.Oracle(blob2, cx).score(g["lig_pos"], float(g["t"]), edges=g["edges"])
     r32 = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, debug=True)
     assert rel_inf(r32["h_last"][0], o["h_layers"][-1]) < 1e-4 and rel_inf(r32["f"][0], o["f"]) < 1e-4
-    for prec, th, tf in (("f16", 3e-3, 3e-3), ("bf16", 3e-2, 1e-2)):
+    for prec, th, tf in (("f16", 3e-2, 1e-2), ("bf16", 3e-2, 1e-2)):
         r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, debug=True, bf16=prec == "bf16", f16=prec == "f16")
         assert rel_inf(r["h_last"][0], o["h_layers"][-1]) < th, prec
         assert rel_inf(r["f"][0], o["f"]) < tf and rel_inf(r["tr_score"][0], o["tr_score"].reshape(3)) < tf, prec
@@ -280,9 +280,10 @@ def test_tile_tasks_equal_node_tasks_bitwise(tmp_path):
             assert (outs[tag][k] == outs["node1"][k]).all(), (tag, k)
 
 
-def test_engine_switches_stay_within_the_bf16_gate(tmp_path):
-    """The bf16 engine's default forms (two-term fp16 node GEMMs, fp16 A_i) against their conservative forms
-    (DFM_GEMM_TERMS=3, DFM_EDGE_AW16=0): same graph, both within the SURVEY bf16 gate of the fp32 engine and close to each other."""
+def test_engine_variants_stay_within_the_16bit_gate(tmp_path):
+    """The 16-bit engine's plan against its variants - fp32 A_i (DFM_F_F16), bf16 operands in layers 0..4 (DFM_F_BF16_OPS), the
+    two-term node GEMMs behind the one remaining diagnostic switch (DFM_GEMM_TERMS=2, its own process: switches are read once):
+    same graph, all within SURVEY's 16-bit gate of the fp32 engine, and the config string names the switch."""
     import subprocess, sys, textwrap
     script = tmp_path / "w.py"
     script.write_text(textwrap.dedent(f"""
@@ -297,21 +298,26 @@ def test_engine_switches_stay_within_the_bf16_gate(tmp_path):
         gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
         poses = np.repeat(cx["lig_pos"][None], 3, 0)
         r = gx.score(poses, 0.4, seed=7, bf16=True, energy=True, return_edges=True)
-        r32 = gx.score(poses, 0.4, edges=r["edges"], energy=True)
-        np.savez(sys.argv[1], **{{k: r[k] for k in ("f", "tr_score", "rot_score", "energy")}}, **{{k + "32": r32[k] for k in ("f", "tr_score", "rot_score", "energy")}})
+        out = {{"cfg": np.array(engine.config_string())}}
+        for tag, kw in (("", dict(bf16=True)), ("32", {{}}), ("_a32", dict(f16=True)), ("_bf", dict(bf16=True, bf16_ops=True))):
+            x = gx.score(poses, 0.4, edges=r["edges"], energy=True, **kw)
+            out.update({{k + tag: x[k] for k in ("f", "tr_score", "rot_score", "energy")}})
+        np.savez(sys.argv[1], **out)
     """))
     outs = {}
-    for tag, env in (("default", {}), ("terms3", {"DFM_GEMM_TERMS": "3"}), ("a32", {"DFM_EDGE_AW16": "0"})):
+    for tag, env in (("default", {}), ("terms2", {"DFM_GEMM_TERMS": "2"})):
         p = subprocess.run([sys.executable, str(script), str(tmp_path / f"{tag}.npz")], env=dict(os.environ, **env),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         assert p.returncode == 0, p.stdout.decode()[-2000:]
         outs[tag] = np.load(tmp_path / f"{tag}.npz")
     ref = outs["default"]
-    for tag, o in outs.items():
-        assert (o["f32"] == ref["f32"]).all()                        # the fp32 engine does not see the switches
-        for k, tol in (("f", 1e-2), ("tr_score", 1e-2), ("rot_score", 1e-2), ("energy", 3e-2)):
-            scale = np.abs(o[k + "32"]).max() + 1e-12
-            if k == "energy": scale = max(scale, 0.1)              # the energy gate's convention (test_gpu_configs.check_vs)
-            assert np.abs(o[k] - o[k + "32"]).max() / scale < tol, (tag, k)
-            assert np.abs(o[k] - ref[k]).max() / scale < 5e-3, (tag, k)
-    assert (outs["terms3"]["f"] != ref["f"]).any() and (outs["a32"]["f"] != ref["f"]).any()     # the switches do switch something
+    assert "DFM_GEMM_TERMS=2" in str(outs["terms2"]["cfg"]) and "env: none" in str(ref["cfg"])
+    assert (outs["terms2"]["f32"] == ref["f32"]).all()                   # the fp32 engine does not see the switch
+    for tag, o, suffixes in (("default", ref, ("", "_a32", "_bf")), ("terms2", outs["terms2"], ("",))):
+        for sfx in suffixes:
+            for k, tol in (("f", 1e-2), ("tr_score", 1e-2), ("rot_score", 1e-2), ("energy", 3e-2)):
+                scale = np.abs(o[k + "32"]).max() + 1e-12
+                if k == "energy": scale = max(scale, 0.1)              # the energy gate's convention (test_gpu_configs.check_vs)
+                assert np.abs(o[k + sfx] - o[k + "32"]).max() / scale < tol, (tag, sfx, k)
+    for other in (ref["f_a32"], ref["f_bf"], outs["terms2"]["f"]):       # the flags / the switch do select something else
+        assert (other != ref["f"]).any()

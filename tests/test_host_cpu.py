@@ -198,6 +198,57 @@ def test_record_gather_world2_gloo(tmp_path):
     np.testing.assert_array_equal(a, b)         # every rank ends with the same energy-ranked table
 
 
+INIT_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    from dfmdock_amd import distributed as D
+    rank, _, world = D.dist_env()
+    g = D.init()                                  # prefers nccl; this box has no GPU -> must settle on gloo (or files) and say why
+    lo, hi = D.shard_range(9, world, rank)
+    n = hi - lo
+    res = dict(energy=np.arange(lo, hi, dtype=np.float32)[::-1].copy(), num_clashes=np.zeros(n, np.int32),
+               rot_update=np.zeros((n, 3), np.float32), tr_update=np.full((n, 3), rank, np.float32))
+    allrec = D.gather_records(D.make_records(rank, np.arange(lo, hi), res))
+    again = D.gather_records(D.make_records(rank, np.arange(lo, hi), res))      # a second round on the same group / directory
+    tmax = D.allreduce_max(1.5 + rank)
+    tab = D.allgather_scalars([0.1 * (rank + 1), 7.0 + rank])
+    D.barrier()
+    json.dump(dict(backend=g.backend, reason=g.fallback_reason, n=int(allrec.shape[0]), ids=allrec[:, 1].tolist(),
+                   ranks=sorted(set(allrec[:, 0].astype(int).tolist())), same=bool((allrec == again).all()), tmax=tmax,
+                   tab=tab.tolist()), open(os.path.join({out!r}, f"init_{{rank}}.json"), "w"))
+    D.shutdown()
+""")
+
+
+@pytest.mark.parametrize("mode", ["rendezvous", "replicas"])
+def test_init_falls_back_from_nccl_and_gathers(tmp_path, mode):
+    """distributed.init(): RCCL is probed and, when it does not work on every rank (no GPU here), the record gather runs over
+    gloo - or, with no rendezvous at all (independent replicas: RANK / WORLD_SIZE / DFM_GATHER_DIR only), over files
+    (SURVEY 8(e) last row).  Same records either way, and the group says what it is and why."""
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(INIT_WORKER.format(root=ROOT, out=str(tmp_path)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", DFM_GATHER_DIR=str(tmp_path / "gather"))
+        env.pop("DFM_DIST_BACKEND", None)
+        if mode == "rendezvous":
+            env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29100 + (os.getpid() % 400)))
+        else:
+            env.pop("MASTER_PORT", None)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    a, b = (json.load(open(tmp_path / f"init_{r}.json")) for r in range(2))
+    assert a == b
+    assert a["backend"] == ("gloo" if mode == "rendezvous" else "file") and a["reason"]
+    if mode == "rendezvous":
+        assert "nccl" in a["reason"] or "GPU" in a["reason"]
+    assert a["n"] == 9 and a["ids"] == list(range(9)) and a["ranks"] == [0, 1] and a["same"]
+    assert a["tmax"] == 2.5 and a["tab"] == [[0.1, 7.0], [0.2, 8.0]]
+
+
 def test_dfmdock_wrapper_helpers_match_reference():
     """DFMDock.modify_coords / move_to_lig_center (DFMDock.py:246-257) against values produced by the reference."""
     import numpy as np

@@ -279,12 +279,8 @@ def test_pair_family_sym_channel(flag):
     hp = HParams(family=1, mask_dist=20.0, positional_embed_dim=67)
     blob67 = pack_blob(make_random_weights(0, hp), hp)
     g = load_golden(f"fwd2_sym{flag}_syn_24_16.npz")
-    o = ora.Oracle(blob67, complex_for("syn_24_16"), hp)
-    ora.lib().ora_set_homomer(flag)
-    try:
-        r = o.score(g["lig_pos"], float(g["t"]), edges=g["edges"])
-    finally:
-        ora.lib().ora_set_homomer(0)
+    o = ora.Oracle(blob67, complex_for("syn_24_16"), hp, homomer=bool(flag))
+    r = o.score(g["lig_pos"], float(g["t"]), edges=g["edges"])
     assert rel_inf(r["f"], g["f"]) < 1e-4 and rel_inf(r["tr_score"], g["tr_score"]) < 1e-4
     assert abs(float(r["energy"]) - float(g["energy"])) < 1e-4 * max(1.0, abs(float(g["energy"])))
     assert abs(float(r["confidence"]) - float(g["confidence_logits"])) < 1e-4

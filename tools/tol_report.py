@@ -2,7 +2,7 @@
 fp32 engine vs the oracle on odd sizes.  Prints one line per case; the gates in tests/ are SURVEY 8(d)'s."""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from conftest import complex_for, load_golden, pair_hparams
 from dfmdock_amd import engine
@@ -37,52 +37,8 @@ for fam, bl, hp, cases in ((0, blob, HParams(), ["fwd_syn_9_7", "fwd_syn_24_16",
                   f"  |rot| {np.abs(g['rot_score']).max():.3e} |tr| {np.abs(g['tr_score']).max():.3e}")
         gx.close()
     m.close()
-# further weight draws (two more seeds + one 3x-scaled draw): per-draw worst deviation from the reference's outputs
-from conftest import DRAWS, DRAW_CASES, draw_blob, draw_golden, draw_hparams
-print("\n# per weight draw: worst relative deviation over the draw's forward cases (f / tr_score / rot_score / energy) and the worst")
-print("# ligand CA-RMSD of the 40-step replayed rollout; gates fp32 1e-4, bf16 1e-2 (3e-2 energy), f16 3e-3 (5e-3 energy), 0.5 A")
-print("# yardstick (SURVEY 7): the oracle's own bf16-autocast deviations on 7CEI are 5e-4 (tr) / 3e-3 (rot) / 1e-2 (f) / 1.8e-2 (E)")
-for fam in (0, 1):
-    for draw in ("s0",) + tuple(DRAWS):
-        hp = draw_hparams(fam)
-        m = engine.Model(draw_blob(fam, draw) if draw != "s0" else (blob1 if fam else blob), hp)
-        worst = {p: np.zeros(4) for p in ("fp32", "bf16", "f16")}
-        wcase = {p: [""] * 4 for p in worst}
-        for case in DRAW_CASES[fam]:
-            if draw == "s0":
-                if fam == 1 and case.startswith("fwd_"):
-                    continue
-                g = {k: np.asarray(v) for k, v in load_golden(case + ".npz").items()}
-            else:
-                g = draw_golden(fam, draw, case)
-            cx = complex_for(case)
-            gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-            for prec in worst:
-                r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32), energy=True, bf16=prec == "bf16", f16=prec == "f16")
-                d = [rel(r["f"][0], g["f"]), rel(r["tr_score"][0], np.asarray(g["tr_score"]).reshape(3)),
-                     rel(r["rot_score"][0], np.asarray(g["rot_score"]).reshape(3)),
-                     abs(float(r["energy"][0]) - float(g["energy"])) / max(abs(float(g["energy"])), 0.1)]
-                for i in range(4):
-                    if d[i] > worst[prec][i]:
-                        worst[prec][i], wcase[prec][i] = d[i], case
-            gx.close()
-        roll = {}
-        if draw != "s0":
-            g = draw_golden(fam, draw, "rollout")
-        else:
-            g = load_golden(("rollout2_syn_24_16" if fam else "rollout_syn_24_16") + ".npz")
-        cx = complex_for("syn_24_16")
-        gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-        inj = dict(R0=g["R0"].astype(np.float32), tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"])
-        for prec in worst:
-            r = gx.sample(B=1, num_steps=40, inject=inj, trace=True, bf16=prec == "bf16", f16=prec == "f16")
-            roll[prec] = float(np.sqrt(((r["trace_pose"][0][:, :, 1, :] - g["poses"][:, :, 1, :]) ** 2).sum(-1).mean(-1)).max())
-        gx.close()
-        for prec in worst:
-            w = worst[prec]
-            print(f"draw fam{fam} {draw} {prec:5s} f {w[0]:.2e} tr {w[1]:.2e} rot {w[2]:.2e} E {w[3]:.2e} rollout40 {roll[prec]:.2e} A"
-                  f"   worst cases: {wcase[prec][0]} / {wcase[prec][1]} / {wcase[prec][2]} / {wcase[prec][3]}")
-        m.close()
+import draw_report
+draw_report.main()
 print()
 for family in (0, 1):
     hp = hp1 if family else HParams()
