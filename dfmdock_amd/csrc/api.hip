@@ -277,15 +277,6 @@ static std::vector<uint32_t> pack_bias(const float *bias, bool f16)
     }
     return v;
 }
-// single fp16 tile in the same order (two-term form of k_gemm_split)
-static std::vector<uint16_t> tile_f16(const float *W, int Nout, int K)
-{
-    std::vector<uint16_t> t((size_t)Nout * K);
-    for (int o = 0; o < Nout; ++o)
-        for (int k = 0; k < K; ++k)
-            t[(((size_t)(k / 32) * 4 + (k % 32) / 8) * Nout + o) * 8 + (k % 8)] = f2h(W[(size_t)o * K + k]);
-    return t;
-}
 static std::vector<float> transpose256(const float *W)
 {
     std::vector<float> t((size_t)H * H);
@@ -410,7 +401,6 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
             split_bf16(Wabs.data(), 2 * H, H, hi, lo); up16(&D.Wab_hi, hi); up16(&D.Wab_lo, lo);
             split_bf16(Lw.n1_w, H, 2 * H, hi, lo); up16(&D.W3_hi, hi); up16(&D.W3_lo, lo);
             split_bf16(Lw.n2_w, H, H, hi, lo); up16(&D.W4_hi, hi); up16(&D.W4_lo, lo);
-            up16(&D.Wab_h, tile_f16(Wabs.data(), 2 * H, H)); up16(&D.W3_h, tile_f16(Lw.n1_w, H, 2 * H)); up16(&D.W4_h, tile_f16(Lw.n2_w, H, H));
         }
         if (Lw.c1_w) {
             const std::vector<float> Wc1t = transpose256(Lw.c1_w);
@@ -435,7 +425,6 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
             std::vector<uint16_t> hi, lo;
             up(&D.wab, wab.data(), wab.size());
             split_bf16(wab.data(), 2 * H, H, hi, lo); up16(&D.wab_hi, hi); up16(&D.wab_lo, lo);
-            up16(&D.wab_h, tile_f16(wab.data(), 2 * H, H));
             up(&D.w_d, wd.data(), H); up(&D.ln_w, src.ln_w, H); up(&D.ln_b, src.ln_b, H); up(&D.w3, src.w3, H);
         }
     } else {
@@ -641,25 +630,19 @@ __global__ void k_fill(float *dst, float v, int n)
 //     here: the gathered operands (Wb h_j, the lookup tables) are stored as fp16 in either plan.
 //   * A_i = Wa h_i + b1 is read as fp16 in every layer (it joins Bm_j and the tables; fp32 A_i changes no worst case); the f16
 //     engine (DFM_F_F16) keeps fp32.
-//   * node-level GEMMs: three terms on split-bf16 operands (~1e-5).  The two-term fp16 form (weights as ONE fp16 tile, r02) is
-//     13 % faster per launch but its 2.4e-4 weight rounding is again coherent: 9.2e-3 on tr_score of the second family (seed 1).
-// DFM_GEMM_TERMS=2 (diagnostic, echoed by dfm_config_string) restores the two-term form for A/B runs.
-static bool gemm_two_term()
-{
-    static const bool v = [] { const char *e = getenv("DFM_GEMM_TERMS"); return e && atoi(e) == 2; }();
-    return v;
-}
-
+//   * node-level GEMMs: three terms on split-bf16 operands (~1e-5).  The two-term fp16 form of r02 (weights as ONE fp16 tile) was
+//     13 % faster per launch but its 2.4e-4 weight rounding is again coherent: 9.2e-3 on tr_score of the second family (seed 1);
+//     it is gone.
 extern "C" const char *dfm_config_string(void)
 {
     static const std::string v = [] {
         std::string c = "mfma16: per-edge operands fp16 in every layer (DFM_F_BF16_OPS: bf16 in layers 0..depth-2), A_i fp16 "
                         "(DFM_F_F16: fp32), gathered Bm / tables fp16, node GEMMs ";
-        c += gemm_two_term() ? "TWO-term fp16 (DFM_GEMM_TERMS=2)" : "three-term split-bf16";
+        c += "three-term split-bf16";
         c += ", fp32 accumulate / geometry / GraphNorm statistics / heads / SDE step";
         c += "; build: TAB_MERGE=" + std::to_string((int)DFM_TAB_MERGE);
         std::string env;
-        for (const char *k : {"DFM_GEMM_TERMS", "DFM_GEMM_MT", "DFM_EDGE_SPLIT", "DFM_LIB"}) {
+        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_LIB"}) {
             const char *e = getenv(k);
             if (e) env += std::string(env.empty() ? "" : " ") + k + "=" + e;
         }
@@ -687,7 +670,6 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
     hipStream_t s = cx->stream;
     const int N = cx->N, R = cx->R, L = cx->L, K = cx->K, depth = m->hp.depth;
     const uint32_t stream_id = cx->fwd_counter++;
-    const bool w16 = o.bf16 && !o.f16 && gemm_two_term();
 
     const bool pair_family = m->hp.family == 1;
     HIPCHK(launch_prep_pose(cx->rec_pos, W.lig_cur, B, R, L, pair_family ? 1 : 0, W.pos, W.ca4, W.cb4, s));
@@ -755,14 +737,14 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         // 16-bit engines: the GEMM leaves per-tile column sums of u behind, so GraphNorm needs no extra pass over u
         const bool fused_stats = o.bf16 && gemm_rows_per_tile() == 64;
         if (fused_stats) { g.stat_part = W.gn_part; g.rows_per_graph = N; }
-        if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W3_hi, Lw.W3_lo, s, w16 ? Lw.W3_h : nullptr)); else HIPCHK(launch_gemm_f32(g, s));
+        if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W3_hi, Lw.W3_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         if (fused_stats) HIPCHK(launch_gn_finish(W.gn_part, B, N, Lw.gn_ms, W.gn_shift, W.gn_den, Lw.gn_w, Lw.gn_b, s));
         else HIPCHK(launch_gn_stats(W.u, B, N, Lw.gn_ms, W.gn_shift, W.gn_den, o.bf16 ? Lw.gn_w : nullptr, o.bf16 ? Lw.gn_b : nullptr, s));
         std::memset(&g, 0, sizeof(g));
         g.A0 = W.u; g.lda = H; g.K = H; g.pro = 2; g.gn_shift = W.gn_shift; g.gn_den = W.gn_den; g.gn_w = Lw.gn_w;
         g.gn_b = Lw.gn_b; g.rows_per_graph = N; g.W = Lw.W4; g.ldw = H; g.bias = Lw.b4; g.M = M; g.Nout = H;
         g.epi = 1; g.R = h; g.C = hn; g.ldc = H;
-        if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W4_hi, Lw.W4_lo, s, w16 ? Lw.W4_h : nullptr)); else HIPCHK(launch_gemm_f32(g, s));
+        if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W4_hi, Lw.W4_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         { float *tmp = h; h = hn; hn = tmp; }
         if (l == 0 && o.h_first_out)
             HIPCHK(hipMemcpyAsync(o.h_first_out, h, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -773,7 +755,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             g.bias = cx->homomer ? (o.bf16 ? Ln.bias_ab_h_s : Ln.bias_ab_h) : (o.bf16 ? Ln.bias_ab_s : Ln.bias_ab);
             g.epi = 2; g.C = W.A; g.ldc = H; g.C2 = o.bf16 ? nullptr : W.Bm; g.C2b = W.Bmb;   // 16-bit engines gather the fp16 copy only
             if (layer_aw16(l + 1)) g.Cb = reinterpret_cast<uint16_t *>(W.A);     // ... and, bf16 operands, A as fp16 too (same buffer)
-            if (o.bf16) HIPCHK(launch_gemm_split(g, Ln.Wab_hi, Ln.Wab_lo, s, w16 ? Ln.Wab_h : nullptr)); else HIPCHK(launch_gemm_f32(g, s));
+            if (o.bf16) HIPCHK(launch_gemm_split(g, Ln.Wab_hi, Ln.Wab_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         }
     }
     if (h != W.h) {   // keep the final node features in W.h (depth odd)
@@ -788,7 +770,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             std::memset(&g, 0, sizeof(g));
             g.A0 = W.h; g.lda = H; g.K = H; g.W = Ph.wab; g.ldw = H; g.M = M; g.Nout = 2 * H; g.epi = 2; g.C = W.A; g.ldc = H;
             g.C2 = W.Bm;
-            if (o.bf16) HIPCHK(launch_gemm_split(g, Ph.wab_hi, Ph.wab_lo, s, w16 ? Ph.wab_h : nullptr)); else HIPCHK(launch_gemm_f32(g, s));
+            if (o.bf16) HIPCHK(launch_gemm_split(g, Ph.wab_hi, Ph.wab_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
             PairArgs a;
             std::memset(&a, 0, sizeof(a));
             a.P = W.A; a.Q = W.Bm; a.ca4 = W.ca4; a.B = B; a.R = R; a.L = L; a.w_d = Ph.w_d; a.ln_w = Ph.ln_w; a.ln_b = Ph.ln_b;

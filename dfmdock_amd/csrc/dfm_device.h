@@ -88,6 +88,15 @@ __host__ __device__ inline float h2f(uint16_t hbits)
 
 __device__ inline float bflo(uint32_t packed) { return __uint_as_float(packed << 16); }
 __device__ inline float bfhi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+// two fp32 -> packed fp16 on the hardware converter (round to nearest even), saturating at +-65504 like f2h (NaN stays NaN).
+// f2h above is bit manipulation for host AND device (~30 instructions and several branches per value): fine for one-off uploads,
+// not for a GEMM epilogue - the [Wa|Wb] projection spent half its time in it (profiles/r03_exp_gemm_variants.txt)
+__device__ inline uint32_t pack_h2_sat(float a, float b)
+{
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t v = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+    return __builtin_bit_cast(uint32_t, v);
+}
 __device__ inline uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 __device__ inline float silu(float x) { return x / (1.0f + __expf(-x)); }

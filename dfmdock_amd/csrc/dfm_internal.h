@@ -60,7 +60,6 @@ struct LayerDev {
     float *W4;        // [256][256]   node_mlp.3.weight
     float *b4;
     uint16_t *Wab_hi, *Wab_lo, *W3_hi, *W3_lo, *W4_hi, *W4_lo;   // bf16 hi/lo splits for launch_gemm_split
-    uint16_t *Wab_h, *W3_h, *W4_h;                               // the same weights as single fp16 tiles (two-term form, bf16 engine)
     float *Wc1t;      // [256 in][256 out] coord_mlp.0.weight transposed (last layer)
     uint16_t *Wc1f;   // bf16 fragments of coord_mlp.0.weight
     uint16_t *Wc1f16; // fp16 fragments
@@ -93,7 +92,6 @@ struct HeadsDev {
 struct PairHeadDev {
     float *wab;                 // [512][256] fp32 (fp32 engine)
     uint16_t *wab_hi, *wab_lo;  // split-bf16 tiles of the same (16-bit engines)
-    uint16_t *wab_h;            // single fp16 tile (two-term form, bf16 engine)
     float *w_d, *ln_w, *ln_b, *w3;
 };
 
@@ -144,8 +142,8 @@ struct GemmArgs {
 hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s);
 // split-bf16 (hi/lo) variant, ~1e-5 relative error; Whi/Wlo = pre-split weights [Nout][ldw] bf16
 // W16 non-null: the two-term fp16 form (weights as ONE fp16 tile in the same [K/32][4][Nout][8] order); else three bf16 terms
-hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s, const uint16_t *W16 = nullptr);
-int gemm_rows_per_tile();   // 64 (default) or 128 (DFM_GEMM_MT=2): the fused GraphNorm statistics need the 64-row tile
+hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s);
+int gemm_rows_per_tile();   // 64: the row tile of k_gemm_split (tiles of the fused GraphNorm statistics)
 
 hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, int all_atoms, float *pos,
                             float4 *ca4, float4 *cb4, hipStream_t s);

@@ -158,7 +158,7 @@ constexpr int SN = 256, SK = 32, SLD = 40;   // output columns per workgroup; K 
 
 struct GemmSplitArgs {
     GemmArgs g;
-    const uint16_t *Whi, *Wlo;   // [K/32][4][Nout][8] bf16 hi / lo (split_bf16 in api.hip); W16 kernels: Whi = the fp16 tile, Wlo unused
+    const uint16_t *Whi, *Wlo;   // [K/32][4][Nout][8] bf16 hi / lo (split_bf16 in api.hip)
 };
 
 __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
@@ -168,18 +168,17 @@ __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
     return v.u;
 }
 
-// MT = 64-row groups per workgroup.  MT 2: 128 x 256 tile, waves 2 x 2 of 64 x 128 (60 KiB LDS, 2 workgroups / CU);
-// MT 1: 64 x 256 tile, waves 1 x 4 of 64 x 64 (50 KiB LDS, 3 workgroups / CU: more independent phases in flight).
-// W16 = 1 (the bf16 engine): TWO terms on fp16 operands instead of three on bf16 - the weights as ONE fp16 tile (11 mantissa bits:
-// ~3e-4 relative on an output, against ~3e-3 from the bf16 per-edge contractions of the same engine), the activations as fp16
-// hi + lo (hi by one v_cvt_pkrtz per pair - round-to-zero also saturates -, lo = x - hi).  A third less MFMA work, 40 % less
-// staging, 38 KiB of LDS (0.138 vs 0.162 ms per launch).  Register target: three workgroups per CU - forcing 128 registers for four
-// costs 9 spills and 6 % (0.146 ms), five 0.159 ms.
-#ifndef DFM_GEMM_W16_WGS
-#define DFM_GEMM_W16_WGS 3
-#endif
-template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 ? DFM_GEMM_W16_WGS : 3)) void k_gemm_split(GemmSplitArgs sa)
+// 64 x 256 tile per workgroup, waves 1 x 4 of 64 x 64 (50 KiB LDS, 3 workgroups / CU: more independent phases in flight than the
+// 128-row tile of r01).  Variants measured this round and dropped (same-box A/B, profiles/r03_exp_gemm_variants.txt): weight fragments
+// straight from L2 into registers + double-buffered activation stages (200 registers, 2 workgroups / CU: 175 vs 162 us - the
+// vector-memory path, not LDS, carries the 32 KiB of weights per stage either way, and occupancy matters more); that kernel made
+// persistent (181 vs 186 us); two terms a_hi x (w_hi + w_lo) on fp16 (no faster: not MFMA-bound; 8.2e-3 on f of the 3x draw).
+// What did pay: the fp16 outputs of the [Wa|Wb] projection converted by the hardware (f2h is 30 instructions of bit manipulation
+// per value: half of that launch) and stored as 16-byte vectors: 200 -> 153 us for that launch, 166 -> 149 us over the three.
+// HALF = 1: epilogue 2 with 16-bit outputs only (Cb and C2b set, no fp32 C2): the [Wa|Wb] projection of the 16-bit engine
+template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmSplitArgs sa)
 {
+    constexpr int MT = 1, W16 = 0;
     constexpr int SM = 64 * MT, WN = 4 / MT, NJ = 8 / WN;      // rows; waves along N; 32-column tiles per wave
     const GemmArgs &a = sa.g;
     // operand tiles; the epilogue reuses the space as 4 x 9216 B of transposition buffers
@@ -194,7 +193,11 @@ template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 
     // block -> (row tile, 256-column block).  With two column blocks (the [Wa|Wb] projection, Nout = 512) the launch is 1-D and the
     // two blocks of a row tile are 8 apart: workgroup g runs on XCD g % 8, so they share an L2 and run close in time - the second
     // read of the 64 x K activation tile hits L2 instead of HBM
-    int bx = blockIdx.x, by = blockIdx.y;
+    // (A persistent grid - three workgroups per CU walking the tiles, so that a tile's store burst drains under the next tile's K
+    // loop - costs 68 spilled registers at this kernel's 168-register budget: 4x slower.)
+    __shared__ __attribute__((aligned(16))) float gn_s[MT == 1 ? 2 * H : 4];
+    const int vb = blockIdx.x;
+    int bx = vb, by = blockIdx.y;
     if (gridDim.y == 1 && a.Nout == 2 * SN) {
         const int g16 = bx >> 4, j = bx & 15;
         bx = g16 * 8 + (j & 7); by = j >> 3;
@@ -204,7 +207,6 @@ template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 
     const int col0 = by * SN;
     // GraphNorm prologue (MT = 1): the folded scale / shift of the tile's trajectory, 2 KiB in LDS for the whole K loop (a load
     // per K-stage inside the staging code would expose an L2 round trip per stage)
-    __shared__ __attribute__((aligned(16))) float gn_s[MT == 1 ? 2 * H : 4];
     if (MT == 1 && (a.stat_part || a.pro == 2)) {
         const int tpt = (a.rows_per_graph + SM - 1) / SM, tb = bx / tpt;
         row0 = tb * a.rows_per_graph + (bx - tb * tpt) * SM;
@@ -380,6 +382,26 @@ template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 
                     est[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * ELD + jj * 32 + l31] = acc[i][j][r] + bias;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // 16-bit outputs only (the [Wa|Wb] projection of the 16-bit engines: A as fp16, Bm as fp16): 8 lanes x 16 B cover a
+            // row's 64 columns (one 128-byte line), 8 rows = 1 KiB per store instruction - the 4 x 16 float4 read-back below
+            // would emit 8-byte stores, twice the instructions for the same bytes (r02 stamps: 60 % of that launch was epilogue)
+            if constexpr (HALF) {
+                uint16_t *half_out = col0 < H ? a.Cb : a.C2b;
+                const int er8 = lane >> 3, ec8 = (lane & 7) * 8;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int lr = q * 8 + er8;
+                    const float4 v0 = *reinterpret_cast<const float4 *>(est + lr * ELD + ec8);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(est + lr * ELD + ec8 + 4);
+                    const size_t row = (size_t)row0 + wm * 64 + i * 32 + lr;
+                    const int col = (col0 < H ? col0 : col0 - H) + (wn * NJ + jp * 2) * 32 + ec8;
+                    if (row >= (size_t)row_end) continue;
+                    uint4 o;
+                    o.x = pack_h2_sat(v0.x, v0.y); o.y = pack_h2_sat(v0.z, v0.w);
+                    o.z = pack_h2_sat(v1.x, v1.y); o.w = pack_h2_sat(v1.z, v1.w);
+                    *reinterpret_cast<uint4 *>(half_out + row * H + col) = o;
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int lr = q * 4 + er;
@@ -403,16 +425,16 @@ template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 
                     if (col0 < H) {
                         if (a.Cb) {
                             uint2 o;
-                            o.x = (uint32_t)f2h(v.x) | ((uint32_t)f2h(v.y) << 16);
-                            o.y = (uint32_t)f2h(v.z) | ((uint32_t)f2h(v.w) << 16);
+                            o.x = pack_h2_sat(v.x, v.y);
+                            o.y = pack_h2_sat(v.z, v.w);
                             *reinterpret_cast<uint2 *>(a.Cb + row * H + col) = o;
                         } else *reinterpret_cast<float4 *>(a.C + row * H + col) = v;
                     } else {
                         if (a.C2) *reinterpret_cast<float4 *>(a.C2 + row * H + (col - H)) = v;
                         if (a.C2b) {
                             uint2 o;
-                            o.x = (uint32_t)f2h(v.x) | ((uint32_t)f2h(v.y) << 16);
-                            o.y = (uint32_t)f2h(v.z) | ((uint32_t)f2h(v.w) << 16);
+                            o.x = pack_h2_sat(v.x, v.y);
+                            o.y = pack_h2_sat(v.z, v.w);
                             *reinterpret_cast<uint2 *>(a.C2b + row * H + (col - H)) = o;
                         }
                     }
@@ -420,18 +442,19 @@ template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 
                     *reinterpret_cast<float4 *>(a.C + row * a.ldc + col) = v;
                 }
             }
+            }   // full-width outputs
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
 #ifdef DFM_GEMM_STAMP
     GSTAMP(3)                      // [3] epilogue
-    if (blockIdx.x == 7 * 8 && tid == 0 && a.C) {       // one mid-grid workgroup reports (debug buffer = first floats of ... stderr-free: printf)
+    if (vb == 7 * 8 + 1536 && tid == 0 && a.C) {       // one mid-grid workgroup reports (debug buffer = first floats of ... stderr-free: printf)
         printf("gemm stamp K=%d Nout=%d pro=%d epi=%d: mfma+barrier %llu  fetch-wait+stage %llu  barrier2 %llu  epilogue %llu cycles\n",
                a.K, a.Nout, a.pro, a.epi, gs[0], gs[1], gs[2], gs[3]);
     }
 #endif
     if constexpr (MT == 1) {
         if (a.stat_part) {
-            float *sp = a.stat_part + (size_t)blockIdx.x * (H * 2);
+            float *sp = a.stat_part + (size_t)vb * (H * 2);
             const float inv_n = st_n > 0.f ? 1.0f / st_n : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -458,34 +481,22 @@ template <int MT, int W16> __global__ __launch_bounds__(256, MT == 2 ? 2 : (W16 
 }
 #undef GEMM_SPLIT_FETCH
 
-int gemm_rows_per_tile()
-{
-    static const int v = [] { const char *e = getenv("DFM_GEMM_MT"); return e && atoi(e) == 2 ? 128 : 64; }();
-    return v;
-}
+int gemm_rows_per_tile() { return 64; }
 
-hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s, const uint16_t *W16)
+hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s)
 {
     if (a.K % SK != 0 || a.Nout % SN != 0 || (a.pro == 1 && (a.K / 2) % SK != 0) || a.lda % 4 != 0 || a.ldc % 4 != 0)
         return hipErrorInvalidValue;
     GemmSplitArgs sa;
-    sa.g = a; sa.Whi = W16 ? W16 : Whi; sa.Wlo = Wlo;
-    static int mt = 0;
-    if (!mt) { const char *e = getenv("DFM_GEMM_MT"); mt = e && atoi(e) == 2 ? 2 : 1; }
-    if (a.stat_part && (mt != 1 || a.Nout != SN || a.rows_per_graph < 1 || a.M % a.rows_per_graph != 0)) return hipErrorInvalidValue;
+    sa.g = a; sa.Whi = Whi; sa.Wlo = Wlo;
+    if (a.stat_part && (a.Nout != SN || a.rows_per_graph < 1 || a.M % a.rows_per_graph != 0)) return hipErrorInvalidValue;
     if (a.pro == 2 && (a.rows_per_graph < 1 || a.M % a.rows_per_graph != 0)) return hipErrorInvalidValue;
     dim3 grid;
-    if (mt == 2) grid = dim3((a.M + 127) / 128, a.Nout / SN);
-    else if (a.stat_part || a.pro == 2) grid = dim3((a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64), a.Nout / SN);   // row tiles aligned to the trajectories
+    if (a.stat_part || a.pro == 2) grid = dim3((a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64), a.Nout / SN);   // row tiles aligned to the trajectories
     else if (a.Nout == 2 * SN) grid = dim3((((a.M + 63) / 64 + 7) / 8) * 16, 1);      // paired column blocks, see the block mapping in the kernel
     else grid = dim3((a.M + 63) / 64, a.Nout / SN);
-    if (mt == 2) {
-        if (W16) hipLaunchKernelGGL((k_gemm_split<2, 1>), grid, dim3(256), 0, s, sa);
-        else hipLaunchKernelGGL((k_gemm_split<2, 0>), grid, dim3(256), 0, s, sa);
-    } else {
-        if (W16) hipLaunchKernelGGL((k_gemm_split<1, 1>), grid, dim3(256), 0, s, sa);
-        else hipLaunchKernelGGL((k_gemm_split<1, 0>), grid, dim3(256), 0, s, sa);
-    }
+    if (a.epi == 2 && a.Cb && a.C2b && !a.C2) hipLaunchKernelGGL(k_gemm_split<1>, grid, dim3(256), 0, s, sa);
+    else hipLaunchKernelGGL(k_gemm_split<0>, grid, dim3(256), 0, s, sa);
     return hipGetLastError();
 }
 

@@ -45,9 +45,31 @@ def current_group() -> Group:
     return _group
 
 
+class _stdout_to_stderr:
+    """gloo / RCCL print connection banners on file descriptor 1; a bench's stdout carries ONE JSON line, so the banners of the
+    rendezvous go to stderr."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def init(device_index: int | None = None, prefer: str | None = None, timeout_s: float = 120.0) -> Group:
     """Bring up the collective layer for this rank (see the module docstring).  `prefer`: "nccl" (default on a GPU box; env
     DFM_DIST_BACKEND overrides), "gloo" or "file"."""
+    with _stdout_to_stderr():
+        return _init(device_index, prefer, timeout_s)
+
+
+def _init(device_index, prefer, timeout_s) -> Group:
     global _group
     import datetime
     rank, _, world = dist_env()

@@ -148,7 +148,7 @@ typedef struct {
 
 const char *dfm_last_error(void);
 /* One line describing the precision plan and every diagnostic environment switch / build knob in force in this process
- * (DFM_GEMM_TERMS, DFM_GEMM_MT, DFM_EDGE_SPLIT, DFM_LIB is the loader's): benches and tests print it, so that a run under
+ * (DFM_EDGE_SPLIT; DFM_LIB is the loader's): benches and tests print it, so that a run under
  * a stray variable cannot pass for the shipped engine.  The pointer stays valid for the life of the process. */
 const char *dfm_config_string(void);
 int dfm_device_count(int *count);
