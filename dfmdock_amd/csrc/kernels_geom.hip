@@ -85,29 +85,95 @@ __device__ inline uint32_t wave_min_u32(uint32_t v)
 // ------------------------------------------------------------------------------------------------
 // kNN(20) + sample(40, p ~ 1/d^3, without replacement) (score_net_mlsb.py:85-135): the pairwise C-alpha distance scan and the
 // radial-graph edge build.  One 64-lane wave per (trajectory, node); the candidates' coordinates are read straight from global
-// memory (the C-alpha array of a trajectory is 9.6 KB at N = 600, 32 KB at N = 2000: L1 / L2 resident, and the scan is 3 % of the
-// kernel's instructions).  An LDS-tiled form - the workgroup stages its trajectory's coordinates as a structure of arrays and
-// the four waves read them back in conflict-free 16-byte reads - was built, parity-tested and measured slower (fill + barrier
-// per short-lived workgroup; with 8 / 32 nodes per workgroup also +14 registers and a coarser tail): 948 / 955 vs 880 us at C3,
-// 949 / 1297 vs 827 us at C5 (N = 2000, B = 32) - profiles/r02_exp_knn_lds.txt.  The lane owns candidates j = 4*(lane + 64*q) + e
-// (q < NPL/4, e < 4) in registers.  Top-k by repeated wave-wide arg-min of (value, index):
-// ascending distance, lowest index first on ties, slot 0 = the node itself.  The sampled slots
-// are an exponential race: key_j = Exp(1)_j * d_j^3, the 40 smallest keys = successive sampling
-// without replacement with p ~ d^-3 (the scheme torch.multinomial uses), Exp(1) from Philox4x32-10.
+// memory (the C-alpha array of a trajectory is 9.6 KB at N = 600, 32 KB at N = 2000: L1 / L2 resident).  An LDS-tiled form of the
+// scan was built, parity-tested and measured slower in r02 (profiles/r02_exp_knn_lds.txt).  The lane owns candidates
+// j = 4*(lane + 64*q) + e (q < NPL/4, e < 4) in registers.
+//
+// Both selections - the knn nearest (ascending distance, lowest index first on ties, slot 0 = the node itself) and the nsamp
+// smallest race keys key_j = Exp(1)_j * d_j^3 (= successive sampling without replacement with p ~ d^-3, the scheme
+// torch.multinomial uses; Exp(1) from Philox4x32-10) - are THRESHOLD selections: non-negative floats order like their bit
+// patterns, so the k-th smallest word is found bit by bit from the top with one wave-wide count (NPL compares + scalar popcounts)
+// per bit, stopping as soon as a threshold cuts off exactly k words (about 15-20 bits in practice); ties at the k-th value go to the
+// lowest candidate index.  The kNN winners are then ranked among themselves through LDS (20 x 20 comparisons) for the sorted order
+// the reference's topk gives; sampled slots keep candidate order (their order carries no meaning).  r02 ran knn + nsamp = 60
+// wave-wide arg-min passes per node (the kernel was VALU-issue-bound: 4.2 k instructions per node at N = 600, 8.5 k at N = 2000,
+// profiles/r03_a_pmc_knn_*.txt); this form needs about a third of that.
+template <int NPL> __device__ inline uint32_t knn_count_lt(const uint32_t (&key)[NPL], uint32_t t)
+{
+    uint32_t c = 0;
+    if constexpr (NPL < 32) {      // ballots + scalar popcounts: the scalar unit works beside the vector pipe (kernel x0.50 at N = 600)
+#pragma unroll
+        for (int r = 0; r < NPL; ++r) c += (uint32_t)__builtin_popcountll(__ballot(key[r] < t));
+        return c;
+    }
+    // NPL >= 32: 2 NPL live scalar registers spill (86 at NPL = 32); per-lane count on the vector pipe, then ONE wave sum
+    // (kernel x0.70 at N = 2000 against x0.79 with ballots)
+#pragma unroll
+    for (int r = 0; r < NPL; ++r) c += key[r] < t ? 1u : 0u;
+    c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x141, 0xF, 0xF, true);    // row_half_mirror
+    c += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)c, 0x140, 0xF, 0xF, true);    // row_mirror
+    c += (uint32_t)__builtin_amdgcn_ds_swizzle((int)c, 0x401F);                      // lane ^ 16
+    return (uint32_t)__builtin_amdgcn_readlane((int)c, 0) + (uint32_t)__builtin_amdgcn_readlane((int)c, 32);      // wave-uniform
+}
+__device__ inline uint32_t knn_cand(int lane, int r) { return 4u * (uint32_t)lane + 256u * (uint32_t)(r >> 2) + (uint32_t)(r & 3); }
+// bit r of the result: slot r of this lane is among the k smallest (key, candidate index) pairs of the wave (k <= valid keys)
+template <int NPL> __device__ inline uint64_t knn_select(const uint32_t (&key)[NPL], int k, int lane)
+{
+    uint32_t prefix = 0, thr = 0;
+    bool exact = false;
+    for (int bit = 30; bit >= 0; --bit) {      // keys are non-negative floats: bit 31 is clear
+        const uint32_t t = prefix | (1u << bit);
+        const uint32_t c = knn_count_lt<NPL>(key, t);
+        if (c == (uint32_t)k) { thr = t; exact = true; break; }
+        if (c < (uint32_t)k) prefix = t;       // the k-th smallest word is >= t
+    }
+    uint64_t sel = 0;
+    if (exact) {
+#pragma unroll
+        for (int r = 0; r < NPL; ++r) sel |= (uint64_t)(key[r] < thr) << r;
+        return sel;
+    }
+    // prefix = the k-th smallest word itself: everything below it, then the ties in ascending candidate order (rare)
+    uint64_t tie = 0;
+#pragma unroll
+    for (int r = 0; r < NPL; ++r) { sel |= (uint64_t)(key[r] < prefix) << r; tie |= (uint64_t)(key[r] == prefix) << r; }
+    asm volatile("" : "+v"(sel), "+v"(tie));
+    int need = k - (int)knn_count_lt<NPL>(key, prefix);
+    while (need > 0) {
+        uint32_t jb = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < NPL; ++r) { const uint32_t j = knn_cand(lane, r); jb = ((tie >> r) & 1) && j < jb ? j : jb; }
+        const uint32_t win = wave_min_u32(jb);
+#pragma unroll
+        for (int r = 0; r < NPL; ++r)
+            if (((tie >> r) & 1) && knn_cand(lane, r) == win) { sel |= 1ull << r; tie &= ~(1ull << r); }
+        --need;
+    }
+    return sel;
+}
+__device__ inline int lanes_below(unsigned long long m)      // set bits of m below this lane
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 template <int NPL>
 __global__ __launch_bounds__(256) void k_knn_sample(const float4 *__restrict__ ca4, int B, int N, int knn, int nsamp,
                                                     uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
                                                     int32_t *__restrict__ edges)
 {
-    const int lane = threadIdx.x & 63;
-    const long long node = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t sh_key[4][64], sh_j[4][64];
+    __shared__ int32_t sh_out[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long node = (long long)blockIdx.x * 4 + w;
     if (node >= (long long)B * N) return;   // whole wave exits together; no block-level sync below
-    const int b = (int)(node / N), i = (int)(node % N);
+    const int b = (int)((unsigned long long)node / (unsigned)N), i = (int)(node - (long long)b * N);
     const float4 *ca = ca4 + (size_t)b * N;
     const float4 ci = ca[i];
     const int K = knn + nsamp;
 
-    float val[NPL];
+    uint32_t key[NPL];      // first the distance bits, then (sampling) the race-key bits of the same candidates
 #pragma unroll
     for (int q = 0; q < NPL / 4; ++q) {
 #pragma unroll
@@ -119,39 +185,35 @@ __global__ __launch_bounds__(256) void k_knn_sample(const float4 *__restrict__ c
                 const float dx = ci.x - cj.x, dy = ci.y - cj.y, dz = ci.z - cj.z;
                 d = sqrtf((dx * dx + dy * dy) + dz * dz);
             }
-            val[q * 4 + e] = d;
+            key[q * 4 + e] = __float_as_uint(d);
         }
+        // (keeps the scheduler from hoisting all NPL coordinate loads - 4 registers each - to the top: at NPL = 32 that alone is 128)
+        if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);
     }
-    float dist[NPL];
+    // ---- kNN: the knn smallest (distance, j), written in ascending order
+    uint64_t near = knn_select<NPL>(key, knn, lane);
+    asm volatile("" : "+v"(near));      // one packed mask, not NPL separate predicates kept alive across the sampling stage
+    {
+        int base = 0;
 #pragma unroll
-    for (int r = 0; r < NPL; ++r) dist[r] = val[r];
-
-    int my_edge = -1;   // lane s keeps the winner of pass s
-    // ---- kNN: `knn` exact passes of a wave-wide arg-min of (distance, j), ties to the smallest j.  Distances are
-    // non-negative floats, so their bit patterns order like unsigned integers: min value first (32-bit), then the
-    // smallest j that holds it.
-    for (int s = 0; s < knn; ++s) {
-        uint32_t mv = 0xFFFFFFFFu;
-#pragma unroll
-        for (int r = 0; r < NPL; ++r) { const uint32_t k = __float_as_uint(val[r]); mv = k < mv ? k : mv; }
-        const uint32_t wm = wave_min_u32(mv);
-        int rb = NPL;                          // this lane's first slot holding the minimum (slots ascend with j inside a lane)
-#pragma unroll
-        for (int r = NPL - 1; r >= 0; --r) rb = __float_as_uint(val[r]) == wm ? r : rb;
-        const uint32_t jb = rb < NPL ? 4u * (uint32_t)lane + 256u * (uint32_t)(rb >> 2) + (uint32_t)(rb & 3) : 0xFFFFFFFFu;
-        const int win = (int)wave_min_u32(jb);
-        rb = (int)jb == win ? rb : NPL;        // only the owner removes its slot
-#pragma unroll
-        for (int r = 0; r < NPL; ++r) val[r] = r == rb ? __builtin_inff() : val[r];
-        if (lane == s) my_edge = win;
+        for (int r = 0; r < NPL; ++r) {
+            const bool s = (near >> r) & 1;
+            const unsigned long long m = __ballot(s);
+            if (s) { const int pos = base + lanes_below(m); sh_key[w][pos] = key[r]; sh_j[w][pos] = knn_cand(lane, r); }
+            base += (int)__builtin_popcountll(m);
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (NPL ballots hoisted to the top spill scalar registers)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave: the writes above are visible to the reads below
+        const uint32_t myk = sh_key[w][lane & 31], myj = sh_j[w][lane & 31];      // knn <= 20
+        int rank = 0;
+        for (int e = 0; e < knn; ++e) {
+            const uint32_t ke = sh_key[w][e], je = sh_j[w][e];
+            rank += (ke < myk || (ke == myk && je < myj)) ? 1 : 0;
+        }
+        if (lane < knn) sh_out[w][rank] = (int32_t)myj;
     }
     if (nsamp > 0) {
-        // ---- sampling: race keys for every candidate not taken above; the nsamp smallest keys win.  The keys are
-        // random, so their six low mantissa bits are traded for the slot number (a 2^-17 relative perturbation of an
-        // Exp(1) draw): the 32-bit words are then unique inside a lane, each lane sorts its NPL words once (Batcher
-        // odd-even merge network on v_min_u32 / v_max_u32), and a pass is one wave minimum over the list heads plus a
-        // one-register shift in the winning lane.
-        uint32_t kq[NPL];
+        // ---- sampling: race keys for every candidate not taken above; the nsamp smallest win
 #pragma unroll
         for (int q = 0; q < NPL / 4; ++q) {
             const u32x4 rnd = philox4x32((uint32_t)node, (uint32_t)(node >> 32) ^ ((uint32_t)(lane + 64 * q) << 8),
@@ -160,45 +222,29 @@ __global__ __launch_bounds__(256) void k_knn_sample(const float4 *__restrict__ c
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = q * 4 + e;
-                float d = dist[r];
-                float key = __builtin_inff();
-                if (val[r] != __builtin_inff()) {   // not taken by kNN, j < N
+                float d = __uint_as_float(key[r]);
+                float k2 = __builtin_inff();
+                if (!((near >> r) & 1) && d != __builtin_inff()) {   // not taken by kNN, j < N
                     d = d < 1e-10f ? 1e-10f : d;
-                    key = -logf(u01(rr[e])) * ((d * d) * d);
+                    k2 = -__builtin_amdgcn_logf(u01(rr[e])) * ((d * d) * d);      // v_log_f32 (log2): a common factor ln 2 does not change the race
                 }
-                kq[r] = (__float_as_uint(key) & ~63u) | (uint32_t)r;
+                key[r] = __float_as_uint(k2);
             }
+            __builtin_amdgcn_sched_barrier(0);      // one Philox block at a time: its temporaries are not multiplied by NPL / 4
         }
-        constexpr int P2 = NPL <= 4 ? 4 : (NPL <= 8 ? 8 : (NPL <= 16 ? 16 : (NPL <= 32 ? 32 : 64)));
-#pragma unroll
-        for (int pp = 1; pp < P2; pp *= 2)
-#pragma unroll
-            for (int k = pp; k >= 1; k /= 2)
-#pragma unroll
-                for (int j = k % pp; j <= P2 - 1 - k; j += 2 * k)
-#pragma unroll
-                    for (int ii = 0; ii <= (k - 1 < P2 - j - k - 1 ? k - 1 : P2 - j - k - 1); ++ii)
-                        if ((ii + j) / (2 * pp) == (ii + j + k) / (2 * pp) && ii + j + k < NPL) {
-                            const uint32_t lo = kq[ii + j] < kq[ii + j + k] ? kq[ii + j] : kq[ii + j + k];
-                            const uint32_t hi = kq[ii + j] < kq[ii + j + k] ? kq[ii + j + k] : kq[ii + j];
-                            kq[ii + j] = lo; kq[ii + j + k] = hi;
-                        }
-        for (int s = knn; s < K; ++s) {
-            const uint32_t wm = wave_min_u32(kq[0]);
-            const unsigned long long owners = __ballot(kq[0] == wm);
-            const int wl = __builtin_ctzll(owners);                  // lowest lane on a tie across lanes
-            const int slot = (int)(wm & 63u);
-            const int win = 4 * wl + 256 * (slot >> 2) + (slot & 3);  // wave-uniform
-            // shift the winning lane's list by one.  Written as a bit-select (v_bfi_b32) on a lane mask: a plain
-            // `pop ? kq[r + 1] : kq[r]` is canonicalised into a variable-index extract and lowered to NPL^2 selects
-            const uint32_t pm = lane == wl ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-            for (int r = 0; r + 1 < NPL; ++r) kq[r] = (kq[r + 1] & pm) | (kq[r] & ~pm);
-            kq[NPL - 1] |= pm;
-            if (lane == s) my_edge = win;
+        uint64_t drawn = knn_select<NPL>(key, nsamp, lane);
+        asm volatile("" : "+v"(drawn));
+        int base = knn;
+#pragma unroll 1
+        for (int r = 0; r < NPL; ++r) {      // the mask is all this loop needs: no register array, no unrolling
+            const bool s = (drawn >> r) & 1;
+            const unsigned long long m = __ballot(s);
+            if (s) sh_out[w][base + lanes_below(m)] = (int32_t)knn_cand(lane, r);
+            base += (int)__builtin_popcountll(m);
         }
     }
-    if (lane < K) edges[((size_t)b * N + i) * K + lane] = my_edge;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < K) edges[((size_t)b * N + i) * K + lane] = sh_out[w][lane];
 }
 
 hipError_t launch_knn_sample(const float4 *ca4, int B, int N, int knn, int nsamp, uint64_t seed, uint32_t stream_id,

@@ -1,27 +1,33 @@
 #!/bin/bash
 # Round-end evidence run on the GPU box (every step under its own timeout, outputs under gpurun_out/final/, copied into profiles/):
 #   full GPU test suite | default bench line (with cpu_baseline) | rocprofv3 --kernel-trace --stats of the same bench command |
-#   HBM traffic of the dominant kernel (FETCH_SIZE / WRITE_SIZE in separate --pmc passes) + SQ counters |
-#   C5 (1000+1000, B=32) kernel stats | second model family kernel stats + deviation table | tolerance report | size sweep
+#   counters of the dominant kernel (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, SQ busy counters) -> traffic JSON that
+#   bench.py replays | counters of k_knn_sample at C3 and C5 | C5 kernel stats | second model family | tolerance report | size sweep
 cd $GRAFT_REPO_ROOT; OUT=$GRAFT_REPO_ROOT/gpurun_out/final; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
 prof() {   # prof <tag> <cmd...>: rocprofv3 kernel stats of a command, csv -> $OUT/<tag>_kernel_stats.csv, stdout -> $OUT/<tag>.log
   tag=$1; shift
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- "$@" > $OUT/$tag.log 2>&1 )
   cp $(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1) $OUT/${tag}_kernel_stats.csv 2>/dev/null; rm -rf /tmp/prof_$tag
 }
+pmc() {    # pmc <dir> <kernel regex> <bench args...>: one --pmc set per run, kernel-filtered, no trace domains
+  dir=$1; kr=$2; shift 2
+  mkdir -p $OUT/$dir
+  for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE"; do
+    n=$(echo $c | cut -d' ' -f1-2 | tr ' ' '_')
+    ( cd /tmp && timeout 240 rocprofv3 --pmc $c --kernel-include-regex "$kr" --output-format csv -d $OUT/$dir -o $n -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/$dir/$n.log 2>&1 ) || echo "pass $c failed/timeout"
+  done
+  python tools/pmc_summary.py $OUT/$dir > $OUT/$dir.txt 2>&1
+}
 if [ -z "$SKIP_TESTS" ]; then timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log; fi
 timeout 600 python bench.py > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log | cut -c1-300
 prof bench_prof python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline; tail -1 $OUT/bench_prof.log | cut -c1-200; head -8 $OUT/bench_prof_kernel_stats.csv | cut -c1-160
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --batch 256 --num-steps 3 --no-cpu-baseline"
-mkdir -p $OUT/pmc
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
-         "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
-         "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE"; do
-  n=$(echo $c | cut -d' ' -f1-2 | tr ' ' '_')
-  ( cd /tmp && timeout 240 rocprofv3 --pmc $c --kernel-include-regex 'k_edge_msg<' --output-format csv -d $OUT/pmc -o $n -- $CMD > $OUT/pmc/$n.log 2>&1 ) || echo "pass $c failed/timeout"
-done
-python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_edge.txt 2>&1; cat $OUT/pmc_edge.txt
+pmc pmc_edge 'k_edge_msg<' --batch 256 --num-steps 3; cat $OUT/pmc_edge.txt
+pmc pmc_knn_c3 'k_knn_sample' --batch 256 --num-steps 3; cat $OUT/pmc_knn_c3.txt
+pmc pmc_knn_c5 'k_knn_sample' --R 1000 --L 1000 --batch 32 --num-steps 3; cat $OUT/pmc_knn_c5.txt
+python tools/make_traffic_json.py $OUT > $OUT/traffic_summary.txt 2>&1; cat $OUT/traffic_summary.txt
 prof c5 python $GRAFT_REPO_ROOT/bench.py --R 1000 --L 1000 --batch 32 --steps 1 --warmup 1 --no-cpu-baseline; tail -1 $OUT/c5.log | cut -c1-200; head -8 $OUT/c5_kernel_stats.csv | cut -c1-160
 prof pair python $GRAFT_REPO_ROOT/tools/pair_bench.py 256; tail -4 $OUT/pair.log; head -6 $OUT/pair_kernel_stats.csv | cut -c1-160
-timeout 900 python tools/tol_report.py > $OUT/tol_report.txt 2>&1; tail -3 $OUT/tol_report.txt
+timeout 900 python tools/tol_report.py > $OUT/tol_report.txt 2>&1; grep -E "^draw" $OUT/tol_report.txt | cut -c1-110
 timeout 600 python tools/size_sweep.py > $OUT/size_sweep.txt 2>&1; cat $OUT/size_sweep.txt
