@@ -543,6 +543,9 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
 #undef FAKE4
 #else
     auto gather_chunk = [&](int c) {
+#ifdef DFM_EDGE_DENSE_UB
+        if constexpr (AW16) a1 = bload16f_stream(rs_a, c4 * 16 + ((i + 1 < p.N) ? H * 2 : 0), c * 64);      // the next node's row
+#endif
         if constexpr (AW16) a0 = bload16f_stream(rs_a, c4 * 16, c * 64);
         else { a0 = bload16f_stream(rs_a, oc4, c * 128); a1 = bload16f_stream(rs_a, oc4, c * 128 + 16); }
         w0 = bload16f(rs_w, oc4, c * 128); w1 = bload16f(rs_w, oc4, c * 128 + 16);
@@ -583,7 +586,12 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
         if ((k & 1) == 0) {
             const f2 wv = e == 0 ? (f2){w0.x, w0.y} : (e == 1 ? (f2){w0.z, w0.w} : (e == 2 ? (f2){w1.x, w1.y} : (f2){w1.z, w1.w}));
             if constexpr (AW16) {      // w * radial (fp32) + a (fp16), one v_fma_mix_f32 per channel
-                const uint32_t ah = __float_as_uint(e == 0 ? a0.x : (e == 1 ? a0.y : (e == 2 ? a0.z : a0.w)));
+#ifdef DFM_EDGE_DENSE_UB
+                const float4 &aq = q == 1 ? a1 : a0;
+#else
+                const float4 &aq = a0;
+#endif
+                const uint32_t ah = __float_as_uint(e == 0 ? aq.x : (e == 1 ? aq.y : (e == 2 ? aq.z : aq.w)));
                 pv[e] = (f2){fma_half_lo(wv.x, radq[q], ah), fma_half_hi(wv.y, radq[q], ah)};
             } else {
                 const f2 rad2 = {radq[q], radq[q]};
@@ -648,7 +656,11 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
         unsigned ntt = tt;
         int nb = b, ni = i, nmt = mt + 1;
         bool have_next = true;
+#if defined(DFM_EDGE_DENSE_UB) && DFM_EDGE_DENSE_UB == 1     // diagnostic (wrong results): 15 tiles per 8 nodes, the tile count of dense row packing (8 x 60 rows = 15 x 32); 2: only the extra A_i load of that scheme
+        if (split || nmt == (((((i >> 3) + (i >> 6) + i) & 7) == 7) ? 1 : ntile)) {
+#else
         if (split || nmt == ntile) {
+#endif
             ntt = tt + tstride;
             have_next = next_task(ntt, nb, ni, nmt);
         }
@@ -811,7 +823,11 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
             asm volatile("" : "+v"(xt));
             colsum[nt] += xt;
         }
+#if defined(DFM_EDGE_DENSE_UB) && DFM_EDGE_DENSE_UB == 1
+        if (split || mt == (((((i >> 3) + (i >> 6) + i) & 7) == 7) ? 0 : ntile - 1)) {
+#else
         if (split || mt == ntile - 1) {
+#endif
             float *out = p.agg + ((size_t)b * p.N + i) * H + l31;
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {

@@ -152,8 +152,8 @@ def test_c5_large_complex(model, blob):
 # ---- C4 on one GPU ---------------------------------------------------------------------------------------------------
 def test_c4_db5_set_one_gpu(model, blob, tmp_path):
     """The full DB5 test set (24 complexes: backbones + sequences of the reference's data/db5_test, seeded node features),
-    40 trajectories x 40 steps each through driver.run_set; two complexes' per-trajectory energies are replayed through the
-    oracle with every draw injected."""
+    40 trajectories x 40 steps each through driver.run_set; six complexes spanning N = 197 ... 695 are replayed through the
+    oracle with every draw injected (4 trajectories x 5 steps each: poses at 0.05 A fp32 / 0.5 A 16-bit, final energies)."""
     from dfmdock_amd import driver, engine
     from oracle import oracle as ora
     ids = db5_ids()
@@ -169,9 +169,9 @@ def test_c4_db5_set_one_gpu(model, blob, tmp_path):
         assert 0.0 <= float(r["DockQ"]) <= 1.0 and np.isfinite(float(r["energy"])) and float(r["l_rmsd"]) >= 0.0
     for cid in ranked:
         assert ranked[cid].shape == (40, 10) and (np.diff(ranked[cid][:, 2]) >= 0).all()
-    S, B = 3, 2
+    S, B = 5, 4
     rng = np.random.default_rng(8)
-    for cid in ("1AVX", "4POU"):
+    for cid in ("1QA9", "4POU", "1AVX", "1IRA", "2VDB", "1H1V"):
         cx = db5_complex(cid)
         gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
         o = ora.Oracle(blob, cx)
