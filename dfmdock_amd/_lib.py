@@ -26,6 +26,7 @@ DFM_F_STEP_ENERGY = 1 << 6
 DFM_F_F16 = 1 << 7
 DFM_F_IRES = 1 << 8
 DFM_F_BF16_OPS = 1 << 9
+DFM_F_DIST = 1 << 10
 
 EXPORTS = [
     "dfm_last_error", "dfm_config_string", "dfm_device_count", "dfm_set_device", "dfm_default_hparams", "dfm_param_count",
@@ -46,7 +47,7 @@ class HParamsC(C.Structure):
 class ScoreOutC(C.Structure):
     _fields_ = [("tr_score", F32P), ("rot_score", F32P), ("energy", F32P), ("num_clashes", I32P), ("f", F32P),
                 ("h_last", F32P), ("h_first", F32P), ("edges", I32P), ("edge_codes", U32P), ("confidence", F32P),
-                ("ires", F32P)]
+                ("ires", F32P), ("dist_logits", F32P)]
 
 
 class InjectC(C.Structure):

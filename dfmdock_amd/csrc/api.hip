@@ -80,6 +80,7 @@ struct dfm_model {
     HeadsDev heads;
     float *en0_w = nullptr;          // [256][512]
     PairHeadDev pair[3];             // family 1: 0 to_force, 1 to_energy, 2 to_confidence
+    PairHeadDev dist;                // family 1: to_dist (fp32 only; w3 = [256][64], transposed)
     float *ir0_w = nullptr, *ir0_b = nullptr, *ir2_w = nullptr, *ir2_b = nullptr, *ir4_w = nullptr, *ir4_b = nullptr;   // to_ires
 };
 
@@ -134,7 +135,7 @@ struct BlobMap {
             *att_w, *att_b;
     } layer[8];
     const float *en0_w, *en_ln_w, *en_ln_b, *en3_w;
-    struct Ph { const float *w0, *ln_w, *ln_b, *w3; } pair[3];   // family 1: to_force, to_energy, to_confidence
+    struct Ph { const float *w0, *ln_w, *ln_b, *w3; } pair[3], dist;   // family 1: to_force, to_energy, to_confidence; to_dist (w3 is [64][256])
     const float *ir0_w, *ir0_b, *ir2_w, *ir2_b, *ir4_w, *ir4_b;   // to_ires
     const float *t_W, *t_lin, *trs0, *trs_ln_w, *trs_ln_b, *trs4, *rots0, *rots_ln_w, *rots_ln_b, *rots4;
     int64_t total;
@@ -160,16 +161,16 @@ static void map_blob(const dfm_hparams *hp, const float *blob, BlobMap *w)
         else Lw.c1_w = Lw.c1_b = Lw.c2_w = nullptr;
         take(Lw.att_w, Hh); take(Lw.att_b, 1);
     }
-    const float *skip = nullptr;
-    if (hp->family == 1) {   // to_energy, to_force, to_dist (training-only, skipped), to_confidence on cat[h_r, h_l, D]
+    if (hp->family == 1) {   // to_energy, to_force, to_dist, to_confidence on cat[h_r, h_l, D]
         auto head = [&](BlobMap::Ph &h) { take(h.w0, Hh * (2 * Hh + 1)); take(h.ln_w, Hh); take(h.ln_b, Hh); take(h.w3, Hh); };
         head(w->pair[1]); head(w->pair[0]);
-        take(skip, Hh * (2 * Hh + 1)); take(skip, Hh); take(skip, Hh); take(skip, 64 * Hh);
+        take(w->dist.w0, Hh * (2 * Hh + 1)); take(w->dist.ln_w, Hh); take(w->dist.ln_b, Hh); take(w->dist.w3, 64 * Hh);
         head(w->pair[2]);
         w->en0_w = w->en_ln_w = w->en_ln_b = w->en3_w = nullptr;
     } else {
         take(w->en0_w, Hh * 2 * Hh); take(w->en_ln_w, Hh); take(w->en_ln_b, Hh); take(w->en3_w, Hh);
         for (auto &h : w->pair) h.w0 = h.ln_w = h.ln_b = h.w3 = nullptr;
+        w->dist.w0 = w->dist.ln_w = w->dist.ln_b = w->dist.w3 = nullptr;
     }
     take(w->ir0_w, 2 * Hh * Hh); take(w->ir0_b, 2 * Hh); take(w->ir2_w, 4 * Hh * Hh); take(w->ir2_b, 2 * Hh);   // to_ires.{0,2}
     take(w->ir4_w, 2 * Hh); take(w->ir4_b, 1);                                                                  // to_ires.4
@@ -426,6 +427,20 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
             up(&D.wab, wab.data(), wab.size());
             split_bf16(wab.data(), 2 * H, H, hi, lo); up16(&D.wab_hi, hi); up16(&D.wab_lo, lo);
             up(&D.w_d, wd.data(), H); up(&D.ln_w, src.ln_w, H); up(&D.ln_b, src.ln_b, H); up(&D.w3, src.w3, H);
+        }
+        if (ok) {      // to_dist: fp32 projection only (evaluated on request, DFM_F_DIST), Linear(256 -> 64) stored transposed
+            const auto &src = w.dist;
+            std::vector<float> wab((size_t)2 * H * H), wd(H), w3t((size_t)H * 64);
+            for (int c = 0; c < H; ++c) {
+                std::memcpy(&wab[(size_t)c * H], src.w0 + (size_t)c * Kp, H * sizeof(float));
+                std::memcpy(&wab[(size_t)(H + c) * H], src.w0 + (size_t)c * Kp + H, H * sizeof(float));
+                wd[c] = src.w0[(size_t)c * Kp + 2 * H];
+                for (int o = 0; o < 64; ++o) w3t[(size_t)c * 64 + o] = src.w3[(size_t)o * H + c];
+            }
+            PairHeadDev &D = m->dist;
+            std::memset(&D, 0, sizeof(D));
+            up(&D.wab, wab.data(), wab.size()); up(&D.w_d, wd.data(), H); up(&D.ln_w, src.ln_w, H); up(&D.ln_b, src.ln_b, H);
+            up(&D.w3, w3t.data(), w3t.size());
         }
     } else {
         up(&m->en0_w, w.en0_w, (size_t)H * 2 * H);
@@ -856,6 +871,8 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     if (B < 1) return fail(DFM_E_INVALID, "B must be >= 1");
     const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_MFMA16) || f16, want_energy = flags & DFM_F_ENERGY;
     const bool want_ires = (flags & DFM_F_IRES) && out->ires;
+    const bool want_dist = (flags & DFM_F_DIST) && out->dist_logits;
+    if (want_dist && cx->m->hp.family != 1) return fail(DFM_E_INVALID, "DFM_F_DIST needs a family-1 model (EGNN_Net has to_dist, Score_Net does not)");
     DEVICE_SCOPE(cx->device);
     int rc = ensure_workspace(cx, B, bf16);
     if (rc) return rc;
@@ -906,6 +923,20 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
         if (e == hipSuccess) e = launch_gemm_f32(g, s);
         if (e != hipSuccess) rc = fail(DFM_E_HIP, hipGetErrorString(e));
     }
+    float *dist_dev = nullptr;
+    if (rc == DFM_OK && want_dist) {
+        // dist_logits (egnn_net.py:447): project every node through the stacked halves of to_dist.0 (reusing the A / Bm buffers),
+        // then the pair kernel; fp32 in every engine
+        const dfm_model *m = cx->m;
+        hipError_t e = tmp.alloc(&dist_dev, (size_t)B * cx->R * L * 64);
+        GemmArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.A0 = W.h; g.lda = H; g.K = H; g.W = m->dist.wab; g.ldw = H; g.M = (int)(B * N); g.Nout = 2 * H; g.epi = 2; g.C = W.A; g.ldc = H;
+        g.C2 = W.Bm;
+        if (e == hipSuccess) e = launch_gemm_f32(g, s);
+        if (e == hipSuccess) e = launch_pair_dist(W.A, W.Bm, W.ca4, B, cx->R, (int)L, m->dist.w_d, m->dist.ln_w, m->dist.ln_b, m->dist.w3, dist_dev, s);
+        if (e != hipSuccess) rc = fail(DFM_E_HIP, hipGetErrorString(e));
+    }
     if (rc == DFM_OK) {
         std::vector<float> sc((size_t)B * 8);
         hipError_t e = hipEventRecord(cx->ev_total[1], s);
@@ -916,6 +947,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
         if (e == hipSuccess && out->edges) e = hipMemcpyAsync(out->edges, W.edges, (size_t)B * N * K * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && out->edge_codes) e = hipMemcpyAsync(out->edge_codes, W.codes, (size_t)B * N * K * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && want_ires) e = hipMemcpyAsync(out->ires, ir3, (size_t)B * N * 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && want_dist) e = hipMemcpyAsync(out->dist_logits, dist_dev, (size_t)B * cx->R * L * 64 * 4, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && out->confidence) {
             if (cx->m->hp.family == 1 && want_energy) e = hipMemcpyAsync(out->confidence, W.conf, (size_t)B * 4, hipMemcpyDeviceToHost, s);
             else std::memset(out->confidence, 0, (size_t)B * 4);

@@ -195,6 +195,9 @@ struct PairArgs {
     int32_t *clash_part;     // [B][ceil(R/64)*4]
 };
 hipError_t launch_pair_head(const PairArgs &a, hipStream_t s);
+// dist_logits [B][R][L][64] = Linear(256 -> 64)(SiLU(LayerNorm(P_r + Q_l + w_d D)))  (egnn_net.py:347-352,:447); exact fp32
+hipError_t launch_pair_dist(const float *P, const float *Q, const float4 *ca4, int B, int R, int L, const float *w_d, const float *ln_w,
+                            const float *ln_b, const float *w3t /*[256][64]*/, float *out, hipStream_t s);
 hipError_t launch_pair_finish(const float *fpart, int B, int R, int L, float inv_pool, float *fvec, const float *cpart,
                               float *conf, hipStream_t s);
 

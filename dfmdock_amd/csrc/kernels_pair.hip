@@ -169,6 +169,50 @@ __global__ __launch_bounds__(256) void k_pair_finish(const float *__restrict__ f
     }
 }
 
+// dist_logits (egnn_net.py:347-352,:447): the one pair head with a 64-wide output.  A training-loss input (DFMDock.py:196-215) that no
+// sampler reads, evaluated only on request (DFM_F_DIST) and in exact fp32 in every engine: one workgroup per (trajectory, receptor
+// residue), thread = channel, the ligand residues in a loop; LayerNorm as two exact block reductions, then the 256 -> 64 projection
+// as four 64-channel partial dots per output (w3 transposed on the host: lanes read consecutive outputs).
+__global__ __launch_bounds__(256) void k_pair_dist(const float *__restrict__ P, const float *__restrict__ Q, const float4 *__restrict__ ca4,
+                                                   int R, int L, const float *__restrict__ w_d, const float *__restrict__ ln_w,
+                                                   const float *__restrict__ ln_b, const float *__restrict__ w3t, float *__restrict__ out)
+{
+    __shared__ float y[H], red[4], part[4][64];
+    const int r = blockIdx.x, b = blockIdx.y, N = R + L, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const float pc = P[((size_t)b * N + r) * H + c], wd = w_d[c], lw = ln_w[c], lb = ln_b[c];
+    const float4 xr = ca4[(size_t)b * N + r];
+    for (int l = 0; l < L; ++l) {
+        const float4 xl = ca4[(size_t)b * N + R + l];
+        const float dx = xr.x - xl.x, dy = xr.y - xl.y, dz = xr.z - xl.z;
+        const float D = sqrtf((dx * dx + dy * dy) + dz * dz);
+        const float z = (pc + Q[((size_t)b * N + R + l) * H + c]) + wd * D;
+        float s = wave_sum(z);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / H);
+        __syncthreads();
+        const float d = z - mean;
+        s = wave_sum(d * d);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        const float var = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / H);
+        y[c] = silu_exact(d / sqrtf(var + 1e-5f) * lw + lb);
+        __syncthreads();
+        float acc = 0.f;
+        for (int k = 0; k < 64; ++k) acc = fmaf(y[wave * 64 + k], w3t[(size_t)(wave * 64 + k) * 64 + lane], acc);
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (c < 64) out[(((size_t)b * R + r) * L + l) * 64 + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    }
+}
+
+hipError_t launch_pair_dist(const float *P, const float *Q, const float4 *ca4, int B, int R, int L, const float *w_d, const float *ln_w,
+                            const float *ln_b, const float *w3t, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pair_dist, dim3(R, B), dim3(256), 0, s, P, Q, ca4, R, L, w_d, ln_w, ln_b, w3t, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_pair_head(const PairArgs &a, hipStream_t s)
 {
     static std::atomic<bool> done0[MAX_DEVICES], done1[MAX_DEVICES];

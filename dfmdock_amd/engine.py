@@ -115,7 +115,7 @@ class Complex:
         L.check(L.lib().dfm_complex_set_homomer(self._h, int(bool(flag))), "dfm_complex_set_homomer")
 
     def score(self, lig_pos, t, edges=None, seed=0, bf16=False, energy=True, debug=False, profile=False, f16=False,
-              ires=False, return_edges=False, bf16_ops=False):
+              ires=False, return_edges=False, bf16_ops=False, dist=False):
         """B score evaluations.  lig_pos [B,L,3,3] (or [L,3,3]), t [B] (or scalar)."""
         lig_pos = _f32(lig_pos)
         if lig_pos.ndim == 3:
@@ -133,6 +133,9 @@ class Complex:
         if ires:
             o["ires"] = np.zeros((B, N), np.float32)
             out.ires = _p(o["ires"])
+        if dist:      # family 1 only: dist_logits [B,R,L,64] (egnn_net.py:447)
+            o["dist_logits"] = np.zeros((B, self.R, Lg, 64), np.float32)
+            out.dist_logits = _p(o["dist_logits"])
         if return_edges and not debug:      # the graph each evaluation used, without the [B,N,H] debug taps
             o["edges"] = np.zeros((B, N, K), np.int32)
             out.edges = _p(o["edges"], L.I32P)
@@ -149,7 +152,8 @@ class Complex:
             if e.shape != (B, N, K):
                 raise ValueError(f"edges must be [B,N,K] = {(B, N, K)}, got {e.shape}")
         flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_ENERGY if energy else 0) | (L.DFM_F_PROFILE if profile else 0) | \
-                (L.DFM_F_F16 if f16 else 0) | (L.DFM_F_IRES if ires else 0) | (L.DFM_F_BF16_OPS if bf16_ops else 0)
+                (L.DFM_F_F16 if f16 else 0) | (L.DFM_F_IRES if ires else 0) | (L.DFM_F_BF16_OPS if bf16_ops else 0) | \
+                (L.DFM_F_DIST if dist else 0)
         rc = L.lib().dfm_score(self._h, B, _p(lig_pos), _p(t), _p(e, L.I32P), int(seed), flags, C.byref(out))
         L.check(rc, "dfm_score")
         if debug:

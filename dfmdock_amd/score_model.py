@@ -172,7 +172,7 @@ class Score_Model:
             raise ValueError("batch['t'] must hold one time value (the reference runs batch_size=1)")
         self._calls += 1
         r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, bf16=self.precision == "bf16",
-                     f16=self.precision == "f16", energy=True, ires=self.with_ires)
+                     f16=self.precision == "f16", energy=True, ires=self.with_ires, dist=getattr(self, "with_dist", False))
         out = {"tr_score": torch.from_numpy(r["tr_score"]), "rot_score": torch.from_numpy(r["rot_score"]),
                "energy": torch.tensor(float(r["energy"][0]), dtype=torch.float32), "f": torch.from_numpy(r["f"][0]),
                "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64)}
@@ -191,19 +191,20 @@ class DFMDock(Score_Model):
     ``move_to_lig_center`` + ``EGNN_Net(batch, predict=True)`` (DFMDock.py:68-75, egnn_net.py:408-505).
 
     Output keys follow egnn_net.py:486-495: tr_score [1,3], rot_score [1,3], energy [], f [L,3], num_clashes [],
-    confidence_logits [], ires_logits [N,1].  ``dist_logits`` [R,L,64] feeds a training loss only (DFMDock.py:196-215) and
-    is not evaluated.  With a 67-channel checkpoint (configs/model/DFMDock.yaml:5) ``batch['is_homomer']`` selects the
+    confidence_logits [], ires_logits [N,1]; ``dist_logits`` [R,L,64] - a training-loss input (DFMDock.py:196-215) - with
+    ``with_dist=True`` (off by default: 64 floats per residue pair).  With a 67-channel checkpoint (configs/model/DFMDock.yaml:5) ``batch['is_homomer']`` selects the
     value of the sym channel (default False).  The sampler of this family rotates about the all-backbone-atom centroids
     (src/inference.py:220-254); the engine does the same for ``family=1`` models.  The diffusers and the Euler-Maruyama sampler are shared with
     Score_Model, so ``Euler_Maruyama_sampler(model, batch)`` / ``sample_trajectories`` accept this class too.
     """
 
     def __init__(self, weights, hp: HParams | None = None, precision: str = "bf16", device_index: int = 0, seed: int = 0,
-                 with_ires: bool = True):
+                 with_ires: bool = True, with_dist: bool = False):
         hp = hp or HParams(family=1, mask_dist=20.0)
         if hp.family != 1:
             raise ValueError("DFMDock needs HParams(family=1)")
         super().__init__(weights, hp=hp, precision=precision, device_index=device_index, seed=seed, with_ires=with_ires)
+        self.with_dist = bool(with_dist)      # dist_logits [R,L,64] (egnn_net.py:447,:500): 64 floats per residue pair, off by default
 
     _ires_key = "ires_logits"       # egnn_net.py:486-495
 
@@ -211,6 +212,8 @@ class DFMDock(Score_Model):
         import torch
         out, r = self._score_dict(batch)
         out["confidence_logits"] = torch.tensor(float(r["confidence"][0]), dtype=torch.float32)
+        if self.with_dist:
+            out["dist_logits"] = torch.from_numpy(r["dist_logits"][0].copy())
         return out
 
     __call__ = forward

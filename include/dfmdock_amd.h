@@ -90,6 +90,8 @@ enum {
     DFM_F_STEP_ENERGY = 1u << 6,     /* dfm_sample: evaluate the energy head on every step (traces) */
     DFM_F_F16 = 1u << 7,             /* like DFM_F_MFMA16 but A_i = Wa h_i + b1 stays fp32 (one more load per chunk)     */
     DFM_F_IRES = 1u << 8,            /* dfm_score: also evaluate the interface-residue head (score_net_mlsb.py:383) */
+    DFM_F_DIST = 1u << 10,           /* dfm_score, family 1: also evaluate dist_logits = to_dist(cat[h_r, h_l, D]) over all R x L pairs
+                                        (egnn_net.py:347-352,:447; a training-loss input, never read by a sampler); fp32 in every engine */
     DFM_F_BF16_OPS = 1u << 9         /* with DFM_F_MFMA16: bf16 instead of fp16 MFMA operands in layers 0..depth-2 (the r02
                                         plan; ~3 % faster).  OUTSIDE SURVEY 8(d)'s 1e-2 gate: measured up to 1.5e-2 on f /
                                         tr_score / rot_score over four weight draws (profiles/r03_tol_report.txt) - an opt-in
@@ -111,6 +113,7 @@ typedef struct {
     float *confidence;    /* [B]      family 1 + DFM_F_ENERGY: confidence_logits (egnn_net.py:444); may be NULL */
     float *ires;          /* [B,N]    needs DFM_F_IRES: to_ires(node_out) (score_net_mlsb.py:297-303,:383; family 1:
                                       ires_logits, egnn_net.py:362-368,:462); may be NULL                     */
+    float *dist_logits;   /* [B,R,L,64] needs DFM_F_DIST and a family-1 model (egnn_net.py:447,:500); may be NULL  */
 } dfm_score_out;
 
 /* Injected randomness for parity tests (every pointer may be NULL = draw natively with Philox) */

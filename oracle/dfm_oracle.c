@@ -35,6 +35,7 @@ typedef struct {
     const float *en0_w, *en_ln_w, *en_ln_b, *en3_w;
     const float *fo0_w, *fo_ln_w, *fo_ln_b, *fo3_w;    /* family 1: to_force       */
     const float *cf0_w, *cf_ln_w, *cf_ln_b, *cf3_w;    /* family 1: to_confidence  */
+    const float *di0_w, *di_ln_w, *di_ln_b, *di3_w;    /* family 1: to_dist (Linear(256 -> 64) last) */
     const float *ir0_w, *ir0_b, *ir2_w, *ir2_b, *ir4_w, *ir4_b;
     const float *t_W, *t_lin;
     const float *trs0_w, *trs_ln_w, *trs_ln_b, *trs4_w;
@@ -65,16 +66,15 @@ static void map_weights(const ora_hparams *hp, const float *blob, net_w *w)
         TAKE(L->att_w, H); TAKE(L->att_b, 1);
     }
     if (hp->family == 1) {   /* egnn_net.py:329-360: to_energy, to_force, to_dist, to_confidence on cat[h_r, h_l, D] */
-        const float *skip;
         TAKE(w->en0_w, (int64_t)H * (2 * H + 1)); TAKE(w->en_ln_w, H); TAKE(w->en_ln_b, H); TAKE(w->en3_w, H);
         TAKE(w->fo0_w, (int64_t)H * (2 * H + 1)); TAKE(w->fo_ln_w, H); TAKE(w->fo_ln_b, H); TAKE(w->fo3_w, H);
-        TAKE(skip, (int64_t)H * (2 * H + 1)); TAKE(skip, H); TAKE(skip, H); TAKE(skip, (int64_t)64 * H);   /* to_dist */
+        TAKE(w->di0_w, (int64_t)H * (2 * H + 1)); TAKE(w->di_ln_w, H); TAKE(w->di_ln_b, H); TAKE(w->di3_w, (int64_t)64 * H);
         TAKE(w->cf0_w, (int64_t)H * (2 * H + 1)); TAKE(w->cf_ln_w, H); TAKE(w->cf_ln_b, H); TAKE(w->cf3_w, H);
-        (void)skip;
     } else {
         TAKE(w->en0_w, (int64_t)H * 2 * H); TAKE(w->en_ln_w, H); TAKE(w->en_ln_b, H); TAKE(w->en3_w, H);
         w->fo0_w = w->fo_ln_w = w->fo_ln_b = w->fo3_w = NULL;
         w->cf0_w = w->cf_ln_w = w->cf_ln_b = w->cf3_w = NULL;
+        w->di0_w = w->di_ln_w = w->di_ln_b = w->di3_w = NULL;
     }
     TAKE(w->ir0_w, (int64_t)2 * H * H); TAKE(w->ir0_b, 2 * H);
     TAKE(w->ir2_w, (int64_t)4 * H * H); TAKE(w->ir2_b, 2 * H);
@@ -798,6 +798,33 @@ int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const floa
         }
         for (int q = 0; q < L * 3; ++q) fpair[q] = (float)(hp->agg_mean ? facc[q] / R : facc[q]);
         free(facc);
+        if (dbg && dbg->dist) {   /* egnn_net.py:447 dist_logits = to_dist(interaction): [R, L, 64] (a training-loss input, :196-215) */
+            float *Ad = (float *)malloc(sizeof(float) * (int64_t)R * H), *Bd = (float *)malloc(sizeof(float) * (int64_t)L * H);
+            linear(h, R, H, H, w.di0_w, Kp, NULL, H, Ad, H, 1);
+            linear(h + (int64_t)R * H, L, H, H, w.di0_w + H, Kp, NULL, H, Bd, H, 1);
+#pragma omp parallel
+            {
+                float *v = (float *)malloc(sizeof(float) * H);
+#pragma omp for schedule(static)
+                for (int r = 0; r < R; ++r)
+                    for (int q = 0; q < L; ++q) {
+                        const int j = R + q;
+                        const float dx = ca[r * 3] - ca[j * 3], dy = ca[r * 3 + 1] - ca[j * 3 + 1], dz = ca[r * 3 + 2] - ca[j * 3 + 2];
+                        const float D = sqrtf((dx * dx + dy * dy) + dz * dz);
+                        for (int c = 0; c < H; ++c)
+                            v[c] = (Ad[(int64_t)r * H + c] + Bd[(int64_t)q * H + c]) + w.di0_w[(int64_t)c * Kp + 2 * H] * D;
+                        layernorm(v, H, w.di_ln_w, w.di_ln_b);
+                        for (int c = 0; c < H; ++c) v[c] = siluf(v[c]);
+                        for (int o = 0; o < 64; ++o) {
+                            float acc = 0;
+                            for (int c = 0; c < H; ++c) acc += v[c] * w.di3_w[(int64_t)o * H + c];
+                            dbg->dist[((int64_t)r * L + q) * 64 + o] = acc;
+                        }
+                    }
+                free(v);
+            }
+            free(Ad); free(Bd);
+        }
         for (int q = 0; q < nh; ++q) { free(Ar[q]); free(Bl[q]); }
         if (want_energy) {
             out->energy = hp->agg_mean ? (float)((float)esum / (msum < 1.0 ? 1.0f : (float)msum)) : (float)esum;

@@ -46,6 +46,7 @@ typedef struct {
     int8_t *relpos;  /* [N,K]                                               */
     int32_t *edges;  /* [N,K] edge list actually used                       */
     float *ires;     /* [N]                                                 */
+    float *dist;     /* [R,L,64] family 1: dist_logits (egnn_net.py:447), or NULL */
 } ora_debug;
 
 typedef struct {

@@ -80,29 +80,51 @@ def forward_case(net, cx, lig_pos, t, seed):
         "confidence_logits": out["confidence_logits"].detach().numpy(),
         "ires_logits": out["ires_logits"].detach().numpy()[:, 0],
         "dist_logits_sample": out["dist_logits"].detach().numpy()[:4, :4].copy(),
+        "_dist_full": out["dist_logits"].detach().numpy().copy(),      # popped by the callers (only fwd2_dist.npz keeps it)
         "h_last": hs[-1].astype(np.float32), "h_first": hs[0].astype(np.float32),
         "centered_lig_ca": batch["lig_pos"][:, 1, :].detach().numpy().copy(),
     }
+
+
+def slim(r):
+    return {k: v for k, v in r.items() if not k.startswith("_")}
+
+
+def gen_dist(net):
+    """dist_logits = to_dist(interaction) [R, L, 64] (egnn_net.py:347-352,:447,:500): the whole tensor for the small synthetic
+    complex, every 8th receptor / ligand residue for 7CEI (87 x 127 x 64 floats would be 2.8 MB)."""
+    cx = make_complex(24, 16, seed=5)
+    g = dict(np.load(os.path.join(HERE, "fwd2_syn_24_16.npz")))
+    r = forward_case(net, cx, g["lig_pos"], float(g["t"]), seed=1)
+    assert (r["edges"] == g["edges"]).all()
+    d = load_db5_pt(os.path.join(mg.REF, "data/db5_test/7CEI.pt"))
+    cx7 = {"rec_x": np.concatenate([d["rec_esm"].astype(np.float16).astype(np.float32), d["rec_x"][:, 1280:]], 1),
+           "lig_x": np.concatenate([d["lig_esm"].astype(np.float16).astype(np.float32), d["lig_x"][:, 1280:]], 1),
+           "rec_pos": d["rec_pos"], "lig_pos": d["lig_pos"]}
+    g7 = dict(np.load(os.path.join(HERE, "fwd2_7CEI_p1.npz")))
+    r7 = forward_case(net, cx7, g7["lig_pos"], float(g7["t"]), seed=41)
+    assert (r7["edges"] == g7["edges"]).all(), "same seed as fwd2_7CEI_p1 -> same graph"
+    mg.save("fwd2_dist.npz", syn_24_16=r["_dist_full"], cei_p1_stride8=r7["_dist_full"][::8, ::8].copy())
 
 
 def main():
     net = build_net(0)
     rng = np.random.Generator(np.random.PCG64(29))
     cx = make_complex(24, 16, seed=5)
-    mg.save("fwd2_syn_24_16.npz", R=24, L=16, cx_seed=5, **forward_case(net, cx, cx["lig_pos"], 0.5, seed=1))
+    mg.save("fwd2_syn_24_16.npz", R=24, L=16, cx_seed=5, **slim(forward_case(net, cx, cx["lig_pos"], 0.5, seed=1)))
     cx = make_complex(9, 7, seed=6)
-    mg.save("fwd2_syn_9_7.npz", R=9, L=7, cx_seed=6, **forward_case(net, cx, cx["lig_pos"], 0.3, seed=1))
+    mg.save("fwd2_syn_9_7.npz", R=9, L=7, cx_seed=6, **slim(forward_case(net, cx, cx["lig_pos"], 0.3, seed=1)))
     cx = make_complex(64, 48, seed=7)
     for i, (t, rot, trs) in enumerate([(1.0, 40.0, 6.0), (0.49, 10.0, 2.0), (0.001, 0.0, 0.0)]):
         lp = mg.noised_pose(cx, rng, rot, trs)
-        mg.save(f"fwd2_syn_64_48_p{i}.npz", R=64, L=48, cx_seed=7, **forward_case(net, cx, lp, t, seed=10 + i))
+        mg.save(f"fwd2_syn_64_48_p{i}.npz", R=64, L=48, cx_seed=7, **slim(forward_case(net, cx, lp, t, seed=10 + i)))
     d = load_db5_pt(os.path.join(mg.REF, "data/db5_test/7CEI.pt"))
     cx = {"rec_x": np.concatenate([d["rec_esm"].astype(np.float16).astype(np.float32), d["rec_x"][:, 1280:]], 1),
           "lig_x": np.concatenate([d["lig_esm"].astype(np.float16).astype(np.float32), d["lig_x"][:, 1280:]], 1),
           "rec_pos": d["rec_pos"], "lig_pos": d["lig_pos"]}
     for i, (t, rot, trs) in enumerate([(0.001, 0.0, 0.0), (1.0, 60.0, 8.0), (0.3, 12.0, 2.5)]):
         lp = mg.noised_pose(cx, rng, rot, trs) if i else cx["lig_pos"]
-        mg.save(f"fwd2_7CEI_p{i}.npz", **forward_case(net, cx, lp, t, seed=40 + i))
+        mg.save(f"fwd2_7CEI_p{i}.npz", **slim(forward_case(net, cx, lp, t, seed=40 + i)))
     # DFMDock.modify_coords / move_to_lig_center (DFMDock.py:246-257): rotation about the ALL-ATOM centroid
     x = torch.from_numpy(rng.standard_normal((9, 3, 3)).astype(np.float32) * 10)
     rot, tr = torch.tensor([[0.2, -0.1, 0.4]]), torch.tensor([[1.0, -2.0, 0.5]])
@@ -116,8 +138,11 @@ def main():
     hp_sum = HParams(family=1, mask_dist=20.0, agg_mean=False)
     net_s = build_net(0, hp_sum)
     cx = make_complex(24, 16, seed=5)
-    mg.save("fwd2_sum_syn_24_16.npz", R=24, L=16, cx_seed=5, **forward_case(net_s, cx, cx["lig_pos"], 0.5, seed=1))
+    mg.save("fwd2_sum_syn_24_16.npz", R=24, L=16, cx_seed=5, **slim(forward_case(net_s, cx, cx["lig_pos"], 0.5, seed=1)))
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["dist"]:
+        gen_dist(build_net(0))
+    else:
+        main()

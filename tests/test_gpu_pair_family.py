@@ -130,3 +130,34 @@ def test_reference_shaped_dfmdock_api(blob_pair):
     assert abs(float(out["energy"]) - float(g["energy"])) < 0.2
     rec_pos, lig_pos, rot, tr, o2 = Euler_Maruyama_sampler(model, batch, num_steps=5, seed=3)
     assert tuple(lig_pos.shape) == (16, 3, 3) and torch.isfinite(lig_pos).all()
+
+
+def test_pair_family_dist_logits_vs_reference(blob_pair):
+    """DFM_F_DIST: dist_logits [R, L, 64] of DFMDock.forward (egnn_net.py:447,:500) against the reference's tensor - whole for the
+    synthetic complex, every 8th residue pair for 7CEI -, fp32 engine at 1e-4, 16-bit engines (fp32 head on their node features) at
+    1e-2; the adapter returns the key on request; a first-family model refuses the flag."""
+    import torch
+    from dfmdock_amd import engine
+    from dfmdock_amd.score_model import DFMDock
+    from dfmdock_amd.weights import make_random_weights, pack_blob
+    d = load_golden("fwd2_dist.npz")
+    for case, key, stride in (("fwd2_syn_24_16", "syn_24_16", 1), ("fwd2_7CEI_p1", "cei_p1_stride8", 8)):
+        g = load_golden(case + ".npz")
+        gx, cx = gpu_complex(case, blob_pair)
+        for prec, tol in (("fp32", 1e-4), ("bf16", 1e-2), ("f16", 1e-2)):
+            r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, dist=True, bf16=prec == "bf16", f16=prec == "f16")
+            got = r["dist_logits"][0][::stride, ::stride]
+            assert got.shape == d[key].shape and rel_inf(got, d[key]) < tol, (case, prec, rel_inf(got, d[key]))
+        rb = gx.score(np.stack([g["lig_pos"]] * 2), float(g["t"]), edges=np.stack([g["edges"]] * 2), dist=True)
+        np.testing.assert_array_equal(rb["dist_logits"][0], rb["dist_logits"][1])
+    g = load_golden("fwd2_syn_24_16.npz")
+    cx = complex_for("syn_24_16")
+    m = DFMDock(blob_pair, precision="fp32", with_dist=True)
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in cx.items()}
+    batch["t"] = torch.tensor([float(g["t"])])
+    out = m(batch)
+    assert out["dist_logits"].shape == (24, 16, 64) and "dist_logits" not in DFMDock(blob_pair, precision="fp32")(batch)
+    gx0 = engine.Complex(engine.Model(pack_blob(make_random_weights(0))), cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    with pytest.raises(ValueError):
+        gx0.score(cx["lig_pos"], 0.5, dist=True)
+    gx0.close()

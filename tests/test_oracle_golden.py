@@ -344,3 +344,14 @@ def test_sampler_rollout_on_other_weight_draws(family, draw):
         assert abs(float(r["energy"]) - float(g["final_energy"])) < 1e-3 * max(1.0, abs(float(g["final_energy"])))
         np.testing.assert_allclose(r["tr_update"], g["tr_update"], atol=2e-3)
         np.testing.assert_allclose(r["rot_update"], g["rot_update"], atol=2e-4)
+
+
+def test_pair_family_dist_logits_match_reference(blob_pair):
+    """dist_logits = to_dist(cat[h_r, h_l, D]) [R, L, 64] (egnn_net.py:347-352,:447,:500; tests/golden/make_golden_pair.py dist)."""
+    d = load_golden("fwd2_dist.npz")
+    for case, key, stride in (("fwd2_syn_24_16", "syn_24_16", 1), ("fwd2_7CEI_p1", "cei_p1_stride8", 8)):
+        g = load_golden(case + ".npz")
+        r = ora.Oracle(blob_pair, complex_for(case), pair_hparams()).score(g["lig_pos"], float(g["t"]), edges=g["edges"], dist=True)
+        got = r["dist_logits"][::stride, ::stride]
+        assert got.shape == d[key].shape and rel_inf(got, d[key]) < 1e-4, case
+        np.testing.assert_allclose(r["dist_logits"][:4, :4], g["dist_logits_sample"], atol=1e-4 * np.abs(d[key]).max())
