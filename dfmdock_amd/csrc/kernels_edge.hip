@@ -890,111 +890,137 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_coord(EdgeKArgs p)
     onef.u = make_uint4(h == 0 ? (F16 ? 0x3c003c00u : 0x3f803f80u) : 0u, 0u, 0u, 0u);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    for (unsigned tt = (unsigned)slot * EDGE_WAVES + wave; tt < ntask; tt += tstride) {
-        int b, i;
-        if (!task_node(tt, b, i)) continue;
+    // The walk over (node, tile) runs ahead on the memory side: the tile is computed in two halves of 128 columns (accumulators 64
+    // instead of 128; its A fragments stay in registers for both), and in the SECOND half every k-step's fragment register is
+    // re-loaded with the same k-step of the wave's NEXT tile as soon as its last MFMA has been issued - so the HBM latency that
+    // bounded this kernel in r02 (0.83 ms for 2.6 GB: 3.2 TB/s; every wave alternated between a load phase and a compute phase) lies
+    // under the rest of the half, the epilogue and the next tile's first MFMAs, with no second register set.
+    auto tile_ptr = [&](int tb, int ti, int tm) {
+        return reinterpret_cast<const uint4 *>(p.mbuf + (((size_t)tb * p.L + (ti - p.R)) * 2 + tm) * (32 * H)) + lane;
+    };
+    auto load_tile = [&](const uint4 *Mt, uint4 (&a)[16]) {      // read once: non-temporal, like the stores that wrote them
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const u32x4v v = DFM_EDGE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(Mt + kk * 64))
+                                         : *reinterpret_cast<const u32x4v *>(Mt + kk * 64);
+            a[kk] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+    };
+    unsigned tt = (unsigned)slot * EDGE_WAVES + wave;
+    int b = 0, i = 0, mt = 0;
+    while (tt < ntask && !task_node(tt, b, i)) tt += tstride;
+    if (tt >= ntask) return;
+    float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // sum_s cdiff * w of the open node
+    bool more = true;
+    uint4 cur[16];
+    // one tile from `cur`, which leaves holding the wave's next tile (if any)
+    auto tile_step = [&]() {
+        unsigned ntt = tt;
+        int nb_ = b, ni = i, nmt = mt + 1;
+        bool have_next = true;
+        if (nmt == ntile) {
+            nmt = 0; ntt = tt + tstride;
+            while (ntt < ntask && !task_node(ntt, nb_, ni)) ntt += tstride;
+            have_next = ntt < ntask;
+        }
+        const uint4 *Mn = tile_ptr(have_next ? nb_ : b, have_next ? ni : i, have_next ? nmt : mt);      // (last tile: re-reads itself, unused)
         const size_t node = (size_t)b * p.N + i;
         const size_t ebase = node * K;
-        float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // sum_s cdiff * w
-
-        for (int mt = 0; mt < ntile; ++mt) {
-            f32x16 acc[8];
-            float dv[8];        // dot vector of the epilogue
-            uint32_t bp[8];     // packed (hi, lo) bias of this lane's column per n-tile (biasp is [8][64]: lanes 32..63 hold 0)
-            // the stored messages of this tile are already in A-fragment order (see the store in k_edge_msg): one contiguous
-            // 1 KiB per wave instruction; all sixteen k-steps of the tile are requested up front (HBM latency, not
-            // MFMA rate, bounds this kernel); rows >= K were stored as zeros
-            const uint4 *Mt = reinterpret_cast<const uint4 *>(p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H)) + lane;
-            uint4 a16[16];
+        const int lrow = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;    // one lane per row (16 rows per half, lanes l31 < 16)
+        const float4 c_xi = p.ca4[node];
+        const int c_j = p.edges[ebase + (lrow < K ? lrow : 0)];
+        float4 c_xj = c_xi;
+        f2 part2[8];
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {      // read once: non-temporal, like the stores that wrote them
-                const u32x4v v = DFM_EDGE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(Mt + kk * 64))
-                                             : *reinterpret_cast<const u32x4v *>(Mt + kk * 64);
-                a16[kk] = make_uint4(v.x, v.y, v.z, v.w);
-            }
-            // everything the epilogue needs from memory goes out now too, so that nothing after the MFMAs waits on a load:
-            // bias / dot vector, and the neighbour of this lane's row (edge index first, its coordinates below)
+        for (int q = 0; q < 8; ++q) part2[q] = (f2){0.f, 0.f};
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                dv[nt] = dot_v[nt * 32 + l31];
-                bp[nt] = p.biasp[nt * 64 + lane];
+        for (int hf = 0; hf < 2; ++hf) {
+            f32x16 acc[4];
+            float dv[4];        // dot vector of the epilogue
+            uint32_t bp[4];     // packed (hi, lo) bias of this lane's column per n-tile (biasp is [8][64]: lanes 32..63 hold 0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dv[j] = dot_v[(hf * 4 + j) * 32 + l31];
+                bp[j] = p.biasp[(hf * 4 + j) * 64 + lane];
             }
-            const int lrow = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;    // one lane per row (16 rows per half, lanes l31 < 16)
-            const float4 c_xi = p.ca4[node];
-            const int c_j = p.edges[ebase + (lrow < K ? lrow : 0)];
-            float4 c_xj = c_xi;
             constexpr int CDEPTH = 4;      // weight-fragment LDS reads run three ahead in a static register ring
-            const uint4 *wq = Wf + lane;
+            const uint4 *wq = Wf + lane + hf * 4 * 64;      // fragment (k-step kk, n-tile hf*4 + j) sits at (kk * 8 + hf * 4 + j) * 64
             Frag bq[CDEPTH];
 #pragma unroll
-            for (int d = 0; d < CDEPTH - 1; ++d) bq[d].u = wq[d * 64];
+            for (int d = 0; d < CDEPTH - 1; ++d) bq[d].u = wq[((d >> 2) * 8 + (d & 3)) * 64];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < 2; ++g) {
 #pragma unroll
                 for (int mm = 0; mm < 32; ++mm) {
-                    const int m = g * 32 + mm;
-                    if (m + CDEPTH - 1 < 128) bq[(m + CDEPTH - 1) % CDEPTH].u = wq[(m + CDEPTH - 1) * 64];
+                    const int m = g * 32 + mm, mn = m + CDEPTH - 1;      // m = kk * 4 + j
+                    if (mn < 64) bq[mn % CDEPTH].u = wq[((mn >> 2) * 8 + (mn & 3)) * 64];
                     Frag af;
-                    af.u = a16[m >> 3];
-                    if (m < 8) acc[m] = mfma16<F16>(af, bq[m % CDEPTH], zero16);
-                    else acc[m & 7] = mfma16<F16>(af, bq[m % CDEPTH], acc[m & 7]);
+                    af.u = cur[m >> 2];
+                    if (m < 4) acc[m] = mfma16<F16>(af, bq[m % CDEPTH], zero16);
+                    else acc[m & 3] = mfma16<F16>(af, bq[m % CDEPTH], acc[m & 3]);
+                    if (hf == 1 && (m & 3) == 3) {      // k-step m >> 2 of this tile is done: its register takes the next tile's
+                        const u32x4v v = DFM_EDGE_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(Mn + (m >> 2) * 64))
+                                                     : *reinterpret_cast<const u32x4v *>(Mn + (m >> 2) * 64);
+                        cur[m >> 2] = make_uint4(v.x, v.y, v.z, v.w);
+                    }
                 }
-                if (g == 0) c_xj = p.ca4[(size_t)b * p.N + c_j];     // the edge index has landed under the first 32 MFMAs
+                if (hf == 0 && g == 0) c_xj = p.ca4[(size_t)b * p.N + c_j];     // the edge index has landed under the first 32 MFMAs
                 __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next group's reads (spills)
             }
             // bias k-step: acc += 1 * hi + 1 * lo (the accumulators were opened with C = 0)
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
+            for (int j = 0; j < 4; ++j) {
                 Frag bb;
-                bb.u = make_uint4(bp[nt], 0u, 0u, 0u);
-                acc[nt] = mfma16<F16>(onef, bb, acc[nt]);
+                bb.u = make_uint4(bp[j], 0u, 0u, 0u);
+                acc[j] = mfma16<F16>(onef, bb, acc[j]);
             }
-
-            // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r): w = sum_c silu(.) * wc2
-            float part[16];
-            {
-                f2 part2[8];
+            // epilogue of the half: lane owns columns (hf*4 + j)*32 + l31, rows rowof(r): w += sum_c silu(.) * wc2
 #pragma unroll
-                for (int q = 0; q < 8; ++q) part2[q] = (f2){0.f, 0.f};
+            for (int j = 0; j < 4; ++j) {
+                const f2 vv = {dv[j], dv[j]};
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    const f2 vv = {dv[nt], dv[nt]};
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const f2 m = silu2s((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
-                        part2[q] = m * vv + part2[q];
-                    }
+                for (int q = 0; q < 8; ++q) {
+                    const f2 m = silu2s((f2){acc[j][2 * q], acc[j][2 * q + 1]});
+                    part2[q] = m * vv + part2[q];
                 }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { part[2 * q] = part2[q].x; part[2 * q + 1] = part2[q].y; }
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part[r] = half_sum_dpp(part[r]);   // all 32 lanes of the half hold the row sum
-            // coord_mlp: w = clamp(sum_c silu(.) * wc2, +-2); x_i += mean_s (x_i - x_j)/(|x_i - x_j| + 1) * w
-            // one lane per row (lane l31 < 16 takes register row r = l31), so the 32 edge-index / coordinate loads of a tile
-            // are issued together instead of as a 16-long dependent chain in one lane
-            float w = part[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) w = l31 == r ? part[r] : w;
-            if (l31 < 16 && lrow < K) {
-                const float4 xi = c_xi, xj = c_xj;
-                w = fminf(fmaxf(w, -2.0f), 2.0f);
-                const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-                const float nrm = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f) + 1.0f;
-                cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;
-            }
-        }   // mt
-
-        cacc0 = wave_sum(cacc0); cacc1 = wave_sum(cacc1); cacc2 = wave_sum(cacc2);
-        if (lane == 0) {
-            const float4 xi = p.ca4[node];
-            const float inv = 1.0f / (float)(K > 1 ? K : 1);
-            float *fo = p.fout + ((size_t)b * p.L + (i - p.R)) * 3;
-            fo[0] = (xi.x + cacc0 * inv) - xi.x;
-            fo[1] = (xi.y + cacc1 * inv) - xi.y;
-            fo[2] = (xi.z + cacc2 * inv) - xi.z;
+            __builtin_amdgcn_sched_barrier(0);      // the halves in sequence: interleaved they would hold both accumulator sets
         }
-    }
+        float part[16];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { part[2 * q] = part2[q].x; part[2 * q + 1] = part2[q].y; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] = half_sum_dpp(part[r]);   // all 32 lanes of the half hold the row sum
+        // coord_mlp: w = clamp(sum_c silu(.) * wc2, +-2); x_i += mean_s (x_i - x_j)/(|x_i - x_j| + 1) * w
+        // one lane per row (lane l31 < 16 takes register row r = l31), so the 32 edge-index / coordinate loads of a tile
+        // are issued together instead of as a 16-long dependent chain in one lane
+        float w = part[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) w = l31 == r ? part[r] : w;
+        if (l31 < 16 && lrow < K) {
+            const float4 xi = c_xi, xj = c_xj;
+            w = fminf(fmaxf(w, -2.0f), 2.0f);
+            const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+            const float nrm = sqrtf(dx * dx + dy * dy + dz * dz + 1e-8f) + 1.0f;
+            cacc0 += dx / nrm * w; cacc1 += dy / nrm * w; cacc2 += dz / nrm * w;
+        }
+        if (mt == ntile - 1) {      // the node is complete
+            const float s0 = wave_sum(cacc0), s1 = wave_sum(cacc1), s2 = wave_sum(cacc2);
+            if (lane == 0) {
+                const float4 xi = c_xi;
+                const float inv = 1.0f / (float)(K > 1 ? K : 1);
+                float *fo = p.fout + ((size_t)b * p.L + (i - p.R)) * 3;
+                fo[0] = (xi.x + s0 * inv) - xi.x;
+                fo[1] = (xi.y + s1 * inv) - xi.y;
+                fo[2] = (xi.z + s2 * inv) - xi.z;
+            }
+            cacc0 = cacc1 = cacc2 = 0.f;
+        }
+        tt = ntt; b = nb_; i = ni; mt = nmt;
+        more = have_next;
+    };
+    load_tile(tile_ptr(b, i, 0), cur);
+    while (more) tile_step();
 }
 
 // -------------------------------------------------------------------------------------------------
