@@ -546,7 +546,10 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
 #ifdef DFM_EDGE_DENSE_UB
         if constexpr (AW16) a1 = bload16f_stream(rs_a, c4 * 16 + ((i + 1 < p.N) ? H * 2 : 0), c * 64);      // the next node's row
 #endif
-        if constexpr (AW16) a0 = bload16f_stream(rs_a, c4 * 16, c * 64);
+#ifndef DFM_EDGE_A_NT      // 1: the A_i row carries the non-temporal hint like the single-pass streams; 0 (shipped): cached - the node's second
+#define DFM_EDGE_A_NT 0     // tile and the other half of each 128-byte line re-read it: 2.187 vs 2.221 ms per launch, same box
+#endif
+        if constexpr (AW16) a0 = DFM_EDGE_A_NT ? bload16f_stream(rs_a, c4 * 16, c * 64) : bload16f(rs_a, c4 * 16, c * 64);
         else { a0 = bload16f_stream(rs_a, oc4, c * 128); a1 = bload16f_stream(rs_a, oc4, c * 128 + 16); }
         w0 = bload16f(rs_w, oc4, c * 128); w1 = bload16f(rs_w, oc4, c * 128 + 16);
     };

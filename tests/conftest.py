@@ -23,6 +23,19 @@ def pytest_report_header(config):
         return f"dfmdock_amd engine: unavailable ({e})"
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_threads():
+    """The oracle's OpenMP loops stop scaling well before a 128-core host is full (bench.py cpu_baseline: 0.20 trajectories/s at 32
+    threads, 0.06 at 128): the checker runs on at most 32 threads."""
+    try:
+        from oracle import oracle as ora
+        L = ora.lib()
+        L.ora_set_num_threads(min(32, int(L.ora_num_threads())))
+    except Exception:
+        pass
+    yield
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 
