@@ -152,8 +152,7 @@ hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s)
 // (gn_den := w/den, gn_shift := b - w*shift/den per graph and channel, see k_gn_stats fold=1).
 // Needs K % 32 == 0, Nout % 256 == 0.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 gf16x8 __attribute__((ext_vector_type(8)));
-union FragB { uint4 u; bf16x8 b; gf16x8 f; };
+union FragB { uint4 u; bf16x8 b; };
 constexpr int SN = 256, SK = 32, SLD = 40;   // output columns per workgroup; K per stage; LDS row stride in bf16
 
 struct GemmSplitArgs {
@@ -178,15 +177,15 @@ __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
 // HALF = 1: epilogue 2 with 16-bit outputs only (Cb and C2b set, no fp32 C2): the [Wa|Wb] projection of the 16-bit engine
 template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmSplitArgs sa)
 {
-    constexpr int MT = 1, W16 = 0;
-    constexpr int SM = 64 * MT, WN = 4 / MT, NJ = 8 / WN;      // rows; waves along N; 32-column tiles per wave
+    constexpr int SM = 64, WN = 4, NJ = 2;      // rows; waves along N; 32-column tiles per wave
     const GemmArgs &a = sa.g;
     // operand tiles; the epilogue reuses the space as 4 x 9216 B of transposition buffers
-    constexpr int LDS_U16 = W16 ? ((2 * SM + SN) * SLD > 18432 ? (2 * SM + SN) * SLD : 18432) : (2 * SM + 2 * SN) * SLD;
+    constexpr int LDS_U16 = (2 * SM + 2 * SN) * SLD;
     __shared__ __attribute__((aligned(16))) uint16_t lds[LDS_U16];
     uint16_t *Ah = lds, *Al = lds + SM * SLD, *Wh = lds + 2 * SM * SLD, *Wl = lds + (2 * SM + SN) * SLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31;
+    constexpr int wm = 0;
+    const int wn = wave, l31 = lane & 31;
     // row tile: plain 64/128-row blocks of the [M] rows, or - when the GraphNorm column sums are wanted - blocks aligned to
     // the trajectory (rows_per_graph rows each, last block partial): every block then belongs to one trajectory and the
     // summation order is the same for every trajectory, whatever its position in the batch (batched == single, bitwise)
@@ -195,7 +194,7 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
     // read of the 64 x K activation tile hits L2 instead of HBM
     // (A persistent grid - three workgroups per CU walking the tiles, so that a tile's store burst drains under the next tile's K
     // loop - costs 68 spilled registers at this kernel's 168-register budget: 4x slower.)
-    __shared__ __attribute__((aligned(16))) float gn_s[MT == 1 ? 2 * H : 4];
+    __shared__ __attribute__((aligned(16))) float gn_s[2 * H];
     const int vb = blockIdx.x;
     int bx = vb, by = blockIdx.y;
     if (gridDim.y == 1 && a.Nout == 2 * SN) {
@@ -205,9 +204,9 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
     }
     int row0 = bx * SM, row_end = a.M;
     const int col0 = by * SN;
-    // GraphNorm prologue (MT = 1): the folded scale / shift of the tile's trajectory, 2 KiB in LDS for the whole K loop (a load
+    // GraphNorm prologue: the folded scale / shift of the tile's trajectory, 2 KiB in LDS for the whole K loop (a load
     // per K-stage inside the staging code would expose an L2 round trip per stage)
-    if (MT == 1 && (a.stat_part || a.pro == 2)) {
+    if (a.stat_part || a.pro == 2) {
         const int tpt = (a.rows_per_graph + SM - 1) / SM, tb = bx / tpt;
         row0 = tb * a.rows_per_graph + (bx - tb * tpt) * SM;
         row_end = (tb + 1) * a.rows_per_graph;
@@ -227,15 +226,14 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // staging: thread owns 8 consecutive k (kg) of row ar (and ar + 64 when MT = 2); four lanes cover one row's 128-byte line
+    // staging: thread owns 8 consecutive k (kg) of row ar; four lanes cover one row's 128-byte line
     const int ar = tid >> 2, kg = (tid & 3) * 8;
     const int halfK = a.K >> 1;
-    const bool rv0 = row0 + ar < row_end, rv1 = MT == 2 && row0 + ar + 64 < row_end;
-    const size_t gr0 = (size_t)(rv0 ? row0 + ar : 0), gr1 = (size_t)(rv1 ? row0 + ar + 64 : 0);
-    const int g0 = a.pro == 2 ? (int)(gr0 / a.rows_per_graph) : 0, g1 = a.pro == 2 ? (int)(gr1 / a.rows_per_graph) : 0;
+    const bool rv0 = row0 + ar < row_end;
+    const size_t gr0 = (size_t)(rv0 ? row0 + ar : 0);
 
     // registers of the stage being fetched: activations (rows x 8 k) and 4 x 16 B of hi / lo weights
-    float4 xa0, xa1, xa2, xa3;
+    float4 xa0, xa1;
     uint4 wh0, wh1, wh2, wh3, wl0, wl1, wl2, wl3;
 #define GEMM_SPLIT_FETCH(K0)                                                                                          \
     {                                                                                                                 \
@@ -243,32 +241,20 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
         const float *base_ = (a.pro == 1 && k_ >= halfK) ? a.A1 + (k_ - halfK) : a.A0 + k_;                           \
         const float *s0_ = base_ + gr0 * a.lda;                                                                       \
         xa0 = *reinterpret_cast<const float4 *>(s0_); xa1 = *reinterpret_cast<const float4 *>(s0_ + 4);              \
-        if constexpr (MT == 2) {                                                                                      \
-            const float *s1_ = base_ + gr1 * a.lda;                                                                   \
-            xa2 = *reinterpret_cast<const float4 *>(s1_); xa3 = *reinterpret_cast<const float4 *>(s1_ + 4);          \
-        }                                                                                                             \
         const size_t wbase_ = ((size_t)((K0) / SK) * 4 * a.Nout + col0 + tid) * 8;                                    \
         const size_t wq_ = (size_t)a.Nout * 8;                                                                        \
         const uint16_t *ph_ = sa.Whi + wbase_, *pl_ = sa.Wlo + wbase_;                                                \
         wh0 = *reinterpret_cast<const uint4 *>(ph_); wh1 = *reinterpret_cast<const uint4 *>(ph_ + wq_);               \
         wh2 = *reinterpret_cast<const uint4 *>(ph_ + 2 * wq_); wh3 = *reinterpret_cast<const uint4 *>(ph_ + 3 * wq_); \
-        if constexpr (!W16) {                                                                                         \
-            wl0 = *reinterpret_cast<const uint4 *>(pl_); wl1 = *reinterpret_cast<const uint4 *>(pl_ + wq_);               \
-            wl2 = *reinterpret_cast<const uint4 *>(pl_ + 2 * wq_); wl3 = *reinterpret_cast<const uint4 *>(pl_ + 3 * wq_); \
-        }                                                                                                             \
+        wl0 = *reinterpret_cast<const uint4 *>(pl_); wl1 = *reinterpret_cast<const uint4 *>(pl_ + wq_);                   \
+        wl2 = *reinterpret_cast<const uint4 *>(pl_ + 2 * wq_); wl3 = *reinterpret_cast<const uint4 *>(pl_ + 3 * wq_);     \
     }
-    auto stage_row = [&](const float4 &v0, const float4 &v1, bool valid, int g, int k, int row) {
+    auto stage_row = [&](const float4 &v0, const float4 &v1, bool valid, int k, int row) {
         float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         if (a.pro == 2) {   // GraphNorm + SiLU (egnn.py:72-76) as y = x * sc + sh with per-(graph, channel) sc, sh
-            float4 c0, c1, h0, h1;
-            if constexpr (MT == 1) {     // the tile's trajectory: scale / shift sit in LDS since the start of the kernel
-                c0 = *reinterpret_cast<const float4 *>(&gn_s[k]); c1 = *reinterpret_cast<const float4 *>(&gn_s[k + 4]);
-                h0 = *reinterpret_cast<const float4 *>(&gn_s[H + k]); h1 = *reinterpret_cast<const float4 *>(&gn_s[H + k + 4]);
-            } else {
-                const float *sc = a.gn_den + (size_t)g * H + k, *sh = a.gn_shift + (size_t)g * H + k;
-                c0 = *reinterpret_cast<const float4 *>(sc); c1 = *reinterpret_cast<const float4 *>(sc + 4);
-                h0 = *reinterpret_cast<const float4 *>(sh); h1 = *reinterpret_cast<const float4 *>(sh + 4);
-            }
+            // the tile's trajectory: scale / shift sit in LDS since the start of the kernel
+            const float4 c0 = *reinterpret_cast<const float4 *>(&gn_s[k]), c1 = *reinterpret_cast<const float4 *>(&gn_s[k + 4]);
+            const float4 h0 = *reinterpret_cast<const float4 *>(&gn_s[H + k]), h1 = *reinterpret_cast<const float4 *>(&gn_s[H + k + 4]);
             const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
             const float hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
@@ -281,15 +267,9 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x0 = valid ? x[2 * e] : 0.f, x1 = valid ? x[2 * e + 1] : 0.f;
-            if constexpr (W16) {
-                const auto h2 = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-                hi[e] = __builtin_bit_cast(uint32_t, h2);
-                lo[e] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(x0 - (float)h2[0], x1 - (float)h2[1]));
-            } else {
-                const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
-                hi[e] = pack2(h0, h1);
-                lo[e] = pack2((__bf16)(x0 - (float)h0), (__bf16)(x1 - (float)h1));
-            }
+            const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
+            hi[e] = pack2(b0, b1);
+            lo[e] = pack2((__bf16)(x0 - (float)b0), (__bf16)(x1 - (float)b1));
         }
         *reinterpret_cast<uint4 *>(&Ah[row * SLD + kg]) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
         *reinterpret_cast<uint4 *>(&Al[row * SLD + kg]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
@@ -306,14 +286,11 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
     for (int k0 = 0; k0 < a.K; k0 += SK) {
         if (k0) __syncthreads();   // previous stage fully consumed
         GSTAMP(0)                  // [0] MFMA phase + barrier wait
-        stage_row(xa0, xa1, rv0, g0, k0 + kg, ar);
-        if constexpr (MT == 2) stage_row(xa2, xa3, rv1, g1, k0 + kg, ar + 64);
+        stage_row(xa0, xa1, rv0, k0 + kg, ar);
         *reinterpret_cast<uint4 *>(&Wh[wu]) = wh0; *reinterpret_cast<uint4 *>(&Wh[wu + 8]) = wh1;
         *reinterpret_cast<uint4 *>(&Wh[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&Wh[wu + 24]) = wh3;
-        if constexpr (!W16) {
-            *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
-            *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
-        }
+        *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
+        *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
         GSTAMP(1)                  // [1] waiting for the fetched registers + conversion + LDS stores
         __syncthreads();
         GSTAMP(2)                  // [2] barrier after staging
@@ -333,17 +310,12 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
                 const int c = (wn * NJ + j) * 32 + l31;
                 FragB wh, wl;
                 wh.u = *reinterpret_cast<const uint4 *>(&Wh[c * SLD + ko]);
-                if constexpr (!W16) wl.u = *reinterpret_cast<const uint4 *>(&Wl[c * SLD + ko]);
+                wl.u = *reinterpret_cast<const uint4 *>(&Wl[c * SLD + ko]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    if constexpr (W16) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i].f, wh.f, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i].f, wh.f, acc[i][j], 0, 0, 0);
-                    } else {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].b, wh.b, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wl.b, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wh.b, acc[i][j], 0, 0, 0);
-                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].b, wh.b, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wl.b, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wh.b, acc[i][j], 0, 0, 0);
                 }
             }
         }
@@ -409,7 +381,7 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
                 const size_t row = (size_t)row0 + wm * 64 + i * 32 + lr;
                 const int col = col0 + (wn * NJ + jp * 2) * 32 + ec;
                 if (row >= (size_t)row_end) continue;
-                if constexpr (MT == 1) {
+                {
                     if (a.stat_part) {
                         if (st_n == 0.f) { st_p[0] = v.x; st_p[1] = v.y; st_p[2] = v.z; st_p[3] = v.w; }
                         const float d0 = v.x - st_p[0], d1 = v.y - st_p[1], d2 = v.z - st_p[2], d3 = v.w - st_p[3];
@@ -452,7 +424,7 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
                a.K, a.Nout, a.pro, a.epi, gs[0], gs[1], gs[2], gs[3]);
     }
 #endif
-    if constexpr (MT == 1) {
+    {
         if (a.stat_part) {
             float *sp = a.stat_part + (size_t)vb * (H * 2);
             const float inv_n = st_n > 0.f ? 1.0f / st_n : 0.f;
