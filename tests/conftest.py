@@ -87,7 +87,8 @@ def draw_blob(family, draw):
 def draw_golden(family, draw, case):
     """Outputs of the reference on weight draw `draw` for `case` (inputs = the seed-0 golden's pose, t and edge list)."""
     d = load_golden(f"draws_f{family}_{draw}.npz")
-    g = load_golden(("rollout2_syn_24_16" if family else "rollout_syn_24_16") + ".npz") if case == "rollout" else \
+    g = load_golden(("rollout2_" if family else "rollout_") + ("7CEI" if case == "rollout7" else "syn_24_16") + ".npz") \
+        if case in ("rollout", "rollout7") else \
         {k: v for k, v in load_golden(case + ".npz").items() if k in ("lig_pos", "t", "edges")}
     g = dict(g)
     g.update({k.split("/", 1)[1]: v for k, v in d.items() if k.startswith(case + "/")})

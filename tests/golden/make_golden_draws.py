@@ -9,7 +9,8 @@ the same case, so that a new fixture holds outputs only:
   draws_f<family>_<draw>.npz   keys "<case>/<field>": tr_score, rot_score, energy, f, num_clashes, ires, h_absmean, h_absmax
                                (+ confidence_logits for the second family) for the forward cases
                                syn_9_7, syn_24_16, syn_64_48_p0..2, 7CEI_p0..3 (p0..2 second family), c3_300_300, db5_1AVX
-                               and "rollout/<field>": a 40-step sampler run on syn_24_16 (poses after every step, scores)
+                               and "rollout/<field>": a 40-step sampler run on syn_24_16 (poses after every step, scores),
+                               "rollout7/<field>": a 6-step run on 7CEI
 
 Usage:  python tests/golden/make_golden_draws.py [draw ...]
 """
@@ -120,8 +121,8 @@ class Replayer:
         torch.normal, torch.randn = self.o_normal, self.o_randn
 
 
-def rollout(family, net, base_model):
-    case = "rollout2_syn_24_16" if family else "rollout_syn_24_16"
+def rollout(family, net, base_model, which="syn_24_16"):
+    case = ("rollout2_" if family else "rollout_") + which
     g = load_golden(case + ".npz")
     cx = complex_for(case)
     hp = HP[family]
@@ -173,6 +174,7 @@ def main(draws):
                 print(f"  f{family} {draw} {case}: |h| mean {r['h_absmean'][-1]:.3g} max {r['h_absmax'][-1]:.3g} "
                       f"|tr| {np.abs(r['tr_score']).max():.3g} E {float(r['energy']):.4g}")
             arrs.update({f"rollout/{k}": v for k, v in rollout(family, net, base).items()})
+            arrs.update({f"rollout7/{k}": v for k, v in rollout(family, net, base, "7CEI").items()})      # 6 steps on the DB5 pair
             mg.save(f"draws_f{family}_{draw}.npz", draw=draw, **arrs)
 
 

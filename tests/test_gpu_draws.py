@@ -66,16 +66,18 @@ def test_score_on_other_weight_draws(case_i, family, draw):
         gx.close()
 
 
+@pytest.mark.parametrize("which,steps", [("rollout", 40), ("rollout7", 6)])
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
 @pytest.mark.parametrize("draw", DRAWS)
 @pytest.mark.parametrize("family", [0, 1])
-def test_rollout_on_other_weight_draws(family, draw, prec):
+def test_rollout_on_other_weight_draws(family, draw, prec, which, steps):
+    """40 steps on syn_24_16 and 6 steps on the DB5 pair 7CEI (87 + 127 residues, ESM features) per draw, every draw replayed."""
     from dfmdock_amd import engine
-    g = draw_golden(family, draw, "rollout")
-    cx = complex_for("syn_24_16")
+    g = draw_golden(family, draw, which)
+    cx = complex_for("7CEI" if which == "rollout7" else "syn_24_16")
     gx = engine.Complex(gpu_model(family, draw), cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
     inj = dict(R0=g["R0"].astype(np.float32), tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"])
-    r = gx.sample(B=1, num_steps=40, inject=inj, trace=True, **KW[prec])
+    r = gx.sample(B=1, num_steps=steps, inject=inj, trace=True, **KW[prec])
     rmsd = np.sqrt(((r["trace_pose"][0][:, :, 1, :] - g["poses"][:, :, 1, :]) ** 2).sum(-1).mean(-1))
     assert rmsd[:5].max() < (0.05 if prec == "fp32" else 0.5), rmsd[:5]
     assert rmsd.max() < 0.5, rmsd.max()

@@ -323,3 +323,27 @@ def test_engine_variants_stay_within_the_16bit_gate(tmp_path):
             assert np.abs(ref[k + sfx] - ref[k + "32"]).max() / scale < tol * gate, (sfx, k)
     for other in (ref["f_a32"], ref["f_bf"]):                            # the flags do select something else
         assert (other != ref["f"]).any()
+
+
+def test_guards_and_optional_heads(blob):
+    """(1) The message kernel addresses the [B][N][K] edge arrays through 32-bit buffer offsets: B * N * K * 4 >= 2^31 is refused up
+    front (ValueError, nothing allocated) instead of silently reading zeros.  (2) Score_Model(with_ires=False) skips the
+    interface-residue head and leaves the key out; the other outputs do not change."""
+    import torch
+    from dfmdock_amd import engine
+    from dfmdock_amd.score_model import Score_Model
+    from dfmdock_amd.synthetic import make_complex
+    engine.set_device(0)
+    cx = make_complex(40, 20, seed=9)                      # N = 60 -> K = 60
+    gx = engine.Complex(engine.Model(blob), cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    B = (1 << 31) // (60 * 60 * 4) + 1                     # 149 131 trajectories of 60 nodes
+    with pytest.raises(ValueError, match="split the batch"):
+        gx.sample(B=B, num_steps=2, seed=1, bf16=True)
+    gx.close()
+    batch = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in cx.items()}
+    batch["t"] = torch.tensor([0.4])
+    a = Score_Model(blob, precision="fp32", seed=3)(batch)
+    b = Score_Model(blob, precision="fp32", seed=3, with_ires=False)(batch)
+    assert "ires" in a and "ires" not in b and a["ires"].shape == (60, 1)
+    for k in ("tr_score", "rot_score", "f", "energy"):
+        assert torch.equal(a[k], b[k]), k

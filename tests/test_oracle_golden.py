@@ -330,14 +330,16 @@ def test_score_matches_reference_on_other_weight_draws(family, draw):
             assert abs(float(r["confidence"]) - float(g["confidence_logits"])) < 1e-4, case
 
 
+@pytest.mark.parametrize("which,steps", [("rollout", 40), ("rollout7", 6)])
 @pytest.mark.parametrize("draw", DRAWS)
 @pytest.mark.parametrize("family", [0, 1])
-def test_sampler_rollout_on_other_weight_draws(family, draw):
-    """40 reference sampler steps per draw with R0 / the N(0,30^2) draw / z / edge lists of the seed-0 rollout replayed."""
-    g = draw_golden(family, draw, "rollout")
-    o = ora.Oracle(draw_blob(family, draw), complex_for("syn_24_16"), draw_hparams(family))
+def test_sampler_rollout_on_other_weight_draws(family, draw, which, steps):
+    """Reference sampler runs per draw (40 steps on syn_24_16, 6 on the DB5 pair 7CEI) with R0 / the N(0,30^2) draw / z / edge
+    lists of the seed-0 rollouts replayed."""
+    g = draw_golden(family, draw, which)
+    o = ora.Oracle(draw_blob(family, draw), complex_for("7CEI" if which == "rollout7" else "syn_24_16"), draw_hparams(family))
     inj = dict(R0=g["R0"], tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"])
-    r = o.sample(num_steps=40, inject=inj, trace=True)
+    r = o.sample(num_steps=steps, inject=inj, trace=True)
     rmsd = _ca_rmsd(r["trace_pose"], g["poses"])
     assert rmsd[:5].max() < 0.05 and rmsd.max() < 0.5, rmsd
     if rmsd.max() < 1e-3:
