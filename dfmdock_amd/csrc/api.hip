@@ -266,14 +266,15 @@ static std::vector<uint16_t> pack_frags16(const float *W /*[256 out][256 in]*/)
                 }
     return f;
 }
-// SILU_S * bias for the bias k-step of k_edge_msg16: [64 lanes][16 n-tiles] packed (hi | lo << 16) fp16 pairs, lanes >= 16 zero
+// SILU_S * bias for the bias k-step of k_edge_msg16: [16 columns][16 n-tiles] packed (hi | lo << 16) fp16 pairs
 static std::vector<uint32_t> pack_bias16(const float *bias)
 {
-    std::vector<uint32_t> v((size_t)64 * 16, 0u);
+    std::vector<uint32_t> v((size_t)16 * 16, 0u);
     for (int c = 0; c < H; ++c) {
         const float x = SILU_S * bias[c];
         const uint16_t hi = f2h(x), lo = f2h(x - h2f(hi));
-        v[(size_t)(c % 16) * 16 + c / 16] = (uint32_t)hi | ((uint32_t)lo << 16);
+        const int nt = c / 16;      // groups of n-tiles {j, j + 4, j + 8, j + 12}: [column][j][k], nt = j + 4 k
+        v[(size_t)(c % 16) * 16 + (nt % 4) * 4 + nt / 4] = (uint32_t)hi | ((uint32_t)lo << 16);
     }
     return v;
 }
@@ -397,7 +398,7 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
             up32(&D.b2p, pack_bias(Lw.e2_b, false)); up32(&D.b2p16, pack_bias(Lw.e2_b, true)); up32(&D.b2q16, pack_bias16(Lw.e2_b));
             {
                 std::vector<float> at((size_t)H);
-                for (int c = 0; c < H; ++c) at[(size_t)(c % 16) * 16 + c / 16] = Lw.att_w[c];
+                for (int c = 0; c < H; ++c) at[(size_t)(c % 16) * 16 + ((c / 16) % 4) * 4 + (c / 16) / 4] = Lw.att_w[c];
                 up(&D.att_t, at.data(), H);
             }
             if (Lw.c1_w) {

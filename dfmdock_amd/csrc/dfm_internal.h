@@ -75,7 +75,7 @@ struct LayerDev {
     uint32_t *b2p, *b2p16;    // [8][64] SILU_S * b2 as packed (hi, lo) bf16 / fp16 pairs per (n-tile, lane), 0 for lanes >= 32
     uint32_t *bc1p, *bc1p16;  // [8][64] SILU_S * bc1, same packing
     // k_edge_msg16 (16-row tiles, v_mfma_f32_16x16x32_f16): W2 as fp16 B-fragments [8 k-steps][16 n-tiles][64 lanes][8],
-    // SILU_S * b2 as packed (hi, lo) fp16 pairs [64 lanes][16 n-tiles] (zero for lanes >= 16), att_w transposed [16 columns][16 n-tiles]
+    // SILU_S * b2 as packed (hi, lo) fp16 pairs [16 columns][16 n-tiles], att_w transposed [16 columns][16 n-tiles]
     uint16_t *W2g16; uint32_t *b2q16; float *att_t;
     float *wc2_s;     // [256]  wc2 / SILU_S
 };

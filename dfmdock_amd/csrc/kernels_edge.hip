@@ -869,20 +869,22 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
 // Segment sums: x_t of a tile (rounded on its own) -> pair sums y_p = x_2p + x_2p+1 -> agg = y_0 + y_1; a small launch (p.split)
 // makes a wave task one PAIR of tiles and adds y_p atomically to the zeroed agg: two addends, so both forms agree bitwise.
 #ifndef DFM_EDGE16_WAVES
-#define DFM_EDGE16_WAVES 16
+#define DFM_EDGE16_WAVES 12
 #endif
 constexpr int E16_WAVES = DFM_EDGE16_WAVES;
 constexpr int LDS_STAGE16_BYTES = 2048;            // per wave: two buffers of 16 rows x 32 channels fp16
-constexpr int LDS_EDGE16_BYTES = LDS_WF_BYTES + E16_WAVES * LDS_STAGE16_BYTES;
+constexpr int LDS_X16_OFF = LDS_WF_BYTES + E16_WAVES * LDS_STAGE16_BYTES;      // layer constants: w_r [256] f32 | att_w^T [16][16] f32 | bias [16][16] u32
+constexpr int LDS_EDGE16_BYTES = LDS_X16_OFF + 3072;
+static_assert(LDS_EDGE16_BYTES <= 163840, "k_edge_msg16: 14 waves at most (160 KiB of LDS)");
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DFM_EDGE16_G0
-#define DFM_EDGE16_G0 2       // MFMA slot after which the row gathers of the next-but-one chunk go out (their registers die in slice 0, slot 1)
+#define DFM_EDGE16_G0 0       // MFMA slot after which the row gathers of the next-but-one chunk go out (their registers die in slice 0, slot 0)
 #endif
 #ifndef DFM_EDGE16_GC
-#define DFM_EDGE16_GC 14      // ... and the per-chunk constants A_i / w_r (last used by slice 6, slot 13)
+#define DFM_EDGE16_GC 6       // ... and the per-chunk constants A_i / w_r (last used by slice 6, slot 6)
 #endif
 #ifndef DFM_EDGE16_BD
-#define DFM_EDGE16_BD 2
+#define DFM_EDGE16_BD 3
 #endif
 
 template <int CTRL> __device__ inline float dpp_mov(float v)
@@ -899,6 +901,12 @@ template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg
     char *stage = smem + LDS_WF_BYTES + wave * LDS_STAGE16_BYTES;
     const int g4 = lane >> 4, l15 = lane & 15;
     for (int q = tid; q < LDS_WF_BYTES / 16; q += E16_WAVES * 64) Wf[q] = p.Wf[q];
+    float *xw = reinterpret_cast<float *>(smem + LDS_X16_OFF);
+    uint32_t *xb = reinterpret_cast<uint32_t *>(smem + LDS_X16_OFF + 2048);
+    for (int q = tid; q < 256; q += E16_WAVES * 64) {
+        xw[q] = p.w_r[q]; xw[256 + q] = p.att_w[q];
+        xb[q] = p.biasp[q];      // [16 columns][16 n-tiles]
+    }
     __syncthreads();
 
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
@@ -930,10 +938,12 @@ template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg
     Frag onef;      // A operand of the bias k-step: 1.0 in k = 0, 1 of every row (lanes 0..15 hold k 0..7)
     onef.u = make_uint4(g4 == 0 ? 0x3c003c00u : 0u, 0u, 0u, 0u);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(p.T2b), rs_w = make_rsrc(p.w_r);
+    const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(p.T2b);
     const __amdgpu_buffer_rsrc_t rs_e = make_rsrc(p.edges), rs_c = make_rsrc(p.codes), rs_r = make_rsrc(p.radial);
     const int r16 = lane >> 2, c4 = lane & 3;
     const uint32_t oc4 = c4 * 32;
+    uint32_t xoff = c4 * 32, eoff = l15 * 64;      // byte offsets of this lane's w_r channels / epilogue rows; laundered once per tile so
+                                                   // that the (tile-invariant) LDS reads are not hoisted out of the tile loop into registers
     // epilogue: the in-tile row whose logit this lane ends up with after the quad reduce-scatter
     const int rs_j = ((lane >> 1) & 1) + 2 * (lane & 1), rs_row = 4 * g4 + rs_j;
 
@@ -965,11 +975,10 @@ template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg
         ot0 = ((((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * 12u + ((code >> 16) & 15u)) * (H * 2) + c4 * 16;
         ot1 = (6912u + ((code >> 20) & 127u) * 40u + (code & 63u)) * (H * 2) + c4 * 16;
     };
-    float4 a0, a1, w0, w1;
+    float4 a0, a1;
     auto gather_chunk = [&](int c) {
         if constexpr (AW16) a0 = bload16f(rs_a, c4 * 16, c * 64);
         else { a0 = bload16f_stream(rs_a, oc4, c * 128); a1 = bload16f_stream(rs_a, oc4, c * 128 + 16); }
-        w0 = bload16f(rs_w, oc4, c * 128); w1 = bload16f(rs_w, oc4, c * 128 + 16);
     };
     struct Raw3 { uint4 bm, t0, t1; };
     auto gather = [&](int c, Raw3 &r) {
@@ -981,7 +990,7 @@ template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg
     f2 pv;
     Frag pf;
     // the producer pass of one chunk in eight slices (see k_edge_msg): 2e = pre-activation of channel pair e, 2e + 1 = SiLU + fp16
-    auto slice = [&](int k, const Raw3 &r, char *buf) {
+    auto slice = [&](int cw, int k, const Raw3 &r, char *buf) {      // cw: the chunk being built (w_r comes from LDS)
         const int e = k >> 1;
         if (k == 0) {
             H8 t1, bm;
@@ -990,7 +999,7 @@ template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg
             for (int x = 0; x < 4; ++x) pt.h[x] = __hadd2(__hadd2(pt.h[x], t1.h[x]), bm.h[x]);
         }
         if ((k & 1) == 0) {
-            const f2 wv = e == 0 ? (f2){w0.x, w0.y} : (e == 1 ? (f2){w0.z, w0.w} : (e == 2 ? (f2){w1.x, w1.y} : (f2){w1.z, w1.w}));
+            const f2 wv = *reinterpret_cast<const f2 *>(smem + LDS_X16_OFF + xoff + cw * 128 + e * 8);
             if constexpr (AW16) {
                 const uint32_t ah = __float_as_uint(e == 0 ? a0.x : (e == 1 ? a0.y : (e == 2 ? a0.z : a0.w)));
                 pv = (f2){fma_half_lo(wv.x, radq, ah), fma_half_hi(wv.y, radq, ah)};
@@ -1019,17 +1028,21 @@ template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg
     gather_chunk(0);
     gather(0, r0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) slice(k, r0, stage);
+    for (int k = 0; k < 8; ++k) slice(0, k, r0, stage);
     gather(1, r0);
     gather_chunk(1);
+    Frag af;      // A fragment of the chunk about to be consumed
+    asm volatile("" ::: "memory");
+    af.u = *reinterpret_cast<const uint4 *>(stage + ((g4 * 16 + (l15 ^ (4 * g4))) << 4));
 
     float cp[4], y0[4];      // open pair sum / first pair sum of the open node: n-tiles j + 4 (lane >> 5) + 8 ((lane >> 4) & 1), column l15
 #pragma unroll
     for (int j = 0; j < 4; ++j) { cp[j] = 0.f; y0[j] = 0.f; }
-    const uint4 *biasq = reinterpret_cast<const uint4 *>(p.biasp) + lane * 4;      // [64 lanes][16 n-tiles], zero for lanes >= 16
-    const float4 *dotq = reinterpret_cast<const float4 *>(p.att_w) + l15 * 4;       // [16 columns][16 n-tiles]
 
     while (true) {
+        asm volatile("" : "+v"(xoff), "+v"(eoff));
+        const uint4 *biasq = reinterpret_cast<const uint4 *>(smem + LDS_X16_OFF + 2048 + eoff);      // [16 columns][16 n-tiles]
+        const float4 *dotq = reinterpret_cast<const float4 *>(smem + LDS_X16_OFF + 1024 + eoff);
         const bool task_end = split ? ((mt & 1) || mt == ntile - 1) : (mt == ntile - 1);
         unsigned ntt = tt;
         int nb = b, ni = i, nmt = mt + 1;
@@ -1041,16 +1054,16 @@ template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg
         if (!have_next) { nb = b; ni = i; nmt = mt; }
 
         f32x4 acc[16];
-        uint4 bpq[4];
+        // one chunk: 16 MFMAs on the A fragment `af` (read from the staging buffer at the end of the previous chunk); the producer pass
+        // of the NEXT chunk runs as one slice after each of the first eight MFMAs, its 16 bytes go to the other buffer at slot 7 and
+        // come back as the next A fragment under the last eight MFMAs (LDS runs a wave's accesses in order: no counter wait between
+        // the write and the read); weight fragments are read DFM_EDGE16_BD - 1 MFMAs ahead
         auto chunk = [&](int c, auto first, auto last) {
-            char *bufc = stage + (c & 1) * 1024, *bufn = stage + ((c + 1) & 1) * 1024;
+            char *bufn = stage + ((c + 1) & 1) * 1024;
             const int cg = (c + 2) & 7;
-            wave_lds_fence();
-            Frag af;
-            af.u = *reinterpret_cast<const uint4 *>(bufc + ((g4 * 16 + (l15 ^ (4 * g4))) << 4));
             const uint4 *wq = Wf + (size_t)c * 16 * 64 + lane;
             constexpr int BD = DFM_EDGE16_BD;
-            Frag bq[BD];
+            Frag bq[BD], afn;
 #pragma unroll
             for (int d = 0; d < BD - 1; ++d) bq[d].u = wq[d * 64];
 #pragma unroll
@@ -1058,14 +1071,16 @@ template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg
                 if (m + BD - 1 < 16) bq[(m + BD - 1) % BD].u = wq[(m + BD - 1) * 64];
                 if constexpr (decltype(first)::value) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af.f, bq[m % BD].f, zero4, 0, 0, 0);
                 else acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af.f, bq[m % BD].f, acc[m], 0, 0, 0);
-                if constexpr (decltype(last)::value) {
-                    if (m < 4) bpq[m] = biasq[m];      // older than this chunk's gathers: the bias step does not wait for them
-                }
-                if (m & 1) slice(m >> 1, r0, bufn);
+                if (m < 8) slice((c + 1) & 7, m, r0, bufn);
                 if (m == DFM_EDGE16_G0) gather(cg, r0);
                 if constexpr (!decltype(last)::value) { if (m == DFM_EDGE16_GC) gather_chunk(cg); }
+                if (m == 8) {
+                    asm volatile("" ::: "memory");
+                    afn.u = *reinterpret_cast<const uint4 *>(bufn + ((g4 * 16 + (l15 ^ (4 * g4))) << 4));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            af = afn;
         };
         chunk(0, std::true_type{}, std::false_type{});
         load_idx(nb, ni, nmt);
@@ -1075,29 +1090,33 @@ template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg
         chunk(6, std::false_type{}, std::false_type{});
         radq = radq_nx;
         chunk(7, std::false_type{}, std::true_type{});
-        float4 dvq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dvq[q] = dotq[q];
-        // bias k-step
-#pragma unroll
-        for (int nt = 0; nt < 16; ++nt) {
-            Frag bb;
-            bb.u = make_uint4((&bpq[nt >> 2].x)[nt & 3], 0u, 0u, 0u);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(onef.f, bb.f, acc[nt], 0, 0, 0);
-        }
-
-        // ---- epilogue on the 16 x 256 tile
+        // ---- epilogue on the 16 x 256 tile, in four groups of n-tiles {j, j + 4, j + 8, j + 12} (the LDS tables are laid out that way:
+        // one 16-byte read per group and table); scheduling barriers between the groups keep the register demand at one group's
         f2 part2[2] = {(f2){0.f, 0.f}, (f2){0.f, 0.f}};
 #pragma unroll
-        for (int nt = 0; nt < 16; ++nt) {
-            const float d = (&dvq[nt >> 2].x)[nt & 3];
-            const f2 vv = {d, d};
+        for (int j = 0; j < 4; ++j) {
+            uint4 bq4 = biasq[j];
+            if (g4) bq4 = make_uint4(0u, 0u, 0u, 0u);      // k >= 8 of the bias k-step
+            const float4 dv4 = dotq[j];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const f2 m = silu2s((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
-                acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
-                part2[q] = m * vv + part2[q];
+            for (int k = 0; k < 4; ++k) {      // bias k-step: acc += 1 * hi + 1 * lo
+                Frag bb;
+                bb.u = make_uint4((&bq4.x)[k], 0u, 0u, 0u);
+                acc[j + 4 * k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(onef.f, bb.f, acc[j + 4 * k], 0, 0, 0);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int nt = j + 4 * k;
+                const float d = (&dv4.x)[k];
+                const f2 vv = {d, d};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f2 m = silu2s((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
+                    acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
+                    part2[q] = m * vv + part2[q];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         float gq[4];
         {
@@ -1150,26 +1169,29 @@ template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg
             }
         }
         {
-            float t[16];
-#pragma unroll
-            for (int nt = 0; nt < 16; ++nt) {
-                const f2 cs = (f2){acc[nt][0], acc[nt][1]} * (f2){gq[0], gq[1]} + (f2){acc[nt][2], acc[nt][3]} * (f2){gq[2], gq[3]};
-                t[nt] = cs.x + cs.y;
-            }
-            // sum over the four lane groups as a reduce-scatter: lane ^ 16 (keeps n-tiles 8 b4 + ..), lane ^ 32 (4 b5 + ..)
+            // gated row sums of the tile; over the four lane groups as a reduce-scatter: lane ^ 16 keeps n-tiles 8 b4 + .., lane ^ 32
+            // 4 b5 + .. -> this lane ends with x_t of n-tile j + 4 b5 + 8 b4, j = 0..3
             const bool b4 = lane & 16, b5 = lane & 32;
-            float s8[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float keep = b4 ? t[8 + j] : t[j], send = b4 ? t[j] : t[8 + j];
-                s8[j] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x401F));
-            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float keep = b5 ? s8[4 + j] : s8[j], send = b5 ? s8[j] : s8[4 + j];
+                float t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int nt = j + 4 * k;
+                    const f2 cs = (f2){acc[nt][0], acc[nt][1]} * (f2){gq[0], gq[1]} + (f2){acc[nt][2], acc[nt][3]} * (f2){gq[2], gq[3]};
+                    t[k] = cs.x + cs.y;
+                }
+                float s8[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {      // n-tiles j + 4 k (b4 = 0) / j + 4 k + 8 (b4 = 1)
+                    const float keep = b4 ? t[k + 2] : t[k], send = b4 ? t[k] : t[k + 2];
+                    s8[k] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x401F));
+                }
+                const float keep = b5 ? s8[1] : s8[0], send = b5 ? s8[0] : s8[1];
                 float xt = (keep + __shfl_xor(send, 32, 64)) * p.inv_s;
                 asm volatile("" : "+v"(xt));
                 cp[j] += xt;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if ((mt & 1) || mt == ntile - 1) {      // the pair is complete

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b1 -- python /root/repo/bench.py --steps 5 --warmup 1 --batch 1 --no-cpu-baseline > /tmp/b1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b1 -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --batch 1 --no-cpu-baseline > /tmp/b1.log 2>&1
 f=$(find /tmp/prof_b1 -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
