@@ -27,7 +27,6 @@ DFM_F_F16 = 1 << 7
 DFM_F_IRES = 1 << 8
 DFM_F_BF16_OPS = 1 << 9
 DFM_F_DIST = 1 << 10
-DFM_F_TILE16 = 1 << 11
 
 EXPORTS = [
     "dfm_last_error", "dfm_config_string", "dfm_device_count", "dfm_set_device", "dfm_default_hparams", "dfm_param_count",

@@ -253,31 +253,6 @@ static std::vector<uint16_t> pack_frags(const float *W /*[256 out][256 in]*/, bo
                 }
     return f;
 }
-// fp16 B-operand fragments of v_mfma_f32_16x16x32_f16: [kk 8][nt 16][lane][e] = W[nt*16 + lane%16][kk*32 + (lane/16)*8 + e]
-static std::vector<uint16_t> pack_frags16(const float *W /*[256 out][256 in]*/)
-{
-    std::vector<uint16_t> f((size_t)8 * 16 * 64 * 8);
-    for (int kk = 0; kk < 8; ++kk)
-        for (int nt = 0; nt < 16; ++nt)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < 8; ++e) {
-                    const int n = nt * 16 + (lane & 15), k = kk * 32 + (lane >> 4) * 8 + e;
-                    f[(((size_t)kk * 16 + nt) * 64 + lane) * 8 + e] = f2h(W[(size_t)n * H + k]);
-                }
-    return f;
-}
-// SILU_S * bias for the bias k-step of k_edge_msg16: [16 columns][16 n-tiles] packed (hi | lo << 16) fp16 pairs
-static std::vector<uint32_t> pack_bias16(const float *bias)
-{
-    std::vector<uint32_t> v((size_t)16 * 16, 0u);
-    for (int c = 0; c < H; ++c) {
-        const float x = SILU_S * bias[c];
-        const uint16_t hi = f2h(x), lo = f2h(x - h2f(hi));
-        const int nt = c / 16;      // groups of n-tiles {j, j + 4, j + 8, j + 12}: [column][j][k], nt = j + 4 k
-        v[(size_t)(c % 16) * 16 + (nt % 4) * 4 + nt / 4] = (uint32_t)hi | ((uint32_t)lo << 16);
-    }
-    return v;
-}
 // split-bf16 operands of k_gemm_split, tiled in K-stage order: [K/32][4 k-groups][Nout][8] (W is [Nout][K] row-major)
 static void split_bf16(const float *W, int Nout, int K, std::vector<uint16_t> &hi, std::vector<uint16_t> &lo)
 {
@@ -395,12 +370,7 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
             for (int c = 0; c < H; ++c) wrs[c] = SILU_S * w_r[c];
             for (int c = 0; c < 2 * H; ++c) babs[c] = SILU_S * bias_ab[c];
             up(&D.w_r_s, wrs.data(), H); up(&D.bias_ab_s, babs.data(), 2 * H);
-            up32(&D.b2p, pack_bias(Lw.e2_b, false)); up32(&D.b2p16, pack_bias(Lw.e2_b, true)); up32(&D.b2q16, pack_bias16(Lw.e2_b));
-            {
-                std::vector<float> at((size_t)H);
-                for (int c = 0; c < H; ++c) at[(size_t)(c % 16) * 16 + ((c / 16) % 4) * 4 + (c / 16) / 4] = Lw.att_w[c];
-                up(&D.att_t, at.data(), H);
-            }
+            up32(&D.b2p, pack_bias(Lw.e2_b, false)); up32(&D.b2p16, pack_bias(Lw.e2_b, true));
             if (Lw.c1_w) {
                 for (int c = 0; c < H; ++c) wc2s[c] = Lw.c2_w[c] / SILU_S;
                 up(&D.wc2_s, wc2s.data(), H);
@@ -420,7 +390,7 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
         up(&D.Wab, Wab.data(), Wab.size()); up(&D.bias_ab, bias_ab.data(), bias_ab.size());
         up(&D.w_r, w_r.data(), w_r.size()); up(&D.T, T.data(), T.size()); up16(&D.T2b, T2b);
         const std::vector<float> W2t = transpose256(Lw.e2_w);
-        up(&D.W2t, W2t.data(), W2t.size()); up16(&D.W2f, pack_frags(Lw.e2_w)); up16(&D.W2f16, pack_frags(Lw.e2_w, true)); up16(&D.W2g16, pack_frags16(Lw.e2_w));
+        up(&D.W2t, W2t.data(), W2t.size()); up16(&D.W2f, pack_frags(Lw.e2_w)); up16(&D.W2f16, pack_frags(Lw.e2_w, true));
         up(&D.b2, Lw.e2_b, H); up(&D.att_w, Lw.att_w, H); D.att_b = Lw.att_b[0];
         up(&D.W3, Lw.n1_w, (size_t)H * 2 * H); up(&D.b3, Lw.n1_b, H);
         up(&D.gn_w, Lw.gn_w, H); up(&D.gn_b, Lw.gn_b, H); up(&D.gn_ms, Lw.gn_ms, H);
@@ -700,7 +670,6 @@ extern "C" const char *dfm_config_string(void)
 struct FwdOpts {
     bool bf16 = false, f16 = false, want_energy = false, profile = false;   // bf16: 16-bit MFMA engine; f16: ... with fp32 A_i
     bool bf16_ops = false;                // bf16 MFMA operands in every layer but the last (DFM_F_BF16_OPS)
-    bool tile16 = false;                  // message kernel on 16-row tiles (DFM_F_TILE16)
     const int32_t *edges_dev = nullptr;   // [B][N][K] already on device (or nullptr = sample natively)
     int64_t edges_pitch = 0;              // elements between trajectories in edges_dev
     uint64_t seed = 0;
@@ -747,7 +716,6 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
         e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = coord; e.fout = W.fvec; e.mbuf = W.mbuf;
         e.f16 = layer_f16(l) ? 1 : 0;
-        e.tile16 = o.tile16 ? 1 : 0;
         e.stamp = (o.profile && l == 2) ? cx->stamp_dev : nullptr;
         // the per-edge message kernel, bracketed by HIP events on this stream when profiling (dfm_get_profile)
         auto message_launch = [&](const EdgeArgs &ea) -> int {
@@ -930,7 +898,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     }
     float *ir1 = W.ir1, *ir2 = W.ir2, *ir3 = W.ir3;
     FwdOpts o;
-    o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.tile16 = bf16 && (flags & DFM_F_TILE16); o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
+    o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
     o.edges_pitch = (int64_t)N * K; o.seed = seed; o.h_first_out = h_first_dev;
     HIPCHK(hipEventRecord(cx->ev_total[0], s));
     rc = enqueue_forward(cx, B, o);
@@ -1054,7 +1022,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
         HIPCHK(hipMemcpyAsync(ip_d, W.lig_cur, (size_t)B * L * 9 * 4, hipMemcpyDeviceToDevice, s));
     }
     FwdOpts o;
-    o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.tile16 = bf16 && (flags & DFM_F_TILE16); o.profile = flags & DFM_F_PROFILE; o.seed = seed; o.edges_pitch = (int64_t)(S + 1) * N * K;
+    o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.profile = flags & DFM_F_PROFILE; o.seed = seed; o.edges_pitch = (int64_t)(S + 1) * N * K;
     const bool step_energy = (flags & DFM_F_STEP_ENERGY) != 0;
     for (int i = 0; i < num_steps; ++i) {
         const bool is_last = (i == num_steps - 1);

@@ -74,9 +74,6 @@ struct LayerDev {
     float *bias_ab_h, *bias_ab_h_s;
     uint32_t *b2p, *b2p16;    // [8][64] SILU_S * b2 as packed (hi, lo) bf16 / fp16 pairs per (n-tile, lane), 0 for lanes >= 32
     uint32_t *bc1p, *bc1p16;  // [8][64] SILU_S * bc1, same packing
-    // k_edge_msg16 (16-row tiles, v_mfma_f32_16x16x32_f16): W2 as fp16 B-fragments [8 k-steps][16 n-tiles][64 lanes][8],
-    // SILU_S * b2 as packed (hi, lo) fp16 pairs [16 columns][16 n-tiles], att_w transposed [16 columns][16 n-tiles]
-    uint16_t *W2g16; uint32_t *b2q16; float *att_t;
     float *wc2_s;     // [256]  wc2 / SILU_S
 };
 
@@ -172,7 +169,6 @@ struct EdgeArgs {
     float *fout;           // [B][L][3]   (last)
     uint16_t *mbuf;        // [B][L][64][256] 16-bit gated messages (MFMA path, last)
     int f16;               // MFMA operand type: 0 bf16, 1 fp16
-    int tile16;            // fp16 operands only: 1 = k_edge_msg16 (16-row tiles, 3-4 waves per SIMD), 0 = k_edge_msg (32-row tiles, 2 per SIMD)
     unsigned long long *stamp;   // diagnostic builds (DFM_EDGE_STAMP): [8 waves][4 phases] cycle sums of workgroup 0, or nullptr
 };
 hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);

@@ -855,365 +855,6 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
 #undef STAMP0
 }
 
-// -------------------------------------------------------------------------------------------------
-// Message kernel on 16-row tiles (v_mfma_f32_16x16x32_f16): the same algebra, producer layout, SiLU scaling and epilogue maths as
-// k_edge_msg<1, AW16>, re-tiled for OCCUPANCY.  k_edge_msg holds a 32 x 256 tile per wave = 128 accumulator registers, which
-// pins the CU at two waves per SIMD (256 registers each) - and at two waves the VALU issues 12.2 cycles per transcendental
-// against 10.6 / 9.4 at four / eight (profiles/r01_ubench_valu_rate.txt), with 28 % of the wave cycles waiting on gathers
-// that no other wave covers.  Here a wave owns 16 rows x 256 columns = 64 accumulator registers, so DFM_EDGE16_WAVES = 12 / 16
-// waves fit a CU (168 / 128 registers).  Per 16-row tile and 32-channel chunk: ONE producer pass (lane = 8 channels of one row,
-// as before) -> staging (1 KiB, [8-channel unit][row ^ 4 unit]) -> one A fragment -> 16 MFMAs (one k-step of 32 channels x 16
-// n-tiles of 16 columns).  Costs of the re-tiling: a weight fragment read from LDS now serves 16 rows instead of 32 (LDS read
-// traffic of the resident weights doubles), and the per-tile bookkeeping runs twice per 32 rows.
-// C layout of the 16 x 16 MFMA: lane = column (lane & 15), registers = rows 4 (lane >> 4) + {0..3}.
-// Segment sums: x_t of a tile (rounded on its own) -> pair sums y_p = x_2p + x_2p+1 -> agg = y_0 + y_1; a small launch (p.split)
-// makes a wave task one PAIR of tiles and adds y_p atomically to the zeroed agg: two addends, so both forms agree bitwise.
-#ifndef DFM_EDGE16_WAVES
-#define DFM_EDGE16_WAVES 12
-#endif
-constexpr int E16_WAVES = DFM_EDGE16_WAVES;
-constexpr int LDS_STAGE16_BYTES = 2048;            // per wave: two buffers of 16 rows x 32 channels fp16
-constexpr int LDS_X16_OFF = LDS_WF_BYTES + E16_WAVES * LDS_STAGE16_BYTES;      // layer constants: w_r [256] f32 | att_w^T [16][16] f32 | bias [16][16] u32
-constexpr int LDS_EDGE16_BYTES = LDS_X16_OFF + 3072;
-static_assert(LDS_EDGE16_BYTES <= 163840, "k_edge_msg16: 14 waves at most (160 KiB of LDS)");
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifndef DFM_EDGE16_G0
-#define DFM_EDGE16_G0 0       // MFMA slot after which the row gathers of the next-but-one chunk go out (their registers die in slice 0, slot 0)
-#endif
-#ifndef DFM_EDGE16_GC
-#define DFM_EDGE16_GC 6       // ... and the per-chunk constants A_i / w_r (last used by slice 6, slot 6)
-#endif
-#ifndef DFM_EDGE16_BD
-#define DFM_EDGE16_BD 3
-#endif
-
-template <int CTRL> __device__ inline float dpp_mov(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-
-template <int AW16> __global__ __launch_bounds__(E16_WAVES * 64) void k_edge_msg16(EdgeKArgs p)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint4 *Wf = reinterpret_cast<uint4 *>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char *stage = smem + LDS_WF_BYTES + wave * LDS_STAGE16_BYTES;
-    const int g4 = lane >> 4, l15 = lane & 15;
-    for (int q = tid; q < LDS_WF_BYTES / 16; q += E16_WAVES * 64) Wf[q] = p.Wf[q];
-    float *xw = reinterpret_cast<float *>(smem + LDS_X16_OFF);
-    uint32_t *xb = reinterpret_cast<uint32_t *>(smem + LDS_X16_OFF + 2048);
-    for (int q = tid; q < 256; q += E16_WAVES * 64) {
-        xw[q] = p.w_r[q]; xw[256 + q] = p.att_w[q];
-        xb[q] = p.biasp[q];      // [16 columns][16 n-tiles]
-    }
-    __syncthreads();
-
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
-    const int K = p.K, ntile = (K + 15) >> 4, npair = (ntile + 1) >> 1;
-    const bool split = p.split != 0;
-    const int NT = split ? p.N * npair : p.N;
-    const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;
-    const int NTc = (NT + nsplit - 1) / nsplit;
-    const int U = p.B * nsplit;
-    const int nb_x = U > xcd ? (U - xcd + 7) >> 3 : 0;
-    const unsigned ntask = (unsigned)nb_x * (unsigned)NTc;
-    const unsigned tstride = (unsigned)wg_per_xcd * E16_WAVES;
-    auto task_tile = [&](unsigned tt, int &b, int &i, int &mt) -> bool {      // first tile of task tt
-        const unsigned tq = tt / (unsigned)NTc, tr = tt - tq * (unsigned)NTc;
-        const int u = xcd + 8 * (int)tq;
-        b = __builtin_amdgcn_readfirstlane(u / nsplit);
-        const int idx = __builtin_amdgcn_readfirstlane((u % nsplit) * NTc + (int)tr);
-        i = split ? idx / npair : idx;
-        mt = split ? (idx - i * npair) * 2 : 0;
-        return idx < NT;
-    };
-    auto next_task = [&](unsigned &tt, int &b, int &i, int &mt) -> bool {
-        while (tt < ntask) {
-            if (task_tile(tt, b, i, mt)) return true;
-            tt += tstride;
-        }
-        return false;
-    };
-    Frag onef;      // A operand of the bias k-step: 1.0 in k = 0, 1 of every row (lanes 0..15 hold k 0..7)
-    onef.u = make_uint4(g4 == 0 ? 0x3c003c00u : 0u, 0u, 0u, 0u);
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(p.T2b);
-    const __amdgpu_buffer_rsrc_t rs_e = make_rsrc(p.edges), rs_c = make_rsrc(p.codes), rs_r = make_rsrc(p.radial);
-    const int r16 = lane >> 2, c4 = lane & 3;
-    const uint32_t oc4 = c4 * 32;
-    uint32_t xoff = c4 * 32, eoff = l15 * 64;      // byte offsets of this lane's w_r channels / epilogue rows; laundered once per tile so
-                                                   // that the (tile-invariant) LDS reads are not hoisted out of the tile loop into registers
-    // epilogue: the in-tile row whose logit this lane ends up with after the quad reduce-scatter
-    const int rs_j = ((lane >> 1) & 1) + 2 * (lane & 1), rs_row = 4 * g4 + rs_j;
-
-    unsigned tt = (unsigned)slot * E16_WAVES + wave;
-    int b = 0, i = 0, mt = 0;
-    if (!next_task(tt, b, i, mt)) return;
-
-    int jqn; uint32_t codeqn; float radqn;
-    auto load_idx = [&](int tb, int ti, int tm) {
-        const uint32_t ebase = ((uint32_t)tb * (uint32_t)p.N + (uint32_t)ti) * (uint32_t)K;
-        const int s = tm * 16 + r16;
-        const uint32_t off = (ebase + (uint32_t)(s < K ? s : K - 1)) * 4u;
-        jqn = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_e, (int)off, 0, AUX_STREAM);
-        codeqn = __builtin_amdgcn_raw_buffer_load_b32(rs_c, (int)off, 0, AUX_STREAM);
-        radqn = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)off, 0, AUX_STREAM));
-    };
-    uint32_t obm, ot0, ot1;
-    float radq, radq_nx;
-    __amdgpu_buffer_rsrc_t rs_bm = rs_t, rs_a = rs_t;
-    auto set_tile = [&](int tb, int ti, int tm) {
-        const size_t ab = (size_t)tb * p.ab_bstride;
-        rs_bm = make_rsrc(p.Bmb + ab);
-        rs_a = AW16 ? make_rsrc(p.Ah + ab + (size_t)ti * H) : make_rsrc(p.A + ab + (size_t)ti * H);
-        const bool v = tm * 16 + r16 < K;      // masked rows: self edge, zero features -> finite values, gate forced to 0
-        const int j = v ? jqn : ti;
-        const uint32_t code = v ? codeqn : 0u;
-        radq_nx = v ? radqn : 0.f;
-        obm = (uint32_t)j * (H * 2) + c4 * 16;
-        ot0 = ((((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * 12u + ((code >> 16) & 15u)) * (H * 2) + c4 * 16;
-        ot1 = (6912u + ((code >> 20) & 127u) * 40u + (code & 63u)) * (H * 2) + c4 * 16;
-    };
-    float4 a0, a1;
-    auto gather_chunk = [&](int c) {
-        if constexpr (AW16) a0 = bload16f(rs_a, c4 * 16, c * 64);
-        else { a0 = bload16f_stream(rs_a, oc4, c * 128); a1 = bload16f_stream(rs_a, oc4, c * 128 + 16); }
-    };
-    struct Raw3 { uint4 bm, t0, t1; };
-    auto gather = [&](int c, Raw3 &r) {
-        r.bm = bload16(rs_bm, obm, c * 64);
-        r.t0 = bload16(rs_t, ot0, c * 64);
-        r.t1 = bload16(rs_t, ot1, c * 64);
-    };
-    H8 pt;
-    f2 pv;
-    Frag pf;
-    // the producer pass of one chunk in eight slices (see k_edge_msg): 2e = pre-activation of channel pair e, 2e + 1 = SiLU + fp16
-    auto slice = [&](int cw, int k, const Raw3 &r, char *buf) {      // cw: the chunk being built (w_r comes from LDS)
-        const int e = k >> 1;
-        if (k == 0) {
-            H8 t1, bm;
-            pt.u = r.t0; t1.u = r.t1; bm.u = r.bm;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) pt.h[x] = __hadd2(__hadd2(pt.h[x], t1.h[x]), bm.h[x]);
-        }
-        if ((k & 1) == 0) {
-            const f2 wv = *reinterpret_cast<const f2 *>(smem + LDS_X16_OFF + xoff + cw * 128 + e * 8);
-            if constexpr (AW16) {
-                const uint32_t ah = __float_as_uint(e == 0 ? a0.x : (e == 1 ? a0.y : (e == 2 ? a0.z : a0.w)));
-                pv = (f2){fma_half_lo(wv.x, radq, ah), fma_half_hi(wv.y, radq, ah)};
-            } else {
-                const f2 rad2 = {radq, radq};
-                const f2 av = e == 0 ? (f2){a0.x, a0.y} : (e == 1 ? (f2){a0.z, a0.w} : (e == 2 ? (f2){a1.x, a1.y} : (f2){a1.z, a1.w}));
-                pv = wv * rad2 + av;
-            }
-            pv = add_half2(pv, pt.h[e]);
-        } else {
-            const f2 x = pv;
-            f2 ex = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-            ex = ex * (f2){0.999755859375f, 0.999755859375f} + (f2){0.999755859375f, 0.999755859375f};
-            const f2 rr = {__builtin_amdgcn_rcpf(ex.x), __builtin_amdgcn_rcpf(ex.y)};
-            const f2 m = x * rr;
-            (&pf.u.x)[e] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(m.x, m.y));
-            if (k == 7) *reinterpret_cast<uint4 *>(buf + ((c4 * 16 + (r16 ^ (4 * c4))) << 4)) = pf.u;
-        }
-    };
-
-    // ---- prologue of the wave: first tile's chunk 0 built, its chunk 1 requested
-    Raw3 r0;
-    load_idx(b, i, mt);
-    set_tile(b, i, mt);
-    radq = radq_nx;
-    gather_chunk(0);
-    gather(0, r0);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) slice(0, k, r0, stage);
-    gather(1, r0);
-    gather_chunk(1);
-    Frag af;      // A fragment of the chunk about to be consumed
-    asm volatile("" ::: "memory");
-    af.u = *reinterpret_cast<const uint4 *>(stage + ((g4 * 16 + (l15 ^ (4 * g4))) << 4));
-
-    float cp[4], y0[4];      // open pair sum / first pair sum of the open node: n-tiles j + 4 (lane >> 5) + 8 ((lane >> 4) & 1), column l15
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { cp[j] = 0.f; y0[j] = 0.f; }
-
-    while (true) {
-        asm volatile("" : "+v"(xoff), "+v"(eoff));
-        const uint4 *biasq = reinterpret_cast<const uint4 *>(smem + LDS_X16_OFF + 2048 + eoff);      // [16 columns][16 n-tiles]
-        const float4 *dotq = reinterpret_cast<const float4 *>(smem + LDS_X16_OFF + 1024 + eoff);
-        const bool task_end = split ? ((mt & 1) || mt == ntile - 1) : (mt == ntile - 1);
-        unsigned ntt = tt;
-        int nb = b, ni = i, nmt = mt + 1;
-        bool have_next = true;
-        if (task_end) {
-            ntt = tt + tstride;
-            have_next = next_task(ntt, nb, ni, nmt);
-        }
-        if (!have_next) { nb = b; ni = i; nmt = mt; }
-
-        f32x4 acc[16];
-        // one chunk: 16 MFMAs on the A fragment `af` (read from the staging buffer at the end of the previous chunk); the producer pass
-        // of the NEXT chunk runs as one slice after each of the first eight MFMAs, its 16 bytes go to the other buffer at slot 7 and
-        // come back as the next A fragment under the last eight MFMAs (LDS runs a wave's accesses in order: no counter wait between
-        // the write and the read); weight fragments are read DFM_EDGE16_BD - 1 MFMAs ahead
-        auto chunk = [&](int c, auto first, auto last) {
-            char *bufn = stage + ((c + 1) & 1) * 1024;
-            const int cg = (c + 2) & 7;
-            const uint4 *wq = Wf + (size_t)c * 16 * 64 + lane;
-            constexpr int BD = DFM_EDGE16_BD;
-            Frag bq[BD], afn;
-#pragma unroll
-            for (int d = 0; d < BD - 1; ++d) bq[d].u = wq[d * 64];
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                if (m + BD - 1 < 16) bq[(m + BD - 1) % BD].u = wq[(m + BD - 1) * 64];
-                if constexpr (decltype(first)::value) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af.f, bq[m % BD].f, zero4, 0, 0, 0);
-                else acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af.f, bq[m % BD].f, acc[m], 0, 0, 0);
-                if (m < 8) slice((c + 1) & 7, m, r0, bufn);
-                if (m == DFM_EDGE16_G0) gather(cg, r0);
-                if constexpr (!decltype(last)::value) { if (m == DFM_EDGE16_GC) gather_chunk(cg); }
-                if (m == 8) {
-                    asm volatile("" ::: "memory");
-                    afn.u = *reinterpret_cast<const uint4 *>(bufn + ((g4 * 16 + (l15 ^ (4 * g4))) << 4));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            af = afn;
-        };
-        chunk(0, std::true_type{}, std::false_type{});
-        load_idx(nb, ni, nmt);
-#pragma unroll 1
-        for (int c = 1; c < 6; ++c) chunk(c, std::false_type{}, std::false_type{});
-        set_tile(nb, ni, nmt);
-        chunk(6, std::false_type{}, std::false_type{});
-        radq = radq_nx;
-        chunk(7, std::false_type{}, std::true_type{});
-        // ---- epilogue on the 16 x 256 tile, in four groups of n-tiles {j, j + 4, j + 8, j + 12} (the LDS tables are laid out that way:
-        // one 16-byte read per group and table); scheduling barriers between the groups keep the register demand at one group's
-        f2 part2[2] = {(f2){0.f, 0.f}, (f2){0.f, 0.f}};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint4 bq4 = biasq[j];
-            if (g4) bq4 = make_uint4(0u, 0u, 0u, 0u);      // k >= 8 of the bias k-step
-            const float4 dv4 = dotq[j];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {      // bias k-step: acc += 1 * hi + 1 * lo
-                Frag bb;
-                bb.u = make_uint4((&bq4.x)[k], 0u, 0u, 0u);
-                acc[j + 4 * k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(onef.f, bb.f, acc[j + 4 * k], 0, 0, 0);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int nt = j + 4 * k;
-                const float d = (&dv4.x)[k];
-                const f2 vv = {d, d};
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const f2 m = silu2s((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
-                    acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
-                    part2[q] = m * vv + part2[q];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        float gq[4];
-        {
-            // logits: reduce-scatter over the quad (lane ^ 1, ^ 2), then the four quads of the 16-lane row (rotations by 4 and 8 keep
-            // the position inside the quad); gate by the lane that holds the row, handed to the quad by DPP broadcasts
-            const bool b0 = lane & 1, b1 = lane & 2;
-            const float k0 = b0 ? part2[1].x : part2[0].x, s0 = b0 ? part2[0].x : part2[1].x;
-            const float k1 = b0 ? part2[1].y : part2[0].y, s1 = b0 ? part2[0].y : part2[1].y;
-            const float u0 = k0 + dpp_mov<0xB1>(s0), u1 = k1 + dpp_mov<0xB1>(s1);      // rows 2 b0 + {0, 1}
-            const float kk = b1 ? u1 : u0, ss = b1 ? u0 : u1;
-            float lg = kk + dpp_mov<0x4E>(ss);                                           // row 2 b0 + b1
-            lg += dpp_mov<0x124>(lg);      // row_ror:4
-            lg += dpp_mov<0x128>(lg);      // row_ror:8
-            const int rown = mt * 16 + rs_row;
-            const float gate = rown < K ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(lg + p.att_b)) : 0.f;
-            gq[0] = dpp_mov<0x00>(gate); gq[1] = dpp_mov<0xAA>(gate); gq[2] = dpp_mov<0x55>(gate); gq[3] = dpp_mov<0xFF>(gate);
-        }
-        if (p.last && i >= p.R) {
-            // gated messages of a ligand node in the A-fragment order k_edge_coord reads ([k-step 16][half 2][row 32][8 channels] per
-            // 32-row tile): n-tile nt = k-step nt, halves = columns 0..7 / 8..15; this tile fills rows 16 (mt & 1) .. + 16 of every
-            // unit.  Two n-tiles (4 units x 16 rows x 16 B = 1 KiB) go through the wave's free staging buffer per round.
-            char *tb = stage + 1024;
-            uint4 *Mout = reinterpret_cast<uint4 *>(p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + (mt >> 1)) * (32 * H)) + (mt & 1) * 16;
-            const int hu = l15 >> 3;
-            int wb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wb[j] = hu * 256 + (((4 * g4 + j) ^ (2 * hu)) << 4) + (l15 & 7) * 2;
-            const int ru = lane >> 4, rrow = lane & 15;
-            const int rd = ru * 256 + ((rrow ^ (2 * (ru & 1))) << 4);
-            float ps[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { ps[j] = gq[j]; asm volatile("" : "+v"(ps[j])); }
-#pragma unroll
-            for (int np = 0; np < 8; ++np) {
-#pragma unroll
-                for (int x = 0; x < 2; ++x) {
-                    const int nt = np * 2 + x;
-                    const uint32_t pk0 = pack_f16_sat_lo(acc[nt][0] * ps[0], acc[nt][1] * ps[1]);
-                    const uint32_t pk1 = pack_f16_sat_lo(acc[nt][2] * ps[2], acc[nt][3] * ps[3]);
-                    *reinterpret_cast<uint16_t *>(tb + x * 512 + wb[0]) = (uint16_t)pk0;
-                    *reinterpret_cast<uint16_t *>(tb + x * 512 + wb[1]) = (uint16_t)(pk0 >> 16);
-                    *reinterpret_cast<uint16_t *>(tb + x * 512 + wb[2]) = (uint16_t)pk1;
-                    *reinterpret_cast<uint16_t *>(tb + x * 512 + wb[3]) = (uint16_t)(pk1 >> 16);
-                }
-                wave_lds_fence();
-                const uint4 v0 = *reinterpret_cast<const uint4 *>(tb + rd);
-                wave_lds_fence();
-                // unit ru of this round = (k-step 2 np + (ru >> 1), half ru & 1): 64 fragment lanes per k-step, half = 32 lanes
-                store_stream(Mout + (np * 2 + (ru >> 1)) * 64 + (ru & 1) * 32 + rrow, v0);
-            }
-        }
-        {
-            // gated row sums of the tile; over the four lane groups as a reduce-scatter: lane ^ 16 keeps n-tiles 8 b4 + .., lane ^ 32
-            // 4 b5 + .. -> this lane ends with x_t of n-tile j + 4 b5 + 8 b4, j = 0..3
-            const bool b4 = lane & 16, b5 = lane & 32;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int nt = j + 4 * k;
-                    const f2 cs = (f2){acc[nt][0], acc[nt][1]} * (f2){gq[0], gq[1]} + (f2){acc[nt][2], acc[nt][3]} * (f2){gq[2], gq[3]};
-                    t[k] = cs.x + cs.y;
-                }
-                float s8[2];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {      // n-tiles j + 4 k (b4 = 0) / j + 4 k + 8 (b4 = 1)
-                    const float keep = b4 ? t[k + 2] : t[k], send = b4 ? t[k] : t[k + 2];
-                    s8[k] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x401F));
-                }
-                const float keep = b5 ? s8[1] : s8[0], send = b5 ? s8[0] : s8[1];
-                float xt = (keep + __shfl_xor(send, 32, 64)) * p.inv_s;
-                asm volatile("" : "+v"(xt));
-                cp[j] += xt;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if ((mt & 1) || mt == ntile - 1) {      // the pair is complete
-            float *out = p.agg + ((size_t)b * p.N + i) * H + (((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 8) * 16 + l15;
-            if (split) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { atomicAdd(out + j * 16, cp[j]); cp[j] = 0.f; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { y0[j] = mt <= 1 ? cp[j] : y0[j] + cp[j]; cp[j] = 0.f; }
-                if (mt == ntile - 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) store_stream(out + j * 16, y0[j]);
-                }
-            }
-        }
-        if (!have_next) break;
-        gather_chunk(1);      // the next tile's per-chunk constants (kept out of the epilogue's in-order wait chain)
-        tt = ntt; b = nb; i = ni; mt = nmt;
-    }
-}
-
 // Coordinate MLP of the last layer (egnn.py:118-137) over the stored gated messages of the ligand nodes: same tile and epilogue
 // layout as the message kernel, the A operand comes straight from HBM in fragment order (no producer).
 template <int F16>   // F16 0: bf16 MFMA operands, 1: fp16 MFMA operands (3 more mantissa bits, same rate)
@@ -1408,8 +1049,7 @@ static EdgeKArgs to_kargs_mfma(const EdgeArgs &a, int mode)
     const LayerDev *w = a.lw;
     k.w_r = w->w_r_s; k.att_b = w->att_b * SILU_S; k.inv_s = 1.0f / SILU_S; k.wc2 = w->wc2_s;
     if (mode == 0) { k.Wf = reinterpret_cast<const uint4 *>(a.f16 ? w->W2f16 : w->W2f); k.biasp = a.f16 ? w->b2p16 : w->b2p; }
-    else if (mode == 1) { k.Wf = reinterpret_cast<const uint4 *>(a.f16 ? w->Wc1f16 : w->Wc1f); k.biasp = a.f16 ? w->bc1p16 : w->bc1p; }
-    else { k.Wf = reinterpret_cast<const uint4 *>(w->W2g16); k.biasp = w->b2q16; k.att_w = w->att_t; }      // k_edge_msg16
+    else { k.Wf = reinterpret_cast<const uint4 *>(a.f16 ? w->Wc1f16 : w->Wc1f); k.biasp = a.f16 ? w->bc1p16 : w->bc1p; }
     return k;
 }
 
@@ -1447,47 +1087,6 @@ template <int F16, int AW16> static hipError_t launch_msg_t(const EdgeKArgs &k, 
     hipLaunchKernelGGL((k_edge_msg<F16, AW16>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
     return hipGetLastError();
 }
-static int persistent_grid16(long long wave_tasks)
-{
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    long long wgs = (wave_tasks + E16_WAVES - 1) / E16_WAVES;
-    long long g = wgs < cus ? wgs : cus;
-    g = (g + 7) / 8 * 8;
-    return (int)g;
-}
-template <int AW16> static hipError_t launch_msg16_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
-{
-    static std::atomic<bool> attr_done[MAX_DEVICES];
-    {
-        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_msg16<AW16>), LDS_EDGE16_BYTES, attr_done);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL((k_edge_msg16<AW16>), dim3(persistent_grid16(wave_tasks)), dim3(E16_WAVES * 64), LDS_EDGE16_BYTES, s, k);
-    return hipGetLastError();
-}
-// 16-row tiles: node tasks (ceil(K / 16) tiles each) or - small launches - tile-PAIR tasks added atomically to the zeroed agg
-static hipError_t launch_edge_tile16(const EdgeArgs &a, hipStream_t s)
-{
-    EdgeKArgs k = to_kargs_mfma(a, 2);
-    long long tasks = (long long)a.B * a.N;
-    const int ntile = (a.K + 15) / 16, npair = (ntile + 1) / 2;
-    if (npair > 1) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        const long long waves = (long long)cus * E16_WAVES;
-        const long long rounds_node = (tasks + waves - 1) / waves * ntile, rounds_pair = (tasks * npair + waves - 1) / waves * 2;
-        static const int env = [] { const char *e = getenv("DFM_EDGE_SPLIT"); return e ? atoi(e) : -1; }();      // diagnostics: 0 / 1 force
-        if (env >= 0 ? env != 0 : rounds_pair < rounds_node) {
-            k.split = 1; tasks *= npair;
-            hipError_t e = hipMemsetAsync(a.agg, 0, (size_t)a.B * a.N * H * sizeof(float), s);
-            if (e != hipSuccess) return e;
-        }
-    }
-    return a.Ah ? launch_msg16_t<1>(k, tasks, s) : launch_msg16_t<0>(k, tasks, s);
-}
-
 template <int F16> static hipError_t launch_coord_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
 {
     static std::atomic<bool> attr_done[MAX_DEVICES];
@@ -1501,7 +1100,6 @@ template <int F16> static hipError_t launch_coord_t(const EdgeKArgs &k, long lon
 
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    if (a.f16 && a.tile16) return launch_edge_tile16(a, s);
     EdgeKArgs k = to_kargs_mfma(a, 0);
     long long tasks = (long long)a.B * a.N;
     // Small launches: with one node (two tiles) per task the last round of the persistent grid is mostly idle - e.g. B = 8 at

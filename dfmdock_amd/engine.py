@@ -9,13 +9,6 @@ from . import _lib as L
 from .weights import HParams
 
 
-def _dev_flags() -> int:
-    """DFM_TILE16=1 in the environment ORs DFM_F_TILE16 into every call (A/B runs of the whole test suite on the 16-row-tile
-    message kernel; bench.py echoes the variable in its JSON line)."""
-    import os
-    return L.DFM_F_TILE16 if os.environ.get("DFM_TILE16", "0") not in ("", "0") else 0
-
-
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -160,7 +153,7 @@ class Complex:
                 raise ValueError(f"edges must be [B,N,K] = {(B, N, K)}, got {e.shape}")
         flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_ENERGY if energy else 0) | (L.DFM_F_PROFILE if profile else 0) | \
                 (L.DFM_F_F16 if f16 else 0) | (L.DFM_F_IRES if ires else 0) | (L.DFM_F_BF16_OPS if bf16_ops else 0) | \
-                (L.DFM_F_DIST if dist else 0) | _dev_flags()
+                (L.DFM_F_DIST if dist else 0)
         rc = L.lib().dfm_score(self._h, B, _p(lig_pos), _p(t), _p(e, L.I32P), int(seed), flags, C.byref(out))
         L.check(rc, "dfm_score")
         if debug:
@@ -200,7 +193,7 @@ class Complex:
         flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_NOISE_ANNEALING if noise_annealing else 0) | \
                 (L.DFM_F_CLASH_FORCE if use_clash_force else 0) | (L.DFM_F_ODE if ode else 0) | \
                 (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if trace else 0) | (L.DFM_F_F16 if f16 else 0) | \
-                (L.DFM_F_BF16_OPS if bf16_ops else 0) | _dev_flags()
+                (L.DFM_F_BF16_OPS if bf16_ops else 0)
         rc = L.lib().dfm_sample(self._h, int(B), S, float(eps), float(tr_noise_scale), float(rot_noise_scale), flags,
                                 int(seed), C.byref(inj) if inj is not None else None, C.byref(out))
         L.check(rc, "dfm_sample")

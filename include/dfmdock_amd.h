@@ -92,13 +92,10 @@ enum {
     DFM_F_IRES = 1u << 8,            /* dfm_score: also evaluate the interface-residue head (score_net_mlsb.py:383) */
     DFM_F_DIST = 1u << 10,           /* dfm_score, family 1: also evaluate dist_logits = to_dist(cat[h_r, h_l, D]) over all R x L pairs
                                         (egnn_net.py:347-352,:447; a training-loss input, never read by a sampler); fp32 in every engine */
-    DFM_F_BF16_OPS = 1u << 9,        /* with DFM_F_MFMA16: bf16 instead of fp16 MFMA operands in layers 0..depth-2 (the r02
+    DFM_F_BF16_OPS = 1u << 9         /* with DFM_F_MFMA16: bf16 instead of fp16 MFMA operands in layers 0..depth-2 (the r02
                                         plan; ~3 % faster).  OUTSIDE SURVEY 8(d)'s 1e-2 gate: measured up to 1.5e-2 on f /
                                         tr_score / rot_score over four weight draws (profiles/r03_tol_report.txt) - an opt-in
                                         for callers who accept that; tested at 2e-2                                      */
-    DFM_F_TILE16 = 1u << 11          /* 16-bit engines with fp16 operands: per-edge message kernel on 16-row tiles
-                                        (v_mfma_f32_16x16x32_f16, 64 accumulator registers, 3-4 waves per SIMD) instead of 32-row
-                                        tiles (two waves per SIMD); same algebra and precision plan                     */
 };
 
 /* Output of dfm_score.  Required: tr_score, rot_score.  Any other pointer may be NULL. */
