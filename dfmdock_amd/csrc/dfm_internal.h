@@ -136,8 +136,15 @@ struct GemmArgs {
     uint16_t *Cb;         // [M][256]  epi 2: when set, the first 256 columns go here as fp16 INSTEAD of C (k_gemm_split only)
     // optional (k_gemm_split, 64-row tiles, Nout = 256): row tiles aligned to the trajectories (rows_per_graph rows each) and
     // per-tile column statistics of the output for GraphNorm, [M / rows_per_graph][tiles per trajectory][256][2] =
-    // (mean, sum of squared deviations) of the tile's rows; merged by launch_gn_finish
+    // (mean, sum of squared deviations) of the tile's rows; merged in the prologue of the consuming GEMM (gn_part)
     float *stat_part;
+    // optional (k_gemm_split, pro 2): the GraphNorm statistics are finished INSIDE the prologue - every workgroup merges the per-tile
+    // (mean, M2) pairs of its trajectory (gn_part, written by the previous launch's stat_part) exactly as k_gn_finish does, so small
+    // launches do not pay a separate 5 us kernel per layer; gn_ms = mean_scale [256]; gn_shift / gn_den are then unused
+    const float *gn_part, *gn_ms;
+    // optional (k_gemm_split, pro 1): zero the A1 rows of the tile once they are staged (A1 = agg: the next layer's tile-task message
+    // launch adds into it atomically and would otherwise need a memset launch)
+    int zero_a1;
 };
 hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s);
 // split-bf16 (hi/lo) variant, ~1e-5 relative error; Whi/Wlo = pre-split weights [Nout][ldw] bf16
@@ -169,16 +176,16 @@ struct EdgeArgs {
     float *fout;           // [B][L][3]   (last)
     uint16_t *mbuf;        // [B][L][64][256] 16-bit gated messages (MFMA path, last)
     int f16;               // MFMA operand type: 0 bf16, 1 fp16
+    int agg_is_zero;       // 16-bit kernel with tile tasks: agg is known to be zero (zeroed by the previous layer's node GEMM, GemmArgs::zero_a1)
     unsigned long long *stamp;   // diagnostic builds (DFM_EDGE_STAMP): [8 waves][4 phases] cycle sums of workgroup 0, or nullptr
 };
 hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s);
+bool edge_msg_tile_tasks(int B, int N, int K);   // does launch_edge_bf16 run tile tasks (atomic adds into a zero agg) for this size?
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s);
 
 // fold_w / fold_b non-null: write the folded affine (den := w/den, shift := b - w*shift/den) for launch_gemm_split
 // GraphNorm statistics from the per-tile column statistics the node_mlp.0 GEMM left in stat_part (no second pass over u)
-hipError_t launch_gn_finish(const float *stat_part, int B, int N, const float *mean_scale, float *shift, float *den,
-                            const float *fold_w, const float *fold_b, hipStream_t s);
 hipError_t launch_gn_stats(const float *u, int B, int N, const float *mean_scale, float *shift, float *den,
                            const float *fold_w, const float *fold_b, hipStream_t s);
 

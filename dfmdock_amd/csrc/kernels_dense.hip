@@ -151,6 +151,38 @@ hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s)
 // Same prologues / epilogues as k_gemm_f32, except that prologue 2 takes the folded GraphNorm affine
 // (gn_den := w/den, gn_shift := b - w*shift/den per graph and channel, see k_gn_stats fold=1).
 // Needs K % 32 == 0, Nout % 256 == 0.
+// One channel of GraphNorm from the per-tile column statistics of k_gemm_split (stat_part [B][tiles per trajectory][256][2] =
+// (mean, M2 = sum of squared deviations) over the tile's rows): tiles merged in a fixed order with Chan's update in float64, then
+// var = E[(u - shift)^2] = M2 / N + (mean - shift)^2 with shift = mean * mean_scale.  fold_w: returns the folded affine
+// (den := w / den, shift := b - w * shift / den).  Runs in the prologue of the GEMM that consumes the normalised activations
+// (r01-r03: a separate k_gn_finish launch per layer, 5 us each that small batches could not hide).
+__device__ inline void gn_finish_col(const float *__restrict__ part, int b, int N, int c, const float *__restrict__ mean_scale,
+                                     const float *__restrict__ fold_w, const float *__restrict__ fold_b, float &o_den, float &o_shift)
+{
+    const int tpt = (N + 63) / 64;
+    double n = 0, mean = 0, M2 = 0;
+    for (int t = 0; t < tpt; ++t) {
+        const float *pp = part + ((size_t)b * tpt + t) * (H * 2) + c * 2;
+        const double nt = (double)(N - t * 64 < 64 ? N - t * 64 : 64), d = (double)pp[0] - mean, tot = n + nt;
+        mean += d * nt / tot;
+        M2 += (double)pp[1] + d * d * n * nt / tot;
+        n = tot;
+    }
+    const float sft = (float)mean * mean_scale[c];
+    const double dm = mean - (double)sft;
+    double var = M2 / N + dm * dm;
+    var = var > 0 ? var : 0;
+    const float dn = sqrtf((float)var + 1e-5f);
+    if (fold_w) {
+        const float sc = fold_w[c] / dn;
+        o_den = sc;
+        o_shift = fold_b[c] - sc * sft;
+    } else {
+        o_shift = sft;
+        o_den = dn;
+    }
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 union FragB { uint4 u; bf16x8 b; };
 constexpr int SN = 256, SK = 32, SLD = 40;   // output columns per workgroup; K per stage; LDS row stride in bf16
@@ -211,7 +243,11 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
         row0 = tb * a.rows_per_graph + (bx - tb * tpt) * SM;
         row_end = (tb + 1) * a.rows_per_graph;
         if (a.pro == 2) {
-            if (tid < 128) {
+            if (a.gn_part) {      // finish the statistics here (thread = channel): no separate launch between the two GEMMs
+                float sc, sh;
+                gn_finish_col(a.gn_part, tb, a.rows_per_graph, tid, a.gn_ms, a.gn_w, a.gn_b, sc, sh);
+                gn_s[tid] = sc; gn_s[H + tid] = sh;
+            } else if (tid < 128) {
                 const float *src = (tid < 64 ? a.gn_den : a.gn_shift) + (size_t)tb * H + (tid & 63) * 4;
                 *reinterpret_cast<float4 *>(&gn_s[(tid < 64 ? 0 : H) + (tid & 63) * 4]) = *reinterpret_cast<const float4 *>(src);
             }
@@ -287,6 +323,11 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
         if (k0) __syncthreads();   // previous stage fully consumed
         GSTAMP(0)                  // [0] MFMA phase + barrier wait
         stage_row(xa0, xa1, rv0, k0 + kg, ar);
+        if (a.zero_a1 && a.pro == 1 && k0 + kg >= halfK && rv0) {      // the staged values are in registers: the loads have returned
+            float *z = const_cast<float *>(a.A1) + (k0 + kg - halfK) + gr0 * a.lda;
+            *reinterpret_cast<float4 *>(z) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(z + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         *reinterpret_cast<uint4 *>(&Wh[wu]) = wh0; *reinterpret_cast<uint4 *>(&Wh[wu + 8]) = wh1;
         *reinterpret_cast<uint4 *>(&Wh[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&Wh[wu + 24]) = wh3;
         *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
@@ -326,7 +367,7 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
     // dead by now) in 32 x 64 passes and stores 16-byte vectors, 256 B per row.
     __syncthreads();
     // GraphNorm statistics of this lane's rows (4 columns): shifted sums about the lane's first value - no E[u^2] - E[u]^2
-    // cancellation when |mean| >> std - turned into (count, mean, M2) and merged Chan-style across lanes, tiles (k_gn_finish)
+    // cancellation when |mean| >> std - turned into (count, mean, M2) and merged Chan-style across lanes, tiles (gn_finish_col)
     float st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0}, st_p[4] = {0, 0, 0, 0}, st_n = 0.f;
     constexpr int ELD = 72;                               // floats per staged row (64 + 8: the half-waves, 4 rows apart, hit disjoint banks)
     float *est = reinterpret_cast<float *>(lds) + wave * (32 * ELD);   // 9216 B per wave
@@ -527,44 +568,6 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float *__restrict__ u, i
             den[(size_t)b * H + c] = dn;
         }
     }
-}
-
-// GraphNorm statistics from the per-tile column statistics of k_gemm_split (stat_part [B][tiles per trajectory][256][2] =
-// (mean, M2 = sum of squared deviations) over the tile's rows); tiles are merged in a fixed order with Chan's update in
-// float64, then var = E[(u - shift)^2] = M2 / N + (mean - shift)^2 with shift = mean * mean_scale.
-__global__ __launch_bounds__(256) void k_gn_finish(const float *__restrict__ part, int N, const float *__restrict__ mean_scale,
-                                                   float *__restrict__ shift, float *__restrict__ den,
-                                                   const float *__restrict__ fold_w, const float *__restrict__ fold_b)
-{
-    const int b = blockIdx.x, c = threadIdx.x, tpt = (N + 63) / 64;
-    double n = 0, mean = 0, M2 = 0;
-    for (int t = 0; t < tpt; ++t) {
-        const float *pp = part + ((size_t)b * tpt + t) * (H * 2) + c * 2;
-        const double nt = (double)(N - t * 64 < 64 ? N - t * 64 : 64), d = (double)pp[0] - mean, tot = n + nt;
-        mean += d * nt / tot;
-        M2 += (double)pp[1] + d * d * n * nt / tot;
-        n = tot;
-    }
-    const float sft = (float)mean * mean_scale[c];
-    const double dm = mean - (double)sft;
-    double var = M2 / N + dm * dm;
-    var = var > 0 ? var : 0;
-    const float dn = sqrtf((float)var + 1e-5f);
-    if (fold_w) {
-        const float sc = fold_w[c] / dn;
-        den[(size_t)b * H + c] = sc;
-        shift[(size_t)b * H + c] = fold_b[c] - sc * sft;
-    } else {
-        shift[(size_t)b * H + c] = sft;
-        den[(size_t)b * H + c] = dn;
-    }
-}
-
-hipError_t launch_gn_finish(const float *stat_part, int B, int N, const float *mean_scale, float *shift, float *den,
-                            const float *fold_w, const float *fold_b, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_gn_finish, dim3(B), dim3(256), 0, s, stat_part, N, mean_scale, shift, den, fold_w, fold_b);
-    return hipGetLastError();
 }
 
 hipError_t launch_gn_stats(const float *u, int B, int N, const float *mean_scale, float *shift, float *den,

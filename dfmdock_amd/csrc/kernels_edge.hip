@@ -1098,21 +1098,29 @@ template <int F16> static hipError_t launch_coord_t(const EdgeKArgs &k, long lon
     return hipGetLastError();
 }
 
+// Small launches: with one node (two tiles) per task the last round of the persistent grid is mostly idle - e.g. B = 8 at
+// N = 600: 4800 nodes over 2048 waves = 3 rounds of 2 tiles, but 9600 tiles = 5 rounds of 1.  Tile tasks when that saves a round;
+// their partial segment sums are added atomically to an agg that must be zero (EdgeArgs::agg_is_zero, or a memset here).
+bool edge_msg_tile_tasks(int B, int N, int K)
+{
+    const int ntile = (K + 31) / 32;
+    if (ntile <= 1) return false;
+    static const int env = [] { const char *e = getenv("DFM_EDGE_SPLIT"); return e ? atoi(e) : -1; }();      // diagnostics: 0 / 1 force
+    if (env >= 0) return env != 0;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const long long tasks = (long long)B * N, waves = (long long)cus * EDGE_WAVES;
+    const long long rounds_node = (tasks + waves - 1) / waves * ntile, rounds_tile = (tasks * ntile + waves - 1) / waves;
+    return rounds_tile < rounds_node;
+}
+
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
     EdgeKArgs k = to_kargs_mfma(a, 0);
     long long tasks = (long long)a.B * a.N;
-    // Small launches: with one node (two tiles) per task the last round of the persistent grid is mostly idle - e.g. B = 8 at
-    // N = 600: 4800 nodes over 2048 waves = 3 rounds of 2 tiles, but 9600 tiles = 5 rounds of 1.  Tile tasks when that saves a round.
-    const int ntile = (a.K + 31) / 32;
-    if (ntile > 1) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        const long long waves = (long long)cus * EDGE_WAVES;
-        const long long rounds_node = (tasks + waves - 1) / waves * ntile, rounds_tile = (tasks * ntile + waves - 1) / waves;
-        static const int env = [] { const char *e = getenv("DFM_EDGE_SPLIT"); return e ? atoi(e) : -1; }();      // diagnostics: 0 / 1 force
-        if (env >= 0 ? env != 0 : rounds_tile < rounds_node) {
-            k.split = 1; tasks *= ntile;
+    if (edge_msg_tile_tasks(a.B, a.N, a.K)) {
+        k.split = 1; tasks *= (a.K + 31) / 32;
+        if (!a.agg_is_zero) {
             hipError_t e = hipMemsetAsync(a.agg, 0, (size_t)a.B * a.N * H * sizeof(float), s);
             if (e != hipSuccess) return e;
         }
