@@ -717,7 +717,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
         e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = coord; e.fout = W.fvec; e.mbuf = W.mbuf;
         e.f16 = layer_f16(l) ? 1 : 0;
-        e.agg_is_zero = (l > 0 && tile_tasks) ? 1 : 0;      // zeroed by the previous layer's node_mlp.0 GEMM
+        e.agg_is_zero = (l > 0 && tile_tasks) ? 1 : 0;      // zeroed by the previous layer's node_mlp.3 GEMM
         e.stamp = (o.profile && l == 2) ? cx->stamp_dev : nullptr;
         // the per-edge message kernel, bracketed by HIP events on this stream when profiling (dfm_get_profile)
         auto message_launch = [&](const EdgeArgs &ea) -> int {
@@ -754,15 +754,15 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         // 16-bit engines: the GEMM leaves per-tile column sums of u behind, so GraphNorm needs no extra pass over u
         const bool fused_stats = o.bf16 && gemm_rows_per_tile() == 64;
         if (fused_stats) { g.stat_part = W.gn_part; g.rows_per_graph = N; }
-        // tile-task message launches add into a zero agg: this GEMM, the only reader of agg, leaves it zeroed for the next layer
-        if (o.bf16 && !last && tile_tasks) g.zero_a1 = 1;
         if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W3_hi, Lw.W3_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         // fused_stats: the statistics are finished in the prologue of the next GEMM (no k_gn_finish launch)
         if (!fused_stats) HIPCHK(launch_gn_stats(W.u, B, N, Lw.gn_ms, W.gn_shift, W.gn_den, o.bf16 ? Lw.gn_w : nullptr, o.bf16 ? Lw.gn_b : nullptr, s));
         std::memset(&g, 0, sizeof(g));
         g.A0 = W.u; g.lda = H; g.K = H; g.pro = 2; g.gn_shift = W.gn_shift; g.gn_den = W.gn_den; g.gn_w = Lw.gn_w;
         g.gn_b = Lw.gn_b; g.rows_per_graph = N;
-        if (fused_stats) { g.gn_part = W.gn_part; g.gn_ms = Lw.gn_ms; } g.W = Lw.W4; g.ldw = H; g.bias = Lw.b4; g.M = M; g.Nout = H;
+        if (fused_stats) { g.gn_part = W.gn_part; g.gn_ms = Lw.gn_ms; }
+        // tile-task message launches add into a zero agg: its last reader (node_mlp.0) is done, this launch leaves it zeroed for the next layer
+        if (o.bf16 && !last && tile_tasks) g.zbuf = W.agg; g.W = Lw.W4; g.ldw = H; g.bias = Lw.b4; g.M = M; g.Nout = H;
         g.epi = 1; g.R = h; g.C = hn; g.ldc = H;
         if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W4_hi, Lw.W4_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         { float *tmp = h; h = hn; hn = tmp; }

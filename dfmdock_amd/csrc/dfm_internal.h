@@ -142,9 +142,10 @@ struct GemmArgs {
     // (mean, M2) pairs of its trajectory (gn_part, written by the previous launch's stat_part) exactly as k_gn_finish does, so small
     // launches do not pay a separate 5 us kernel per layer; gn_ms = mean_scale [256]; gn_shift / gn_den are then unused
     const float *gn_part, *gn_ms;
-    // optional (k_gemm_split, pro 1): zero the A1 rows of the tile once they are staged (A1 = agg: the next layer's tile-task message
-    // launch adds into it atomically and would otherwise need a memset launch)
-    int zero_a1;
+    // optional (k_gemm_split, Nout = 256): every workgroup zeroes its rows x columns block of this [M][256] buffer, which no launch
+    // reads any more (agg after node_mlp.0: the next layer's tile-task message launch adds into it atomically and would otherwise
+    // need a memset launch per layer)
+    float *zbuf;
 };
 hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s);
 // split-bf16 (hi/lo) variant, ~1e-5 relative error; Whi/Wlo = pre-split weights [Nout][ldw] bf16
@@ -176,7 +177,7 @@ struct EdgeArgs {
     float *fout;           // [B][L][3]   (last)
     uint16_t *mbuf;        // [B][L][64][256] 16-bit gated messages (MFMA path, last)
     int f16;               // MFMA operand type: 0 bf16, 1 fp16
-    int agg_is_zero;       // 16-bit kernel with tile tasks: agg is known to be zero (zeroed by the previous layer's node GEMM, GemmArgs::zero_a1)
+    int agg_is_zero;       // 16-bit kernel with tile tasks: agg is known to be zero (zeroed by the previous layer's node_mlp.3 GEMM, GemmArgs::zbuf)
     unsigned long long *stamp;   // diagnostic builds (DFM_EDGE_STAMP): [8 waves][4 phases] cycle sums of workgroup 0, or nullptr
 };
 hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);

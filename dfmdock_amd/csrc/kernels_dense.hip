@@ -185,7 +185,7 @@ __device__ inline void gn_finish_col(const float *__restrict__ part, int b, int 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 union FragB { uint4 u; bf16x8 b; };
-constexpr int SN = 256, SK = 32, SLD = 40;   // output columns per workgroup; K per stage; LDS row stride in bf16
+constexpr int SK = 32, SLD = 40;   // K per stage; LDS row stride in bf16
 
 struct GemmSplitArgs {
     GemmArgs g;
@@ -207,12 +207,17 @@ __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
 // What did pay: the fp16 outputs of the [Wa|Wb] projection converted by the hardware (f2h is 30 instructions of bit manipulation
 // per value: half of that launch) and stored as 16-byte vectors: 200 -> 153 us for that launch, 166 -> 149 us over the three.
 // HALF = 1: epilogue 2 with 16-bit outputs only (Cb and C2b set, no fp32 C2): the [Wa|Wb] projection of the 16-bit engine
-template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmSplitArgs sa)
+// NJ = 1: 64 x 128 tiles (each wave 64 x 32) for launches with fewer workgroups than CUs: a lone workgroup is bound by what ONE CU
+// can pull from L2 / HBM (~55 GB/s: 40 KiB per K-stage = 0.75 us; deeper prefetch or a pipelined loop buy nothing,
+// profiles/r02_exp_gemm_deep.txt, r03_d notes) - twice the workgroups, each with half the weight bytes per stage.  Same MFMA sequence per
+// output element and the same row order in the column statistics: bitwise the same results as NJ = 2.
+template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmSplitArgs sa)
 {
-    constexpr int SM = 64, WN = 4, NJ = 2;      // rows; waves along N; 32-column tiles per wave
+    constexpr int SM = 64, SN = NJ * 128;      // rows; output columns per workgroup (four waves along N, NJ 32-column tiles each)
     const GemmArgs &a = sa.g;
     // operand tiles; the epilogue reuses the space as 4 x 9216 B of transposition buffers
-    constexpr int LDS_U16 = (2 * SM + 2 * SN) * SLD;
+    constexpr int LDS_OPER = (2 * SM + 2 * SN) * SLD, LDS_EPI = 4 * 32 * 72 * 2;      // operand tiles | epilogue staging (4 waves x 32 x ELD floats)
+    constexpr int LDS_U16 = LDS_OPER > LDS_EPI ? LDS_OPER : LDS_EPI;
     __shared__ __attribute__((aligned(16))) uint16_t lds[LDS_U16];
     uint16_t *Ah = lds, *Al = lds + SM * SLD, *Wh = lds + 2 * SM * SLD, *Wl = lds + (2 * SM + SN) * SLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -229,7 +234,7 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
     __shared__ __attribute__((aligned(16))) float gn_s[2 * H];
     const int vb = blockIdx.x;
     int bx = vb, by = blockIdx.y;
-    if (gridDim.y == 1 && a.Nout == 2 * SN) {
+    if (NJ == 2 && gridDim.y == 1 && a.Nout == 2 * SN) {
         const int g16 = bx >> 4, j = bx & 15;
         bx = g16 * 8 + (j & 7); by = j >> 3;
         if (bx * SM >= a.M) return;          // tail of the last group of 8 tiles
@@ -254,6 +259,14 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
             __syncthreads();
         }
     }
+    if (a.zbuf) {      // zero this tile's block of a [M][256] buffer nobody reads any more (agg: see GemmArgs::zbuf)
+        const int zr = tid >> 2;
+        if (row0 + zr < row_end) {
+            float4 *z = reinterpret_cast<float4 *>(a.zbuf + (size_t)(row0 + zr) * H + col0 + (tid & 3) * (SN / 4));
+#pragma unroll
+            for (int q = 0; q < SN / 16; ++q) z[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -270,20 +283,24 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
 
     // registers of the stage being fetched: activations (rows x 8 k) and 4 x 16 B of hi / lo weights
     float4 xa0, xa1;
-    uint4 wh0, wh1, wh2, wh3, wl0, wl1, wl2, wl3;
+    uint4 wh0, wh1, wh2, wh3, wl0, wl1, wl2, wl3;      // NJ = 1: thread = (column tid & 127, hi / lo tid >> 7), wh0..3 only
+    const int wcol = NJ == 2 ? tid : (tid & 127);
+    const uint16_t *wsrc = (NJ == 2 || tid < 128) ? sa.Whi : sa.Wlo;
 #define GEMM_SPLIT_FETCH(K0)                                                                                          \
     {                                                                                                                 \
         const int k_ = (K0) + kg;                                                                                     \
         const float *base_ = (a.pro == 1 && k_ >= halfK) ? a.A1 + (k_ - halfK) : a.A0 + k_;                           \
         const float *s0_ = base_ + gr0 * a.lda;                                                                       \
         xa0 = *reinterpret_cast<const float4 *>(s0_); xa1 = *reinterpret_cast<const float4 *>(s0_ + 4);              \
-        const size_t wbase_ = ((size_t)((K0) / SK) * 4 * a.Nout + col0 + tid) * 8;                                    \
+        const size_t wbase_ = ((size_t)((K0) / SK) * 4 * a.Nout + col0 + wcol) * 8;                                   \
         const size_t wq_ = (size_t)a.Nout * 8;                                                                        \
-        const uint16_t *ph_ = sa.Whi + wbase_, *pl_ = sa.Wlo + wbase_;                                                \
+        const uint16_t *ph_ = wsrc + wbase_, *pl_ = sa.Wlo + wbase_;                                                  \
         wh0 = *reinterpret_cast<const uint4 *>(ph_); wh1 = *reinterpret_cast<const uint4 *>(ph_ + wq_);               \
         wh2 = *reinterpret_cast<const uint4 *>(ph_ + 2 * wq_); wh3 = *reinterpret_cast<const uint4 *>(ph_ + 3 * wq_); \
-        wl0 = *reinterpret_cast<const uint4 *>(pl_); wl1 = *reinterpret_cast<const uint4 *>(pl_ + wq_);                   \
-        wl2 = *reinterpret_cast<const uint4 *>(pl_ + 2 * wq_); wl3 = *reinterpret_cast<const uint4 *>(pl_ + 3 * wq_);     \
+        if constexpr (NJ == 2) {                                                                                      \
+            wl0 = *reinterpret_cast<const uint4 *>(pl_); wl1 = *reinterpret_cast<const uint4 *>(pl_ + wq_);               \
+            wl2 = *reinterpret_cast<const uint4 *>(pl_ + 2 * wq_); wl3 = *reinterpret_cast<const uint4 *>(pl_ + 3 * wq_); \
+        }                                                                                                             \
     }
     auto stage_row = [&](const float4 &v0, const float4 &v1, bool valid, int k, int row) {
         float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -311,7 +328,8 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
         *reinterpret_cast<uint4 *>(&Al[row * SLD + kg]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     };
 
-    const int wu = tid * SLD;   // weights: thread = output column, q = 8-k group (consecutive lanes -> consecutive LDS rows: conflict-free)
+    const int wu = wcol * SLD;   // weights: thread = output column, q = 8-k group (consecutive lanes -> consecutive LDS rows: conflict-free)
+    uint16_t *wdst = (NJ == 2 || tid < 128) ? Wh : Wl;
 #ifdef DFM_GEMM_STAMP
     unsigned long long gs[4] = {0, 0, 0, 0}, gprev = __builtin_amdgcn_s_memtime();
 #define GSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _n = __builtin_amdgcn_s_memtime(); gs[k] += _n - gprev; gprev = _n; __builtin_amdgcn_sched_barrier(0); }
@@ -323,15 +341,12 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
         if (k0) __syncthreads();   // previous stage fully consumed
         GSTAMP(0)                  // [0] MFMA phase + barrier wait
         stage_row(xa0, xa1, rv0, k0 + kg, ar);
-        if (a.zero_a1 && a.pro == 1 && k0 + kg >= halfK && rv0) {      // the staged values are in registers: the loads have returned
-            float *z = const_cast<float *>(a.A1) + (k0 + kg - halfK) + gr0 * a.lda;
-            *reinterpret_cast<float4 *>(z) = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(z + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<uint4 *>(&wdst[wu]) = wh0; *reinterpret_cast<uint4 *>(&wdst[wu + 8]) = wh1;
+        *reinterpret_cast<uint4 *>(&wdst[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&wdst[wu + 24]) = wh3;
+        if constexpr (NJ == 2) {
+            *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
+            *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
         }
-        *reinterpret_cast<uint4 *>(&Wh[wu]) = wh0; *reinterpret_cast<uint4 *>(&Wh[wu + 8]) = wh1;
-        *reinterpret_cast<uint4 *>(&Wh[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&Wh[wu + 24]) = wh3;
-        *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
-        *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
         GSTAMP(1)                  // [1] waiting for the fetched registers + conversion + LDS stores
         __syncthreads();
         GSTAMP(2)                  // [2] barrier after staging
@@ -375,7 +390,7 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jp = 0; jp < NJ / 2; ++jp) {
+        for (int jp = 0; jp < (NJ + 1) / 2; ++jp) {
             // residual rows of this pass, requested before the transposition below instead of one dependent load per store
             float4 res[8];
             if (a.epi == 1) {
@@ -383,11 +398,11 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
                 for (int q = 0; q < 8; ++q) {
                     const size_t row = (size_t)row0 + wm * 64 + i * 32 + q * 4 + er;
                     const int col = col0 + (wn * NJ + jp * 2) * 32 + ec;
-                    res[q] = row < (size_t)row_end ? *reinterpret_cast<const float4 *>(a.R + row * a.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    res[q] = (row < (size_t)row_end && ec < NJ * 32) ? *reinterpret_cast<const float4 *>(a.R + row * a.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
+            for (int jj = 0; jj < (NJ < 2 ? NJ : 2); ++jj) {
                 const int j = jp * 2 + jj;
                 const float bias = a.bias ? a.bias[col0 + (wn * NJ + j) * 32 + l31] : 0.f;
 #pragma unroll
@@ -408,7 +423,7 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
                     const float4 v1 = *reinterpret_cast<const float4 *>(est + lr * ELD + ec8 + 4);
                     const size_t row = (size_t)row0 + wm * 64 + i * 32 + lr;
                     const int col = (col0 < H ? col0 : col0 - H) + (wn * NJ + jp * 2) * 32 + ec8;
-                    if (row >= (size_t)row_end) continue;
+                    if (row >= (size_t)row_end || ec8 >= NJ * 32) continue;
                     uint4 o;
                     o.x = pack_h2_sat(v0.x, v0.y); o.y = pack_h2_sat(v0.z, v0.w);
                     o.z = pack_h2_sat(v1.x, v1.y); o.w = pack_h2_sat(v1.z, v1.w);
@@ -421,7 +436,7 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
                 const float4 v = *reinterpret_cast<const float4 *>(est + lr * ELD + ec);
                 const size_t row = (size_t)row0 + wm * 64 + i * 32 + lr;
                 const int col = col0 + (wn * NJ + jp * 2) * 32 + ec;
-                if (row >= (size_t)row_end) continue;
+                if (row >= (size_t)row_end || ec >= NJ * 32) continue;
                 {
                     if (a.stat_part) {
                         if (st_n == 0.f) { st_p[0] = v.x; st_p[1] = v.y; st_p[2] = v.z; st_p[3] = v.w; }
@@ -483,8 +498,8 @@ template <int HALF> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmS
                     }
                     ne = nt;
                 }
-                if (er == 0) {       // only this lane's merge order is ever read: deterministic, the same for every trajectory
-                    const int c = col0 + wn * 64 + ec + e;
+                if (er == 0 && ec < NJ * 32) {       // only this lane's merge order is ever read: deterministic, the same for every trajectory
+                    const int c = col0 + wn * (NJ * 32) + ec + e;
                     sp[c * 2] = mean;
                     sp[c * 2 + 1] = M2;
                 }
@@ -498,18 +513,37 @@ int gemm_rows_per_tile() { return 64; }
 
 hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s)
 {
+    constexpr int SN = 256;
     if (a.K % SK != 0 || a.Nout % SN != 0 || (a.pro == 1 && (a.K / 2) % SK != 0) || a.lda % 4 != 0 || a.ldc % 4 != 0)
         return hipErrorInvalidValue;
     GemmSplitArgs sa;
     sa.g = a; sa.Whi = Whi; sa.Wlo = Wlo;
     if (a.stat_part && (a.Nout != SN || a.rows_per_graph < 1 || a.M % a.rows_per_graph != 0)) return hipErrorInvalidValue;
     if (a.pro == 2 && (a.rows_per_graph < 1 || a.M % a.rows_per_graph != 0)) return hipErrorInvalidValue;
+    if (a.zbuf && a.Nout != SN) return hipErrorInvalidValue;
+    const int row_tiles = (a.stat_part || a.pro == 2) ? (a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64) : (a.M + 63) / 64;
+    // fewer 64 x 256 workgroups than two per CU: 64 x 128 tiles (NJ = 1) - a lone workgroup is bound by its CU's own memory pipe
+    static const int narrow_max = [] {
+        const char *e = getenv("DFM_GEMM_NARROW_MAXWG");      // diagnostics: 64 x 256 workgroup count below which NJ = 1 is used (0 = never)
+        if (e) return atoi(e);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        return 2 * cus;      // measured (profiles/r03_d_small_narrow.txt): +17 % at B = 1, +8.5 % at B = 8, +1.5 % at B = 32, even at B = 64 (300+300)
+    }();
+    const bool narrow = (long long)row_tiles * (a.Nout / SN) < narrow_max;
+    const bool half = a.epi == 2 && a.Cb && a.C2b && !a.C2;
+    if (narrow) {
+        const dim3 grid(row_tiles, a.Nout / 128);
+        if (half) hipLaunchKernelGGL((k_gemm_split<1, 1>), grid, dim3(256), 0, s, sa);
+        else hipLaunchKernelGGL((k_gemm_split<0, 1>), grid, dim3(256), 0, s, sa);
+        return hipGetLastError();
+    }
     dim3 grid;
-    if (a.stat_part || a.pro == 2) grid = dim3((a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64), a.Nout / SN);   // row tiles aligned to the trajectories
+    if (a.stat_part || a.pro == 2) grid = dim3(row_tiles, a.Nout / SN);   // row tiles aligned to the trajectories
     else if (a.Nout == 2 * SN) grid = dim3((((a.M + 63) / 64 + 7) / 8) * 16, 1);      // paired column blocks, see the block mapping in the kernel
     else grid = dim3((a.M + 63) / 64, a.Nout / SN);
-    if (a.epi == 2 && a.Cb && a.C2b && !a.C2) hipLaunchKernelGGL(k_gemm_split<1>, grid, dim3(256), 0, s, sa);
-    else hipLaunchKernelGGL(k_gemm_split<0>, grid, dim3(256), 0, s, sa);
+    if (half) hipLaunchKernelGGL((k_gemm_split<1, 2>), grid, dim3(256), 0, s, sa);
+    else hipLaunchKernelGGL((k_gemm_split<0, 2>), grid, dim3(256), 0, s, sa);
     return hipGetLastError();
 }
 

@@ -190,14 +190,15 @@ def make_records(complex_id: int, traj_ids, result) -> np.ndarray:
     return rec
 
 
-def gather_records(records: np.ndarray, device=None) -> np.ndarray:
-    """all_gather variable-length record blocks from every rank; returns the concatenation (rank order)."""
+def gather_records(records: np.ndarray, device=None, force_collective: bool = False) -> np.ndarray:
+    """all_gather variable-length record blocks from every rank; returns the concatenation (rank order).  A one-rank group skips
+    the collectives unless `force_collective` (the one-rank RCCL test runs them on purpose)."""
     g = _group
     if g.backend == "file":
         return _file_gather(records, g)
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return records
     world = dist.get_world_size()
     grp = g.data_group if g.backend == "nccl" else None          # None = the default group (gloo when init() made it)

@@ -9,7 +9,9 @@ rendezvous over gloo (the 8-GPU node runs the same code over RCCL: backend "nccl
     ends with the identical energy-ranked table, rank 0 writes the complete CSV; over 1 complex on 2 ranks: its trajectories
     are split between the ranks instead.
 
-RCCL itself is not executed by any test here (one GPU); the 8-GPU node is the driver's.
+RCCL between GPUs is not executed by any test here (one GPU; the 8-GPU node is the driver's) - but a ONE-rank RCCL communicator is:
+`test_rccl_one_rank_record_gather` builds the "nccl" process group on the box's GPU and runs the record gather of
+dfmdock_amd.distributed through it (library load, communicator init, all_gather / all_reduce kernels on the MI355X).
 """
 import csv
 import json
@@ -131,3 +133,31 @@ def test_run_set_splits_trajectories_when_complexes_are_few(tmp_path):
     assert sorted(int(r[1]) for r in a["ranked"]["0"]) == [0, 1, 2, 3, 4]
     got = list(csv.DictReader(open(tmp_path / "set.csv")))
     assert [(r["id"], r["index"]) for r in got] == [("SYN0", str(i)) for i in range(5)]
+
+
+def test_rccl_one_rank_record_gather():
+    """RCCL itself on the test box: a one-rank "nccl" group (RCCL refuses two ranks on one device, a single rank it serves), the
+    probe all_reduce of distributed.init() and the padded two-phase all_gather of trajectory records that closes a multi-GPU job
+    (inference_base.py:644-657), on device tensors.  A failure to load or initialise RCCL on this image shows up here, not on the
+    8-GPU node."""
+    code = textwrap.dedent("""
+        import datetime, os, sys
+        import numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        from dfmdock_amd import distributed as D
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))
+        probe = torch.ones(1, device="cuda")
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        assert float(probe.item()) == 1.0
+        D._group = D.Group("nccl", 0, 1, data_group=dist.group.WORLD)
+        rec = np.arange(5 * D.RECORD_WIDTH, dtype=np.float32).reshape(5, D.RECORD_WIDTH)
+        out = D.gather_records(rec, force_collective=True)
+        assert dist.get_backend() == "nccl" and out.shape == rec.shape and (out == rec).all(), out.shape
+        dist.destroy_process_group()
+        print("RCCL_OK", torch.cuda.get_device_name(0))
+    """ % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port() + 301), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout.decode(), p.stderr.decode()[-3000:]
