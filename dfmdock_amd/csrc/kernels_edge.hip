@@ -480,7 +480,8 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
     // this lane's half for ds_bpermute
     const int rs_j = rs_index(lane), rs_row = (rs_j & 3) + 8 * (rs_j >> 2) + 4 * h, bp_base = (lane & 32) * 4;
 
-    unsigned tt = (unsigned)slot * EDGE_WAVES + wave;
+    unsigned tt = (unsigned)wave * (unsigned)wg_per_xcd + (unsigned)slot;      // wave-major: a launch with fewer tasks than waves spreads over ALL workgroups
+                                                                               // (a few waves each, a SIMD to themselves) instead of filling the first ones
     int b = 0, i = 0, mt = 0;
     if (!next_task(tt, b, i, mt)) return;
 
@@ -909,7 +910,8 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_coord(EdgeKArgs p)
             a[kk] = make_uint4(v.x, v.y, v.z, v.w);
         }
     };
-    unsigned tt = (unsigned)slot * EDGE_WAVES + wave;
+    unsigned tt = (unsigned)wave * (unsigned)wg_per_xcd + (unsigned)slot;      // wave-major: a launch with fewer tasks than waves spreads over ALL workgroups
+                                                                               // (a few waves each, a SIMD to themselves) instead of filling the first ones
     int b = 0, i = 0, mt = 0;
     while (tt < ntask && !task_node(tt, b, i)) tt += tstride;
     if (tt >= ntask) return;
@@ -1071,7 +1073,7 @@ static int persistent_grid(long long wave_tasks)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    long long wgs = (wave_tasks + EDGE_WAVES - 1) / EDGE_WAVES;
+    long long wgs = wave_tasks;      // small launches: one workgroup per CU as soon as there is a task for it (tasks go wave-major)
     long long g = wgs < cus ? wgs : cus;
     g = (g + 7) / 8 * 8;   // multiple of the XCD count
     return (int)g;

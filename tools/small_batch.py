@@ -10,7 +10,7 @@ engine.set_device(0)
 model = engine.Model(pack_blob(make_random_weights(0)))
 cx = make_complex(300, 300, seed=1)
 gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-for B in (1, 2, 4, 8, 16, 32, 64):
+for B in tuple(int(x) for x in os.environ.get("BS", "1,2,4,8,16,32,64").split(",")):
     gx.sample(B=B, num_steps=2, seed=1, bf16=True)
     best = 1e9
     for rep in range(3):
