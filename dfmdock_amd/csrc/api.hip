@@ -657,7 +657,7 @@ extern "C" const char *dfm_config_string(void)
         c += ", fp32 accumulate / geometry / GraphNorm statistics / heads / SDE step";
         c += "; build: TAB_MERGE=" + std::to_string((int)DFM_TAB_MERGE);
         std::string env;
-        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_LIB"}) {
+        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_GEMM_NARROW_MAXWG", "DFM_LIB"}) {
             const char *e = getenv(k);
             if (e) env += std::string(env.empty() ? "" : " ") + k + "=" + e;
         }
@@ -670,6 +670,8 @@ extern "C" const char *dfm_config_string(void)
 struct FwdOpts {
     bool bf16 = false, f16 = false, want_energy = false, profile = false;   // bf16: 16-bit MFMA engine; f16: ... with fp32 A_i
     bool bf16_ops = false;                // bf16 MFMA operands in every layer but the last (DFM_F_BF16_OPS)
+    bool need_node_out = true;            // false: nobody reads the final node features (no energy / ires / debug tap) - the last layer then
+                                          // computes the messages of the ligand nodes only (all the coordinate update reads) and no node model
     const int32_t *edges_dev = nullptr;   // [B][N][K] already on device (or nullptr = sample natively)
     int64_t edges_pitch = 0;              // elements between trajectories in edges_dev
     uint64_t seed = 0;
@@ -702,11 +704,14 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
     }
     float *h = W.h, *hn = W.h2;
     const int M = B * N;
-    const bool tile_tasks = o.bf16 && edge_msg_tile_tasks(B, N, K);
+    const bool tile_tasks = o.bf16 && edge_msg_tile_tasks(B, N, K);      // (a ligand-only last layer decides for itself and zeroes agg if it must)
     for (int l = 0; l < depth; ++l) {
         const LayerDev &Lw = m->layers[l];
         const bool last = (l == depth - 1);
         const bool coord = last && !pair_family;       // EGNN_Net: update_coords = False in every layer
+        // Score_Net reads the last layer's node outputs only in its energy / ires heads (score_net_mlsb.py:383-390); the force comes
+        // from pos_out of the LIGAND nodes (:396-398), i.e. from the last layer's messages of ligand nodes alone
+        const bool lig_only = coord && !o.need_node_out;
         EdgeArgs e;
         std::memset(&e, 0, sizeof(e));
         if (l == 0) { e.A = o.bf16 ? cx->A0s : cx->A0; e.Bm = cx->Bm0; e.Bmb = cx->Bmb0; e.ab_bstride = 0; }
@@ -717,6 +722,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         e.edges = W.edges; e.codes = W.codes; e.radial = W.radial; e.ca4 = W.ca4;
         e.B = B; e.N = N; e.R = R; e.K = K; e.lw = &Lw; e.agg = W.agg; e.last = coord; e.fout = W.fvec; e.mbuf = W.mbuf;
         e.f16 = layer_f16(l) ? 1 : 0;
+        e.lig_only = lig_only ? 1 : 0;
         e.agg_is_zero = (l > 0 && tile_tasks) ? 1 : 0;      // zeroed by the previous layer's node_mlp.3 GEMM
         e.stamp = (o.profile && l == 2) ? cx->stamp_dev : nullptr;
         // the per-edge message kernel, bracketed by HIP events on this stream when profiling (dfm_get_profile)
@@ -735,7 +741,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             if (o.profile) {
                 HIPCHK(hipEventRecord(e1, s));
                 cx->prof.edge_kernel_launches += 1;
-                cx->prof.edge_rows += (int64_t)ea.B * N * K;
+                cx->prof.edge_rows += (int64_t)ea.B * (ea.lig_only ? N - R : N) * K;
             }
             return DFM_OK;
         };
@@ -746,6 +752,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             if (rc2) return rc2;
             if (coord && o.bf16) HIPCHK(launch_coord_bf16(e, s));
         }
+        if (lig_only) break;      // the node model of the last layer feeds heads nobody asked for
         // node_model (egnn.py:106-116): u = Linear(cat[h, agg]); GraphNorm; SiLU; Linear; residual
         GemmArgs g;
         std::memset(&g, 0, sizeof(g));
@@ -778,7 +785,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             if (o.bf16) HIPCHK(launch_gemm_split(g, Ln.Wab_hi, Ln.Wab_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         }
     }
-    if (h != W.h) {   // keep the final node features in W.h (depth odd)
+    if (h != W.h && o.need_node_out) {   // keep the final node features in W.h (depth odd)
         HIPCHK(hipMemcpyAsync(W.h, h, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     if (pair_family) {
@@ -905,6 +912,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     FwdOpts o;
     o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
     o.edges_pitch = (int64_t)N * K; o.seed = seed; o.h_first_out = h_first_dev;
+    o.need_node_out = want_energy || want_ires || want_dist || out->h_last != nullptr;
     HIPCHK(hipEventRecord(cx->ev_total[0], s));
     rc = enqueue_forward(cx, B, o);
     if (rc == DFM_OK) {
@@ -1034,7 +1042,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
         hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, W.t_dev, ts[i], B);
         HIPCHK(hipGetLastError());
         o.edges_dev = ed_d ? ed_d + (size_t)i * N * K : nullptr;
-        o.want_energy = step_energy;
+        o.want_energy = step_energy; o.need_node_out = step_energy;
         rc = enqueue_forward(cx, B, o);
         if (rc) return rc;
         HeadArgs ha;
@@ -1059,7 +1067,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     }
     // final evaluation of the last pose, with the energy head (inference_base.py:463-466); same t as the last step
     o.edges_dev = ed_d ? ed_d + (size_t)num_steps * N * K : nullptr;
-    o.want_energy = true;
+    o.want_energy = true; o.need_node_out = true;
     rc = enqueue_forward(cx, B, o);
     if (rc) return rc;
     {

@@ -177,6 +177,7 @@ struct EdgeArgs {
     float *fout;           // [B][L][3]   (last)
     uint16_t *mbuf;        // [B][L][64][256] 16-bit gated messages (MFMA path, last)
     int f16;               // MFMA operand type: 0 bf16, 1 fp16
+    int lig_only;          // last layer, node outputs not wanted: messages of the LIGAND nodes only (the coordinate update reads nothing else)
     int agg_is_zero;       // 16-bit kernel with tile tasks: agg is known to be zero (zeroed by the previous layer's node_mlp.3 GEMM, GemmArgs::zbuf)
     unsigned long long *stamp;   // diagnostic builds (DFM_EDGE_STAMP): [8 waves][4 phases] cycle sums of workgroup 0, or nullptr
 };

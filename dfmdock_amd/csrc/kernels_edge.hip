@@ -54,6 +54,8 @@ struct EdgeKArgs {
     unsigned long long *stamp;   // DFM_EDGE_STAMP builds only: per-phase cycle sums of workgroup 0 (tools/edge_phases.py)
     const uint16_t *Ah;          // k_edge_msg<0, 1>: A as fp16
     int split;                   // k_edge_msg: 1 = a wave task is one TILE (small launches), agg is pre-zeroed and added to atomically
+    int node0, nodes;            // message kernels: the tasks cover nodes node0 .. node0 + nodes - 1 of every trajectory (all of them, or - last
+                                 // layer when nobody reads the node outputs - the ligand nodes only: EdgeArgs::lig_only)
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
     const int c = threadIdx.x, lane = c & 63, wave = c >> 6;
     const long long node = blockIdx.x;
     const int b = (int)(node / p.N), i = (int)(node % p.N), K = p.K;
+    if (i < p.node0) return;      // lig_only: receptor nodes are not needed (block-uniform)
     const size_t ebase = (size_t)node * K;
     if (c < 64) {
         const bool v = c < K;
@@ -446,7 +449,7 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
     // forms produce bitwise the same agg: per tile x_t = inv_s * (sum over its rows), agg = x_0 + x_1 (two addends: commutative).
     const int K = p.K, ntile = (K + 31) >> 5;
     const bool split = p.split != 0;
-    const int NT = split ? p.N * ntile : p.N;
+    const int NT = split ? p.nodes * ntile : p.nodes;
     const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;
     const int NTc = (NT + nsplit - 1) / nsplit;
     const int U = p.B * nsplit;
@@ -458,8 +461,9 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
         const int u = xcd + 8 * (int)tq;
         b = __builtin_amdgcn_readfirstlane(u / nsplit);
         const int idx = __builtin_amdgcn_readfirstlane((u % nsplit) * NTc + (int)tr);
-        i = split ? idx / ntile : idx;
-        mt = split ? idx - i * ntile : 0;
+        const int il = split ? idx / ntile : idx;
+        mt = split ? idx - il * ntile : 0;
+        i = p.node0 + il;
         return idx < NT;
     };
     auto next_task = [&](unsigned &tt, int &b, int &i, int &mt) -> bool {      // first valid task at or after tt
@@ -1041,6 +1045,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.Wf = reinterpret_cast<const uint4 *>(w->W2f); k.att_b = w->att_b;
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
     k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.stamp = a.stamp; k.split = 0;
+    k.node0 = a.lig_only ? a.R : 0; k.nodes = a.lig_only ? a.N - a.R : a.N;
     k.Ah = a.Ah;
     return k;
 }
@@ -1103,7 +1108,7 @@ template <int F16> static hipError_t launch_coord_t(const EdgeKArgs &k, long lon
 // Small launches: with one node (two tiles) per task the last round of the persistent grid is mostly idle - e.g. B = 8 at
 // N = 600: 4800 nodes over 2048 waves = 3 rounds of 2 tiles, but 9600 tiles = 5 rounds of 1.  Tile tasks when that saves a round;
 // their partial segment sums are added atomically to an agg that must be zero (EdgeArgs::agg_is_zero, or a memset here).
-bool edge_msg_tile_tasks(int B, int N, int K)
+bool edge_msg_tile_tasks(int B, int N /* nodes with a task per trajectory */, int K)
 {
     const int ntile = (K + 31) / 32;
     if (ntile <= 1) return false;
@@ -1119,8 +1124,8 @@ bool edge_msg_tile_tasks(int B, int N, int K)
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 {
     EdgeKArgs k = to_kargs_mfma(a, 0);
-    long long tasks = (long long)a.B * a.N;
-    if (edge_msg_tile_tasks(a.B, a.N, a.K)) {
+    long long tasks = (long long)a.B * k.nodes;
+    if (edge_msg_tile_tasks(a.B, k.nodes, a.K)) {
         k.split = 1; tasks *= (a.K + 31) / 32;
         if (!a.agg_is_zero) {
             hipError_t e = hipMemsetAsync(a.agg, 0, (size_t)a.B * a.N * H * sizeof(float), s);

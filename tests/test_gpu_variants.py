@@ -347,3 +347,28 @@ def test_guards_and_optional_heads(blob):
     assert "ires" in a and "ires" not in b and a["ires"].shape == (60, 1)
     for k in ("tr_score", "rot_score", "f", "energy"):
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+def test_ligand_only_last_layer_changes_nothing(prec, model):
+    """When nobody reads the final node features (no energy / ires / debug tap) the last layer computes the messages of the ligand
+    nodes only and skips its node model (score_net_mlsb.py:383-398: the force needs pos_out of the ligand nodes alone).  f and both
+    scores must be bitwise what the full evaluation gives - on a 64+48 complex (node tasks) and at B = 1 (tile tasks), and a sampler
+    run without traces (ligand-only in its 40 step evaluations) must end on the bitwise same pose as one with traces (full)."""
+    from dfmdock_amd import engine
+    from dfmdock_amd.synthetic import make_complex
+    kw = dict(bf16=prec == "bf16", f16=prec == "f16")
+    for (R, L, B) in [(64, 48, 3), (24, 16, 1), (129, 67, 2)]:
+        cx = make_complex(R, L, seed=11)
+        gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+        rng = np.random.default_rng(R)
+        poses = np.stack([cx["lig_pos"] + rng.normal(0, 0.7, 3).astype(np.float32) for _ in range(B)])
+        full = gx.score(poses, 0.4, seed=5, energy=True, debug=True)
+        lean = gx.score(poses, 0.4, edges=full["edges"], **kw)
+        ref = gx.score(poses, 0.4, edges=full["edges"], energy=True, **kw)
+        for k in ("f", "tr_score", "rot_score"):
+            assert (lean[k] == ref[k]).all(), (R, L, B, k)
+        s_full = gx.sample(B=B, num_steps=6, seed=9, trace=True, **kw)
+        s_lean = gx.sample(B=B, num_steps=6, seed=9, **kw)
+        assert (s_full["lig_pos"] == s_lean["lig_pos"]).all() and (s_full["energy"] == s_lean["energy"]).all(), (R, L, B)
+        gx.close()
