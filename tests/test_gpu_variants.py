@@ -372,3 +372,38 @@ def test_ligand_only_last_layer_changes_nothing(prec, model):
         s_lean = gx.sample(B=B, num_steps=6, seed=9, **kw)
         assert (s_full["lig_pos"] == s_lean["lig_pos"]).all() and (s_full["energy"] == s_lean["energy"]).all(), (R, L, B)
         gx.close()
+
+
+def test_narrow_gemm_tiles_equal_wide_tiles_bitwise(tmp_path):
+    """k_gemm_split runs 64 x 128 tiles for launches below two workgroups per CU and 64 x 256 tiles above: the same MFMA sequence per
+    output element and the same row order in the GraphNorm column statistics, so the choice (a function of the batch size) must not
+    show in a single bit - of a score evaluation (node features of the first and last layer included) or of a sampled pose.
+    DFM_GEMM_NARROW_MAXWG forces the form (read once per process: subprocesses); B = 1 and B = 7 also cross the tile-task threshold."""
+    import subprocess, sys, textwrap
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {ROOT!r})
+        from dfmdock_amd import engine
+        from dfmdock_amd.synthetic import make_complex
+        from dfmdock_amd.weights import make_random_weights, pack_blob
+        engine.set_device(0)
+        model = engine.Model(pack_blob(make_random_weights(0)))
+        cx = make_complex(120, 94, seed=3)
+        gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+        B = int(sys.argv[2])
+        r = gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.5, seed=5, bf16=True, energy=True, debug=True)
+        s = gx.sample(B=B, num_steps=5, seed=4, bf16=True)
+        out = {{k: r[k][0] for k in ("f", "tr_score", "rot_score", "energy", "edges", "h_first", "h_last")}}
+        out.update(pose=s["lig_pos"][0], final_energy=s["energy"][0])
+        np.savez(sys.argv[1], **out)
+    """))
+    outs = {}
+    for tag, env, B in (("wide1", "0", 1), ("narrow1", "1000000", 1), ("wide7", "0", 7), ("narrow7", "1000000", 7)):
+        p = subprocess.run([sys.executable, str(script), str(tmp_path / f"{tag}.npz"), str(B)],
+                           env=dict(os.environ, DFM_GEMM_NARROW_MAXWG=env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()[-2000:]
+        outs[tag] = np.load(tmp_path / f"{tag}.npz")
+    for tag in ("narrow1", "wide7", "narrow7"):
+        for k in outs["wide1"].files:
+            assert (outs[tag][k] == outs["wide1"][k]).all(), (tag, k)
