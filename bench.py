@@ -253,6 +253,10 @@ def main():
             "config": {"workload": workload_label(args),
                        "trajectories_per_gpu": B, "num_steps": args.num_steps, "parallelism": f"traj-shard x{world}",
                        "weights": "random-init (seeded generator; trained checkpoint not in the reference)",
+                       "work": "41 score evaluations per trajectory through dfm_sample: the 40 step evaluations return f and the two scores "
+                               "(all the sampler reads, inference_base.py:425-448), so their last layer runs over the ligand nodes only and "
+                               "without its node model - bitwise the same f / scores as the full evaluation (tests/test_gpu_variants.py); "
+                               "the final evaluation runs in full with the energy head",
                        "precision": (("16-bit MFMA engine" + (" with fp32 A_i (DFM_F_F16)" if f16 else "") + ": ") if mfma16 else "fp32 engine; library plan: ")
                                     + engine.config_string(),
                        "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DFM_") and k not in

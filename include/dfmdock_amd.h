@@ -106,7 +106,10 @@ typedef struct {
     int32_t *num_clashes; /* [B]      (needs DFM_F_ENERGY)                              */
     float *f;             /* [B,L,3]  per-ligand-residue force                          */
     /* debug / parity taps */
-    float *h_last;        /* [B,N,H]  node features after the last layer                */
+    float *h_last;        /* [B,N,H]  node features after the last layer.  They feed the energy / ires / dist heads only
+                                      (score_net_mlsb.py:383-390): a call that asks for none of those and passes h_last = NULL
+                                      computes the last layer for the ligand nodes alone (all that f needs, :396-398) -
+                                      bitwise the same f / tr_score / rot_score                               */
     float *h_first;       /* [B,N,H]  node features after the first layer               */
     int32_t *edges;       /* [B,N,K]  edge list actually used                           */
     uint32_t *edge_codes; /* [B,N,K]  packed feature bins: d | omega<<6 | theta<<11 | phi<<16 | relpos<<20 */
