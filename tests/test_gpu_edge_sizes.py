@@ -70,3 +70,34 @@ def test_degenerate_geometry_fp32_vs_oracle(blob):
         r16 = gx.score(cx["lig_pos"], 0.5, edges=r["edges"], energy=True, **kw)
         assert np.isfinite(r16["f"]).all() and rel_inf(r16["f"][0], o["f"]) < 2e-2
     gx.close(); m.close()
+
+
+def test_randomised_launch_shapes(blob):
+    """Random complex and batch sizes on both sides of every launch-shape threshold (tile tasks / node tasks in the message kernel,
+    64 x 128 / 64 x 256 node-GEMM tiles, partial last rounds of the persistent kernels, ligand-only / full last layer): the 16-bit
+    engine's force stays within the 16-bit gate of the fp32 engine on the same graph, an evaluation without node-level heads is
+    bitwise the full one, and trajectory 0 of a batch is bitwise the B = 1 trajectory (tools/stress_sizes.py is the long form)."""
+    from dfmdock_amd import engine
+    from dfmdock_amd.synthetic import make_complex
+    engine.set_device(0)
+    model = engine.Model(blob)
+    rng = np.random.default_rng(7)
+    for it in range(10):
+        R, L = int(rng.integers(3, 300)), int(rng.integers(2, 200))
+        B = int(rng.choice([1, 2, 5, 8, 13, 33, 70]))
+        B = max(1, min(B, 30000 // (R + L)))
+        cx = make_complex(R, L, seed=200 + it)
+        gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+        poses = np.stack([cx["lig_pos"] + rng.normal(0, 1.0, 3).astype(np.float32) for _ in range(B)])
+        ref = gx.score(poses, 0.3, seed=it, energy=True, debug=True)
+        full = gx.score(poses, 0.3, edges=ref["edges"], energy=True, bf16=True)
+        lean = gx.score(poses, 0.3, edges=ref["edges"], bf16=True)
+        for k in ("f", "tr_score", "rot_score"):
+            assert (full[k] == lean[k]).all(), (R, L, B, k)
+        dev = np.abs(full["f"].astype(np.float64) - ref["f"]).max() / max(np.abs(ref["f"]).max(), 1e-30)
+        assert dev < 1e-2 and abs(float(np.abs(full["energy"] - ref["energy"]).max())) < 3e-2, (R, L, B, dev)
+        s1 = gx.sample(B=B, num_steps=3, seed=it, bf16=True)
+        s2 = gx.sample(B=1, num_steps=3, seed=it, bf16=True)
+        assert np.isfinite(s1["lig_pos"]).all() and (s1["lig_pos"][0] == s2["lig_pos"][0]).all(), (R, L, B)
+        gx.close()
+    model.close()
