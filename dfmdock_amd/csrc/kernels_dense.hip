@@ -475,7 +475,7 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
         }
 #ifdef DFM_GEMM_STAMP
     GSTAMP(3)                      // [3] epilogue
-    if (vb == 7 * 8 + 1536 && tid == 0 && a.C) {       // one mid-grid workgroup reports (debug buffer = first floats of ... stderr-free: printf)
+    if (vb == (gridDim.x > 2048 ? 7 * 8 + 1536 : 3) && blockIdx.y == 0 && tid == 0 && a.C) {       // one mid-grid workgroup reports (debug buffer = first floats of ... stderr-free: printf)
         printf("gemm stamp K=%d Nout=%d pro=%d epi=%d: mfma+barrier %llu  fetch-wait+stage %llu  barrier2 %llu  epilogue %llu cycles\n",
                a.K, a.Nout, a.pro, a.epi, gs[0], gs[1], gs[2], gs[3]);
     }
