@@ -336,6 +336,11 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
 #else
 #define GSTAMP(k)
 #endif
+    // the epilogue's bias values, requested now: as a load in the epilogue they are a dependent L2 round trip at the head of every
+    // tile's store phase (small launches have no other workgroup on the CU to hide it)
+    float bias_r[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bias_r[j] = a.bias ? a.bias[col0 + (wn * NJ + j) * 32 + l31] : 0.f;
     GEMM_SPLIT_FETCH(0)
     for (int k0 = 0; k0 < a.K; k0 += SK) {
         if (k0) __syncthreads();   // previous stage fully consumed
@@ -404,7 +409,7 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
 #pragma unroll
             for (int jj = 0; jj < (NJ < 2 ? NJ : 2); ++jj) {
                 const int j = jp * 2 + jj;
-                const float bias = a.bias ? a.bias[col0 + (wn * NJ + j) * 32 + l31] : 0.f;
+                const float bias = bias_r[j];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     est[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * ELD + jj * 32 + l31] = acc[i][j][r] + bias;
