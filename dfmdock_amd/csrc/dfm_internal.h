@@ -96,6 +96,18 @@ struct PairHeadDev {
 };
 
 constexpr int MAX_DEVICES = 64;
+// CU count of the current device, queried once per device (launch helpers ask on every launch)
+inline int device_cus()
+{
+    static std::atomic<int> cache[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 256;
+    int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cache[dev].store(c, std::memory_order_relaxed);
+    return c;
+}
 // The opt-in to more than 64 KiB of dynamic LDS is a per-device function attribute: remember it per device (atomic flags:
 // two host threads may drive two GPUs)
 inline hipError_t ensure_lds_attr(const void *fn, int bytes, std::atomic<bool> (&done)[MAX_DEVICES])

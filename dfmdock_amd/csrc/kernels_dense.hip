@@ -531,9 +531,7 @@ hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint1
     static const int narrow_max = [] {
         const char *e = getenv("DFM_GEMM_NARROW_MAXWG");      // diagnostics: 64 x 256 workgroup count below which NJ = 1 is used (0 = never)
         if (e) return atoi(e);
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        return 2 * cus;      // measured (profiles/r03_d_small_narrow.txt): +17 % at B = 1, +8.5 % at B = 8, +1.5 % at B = 32, even at B = 64 (300+300)
+        return 2 * device_cus();      // measured (profiles/r03_d_small_narrow.txt): +17 % at B = 1, +8.5 % at B = 8, +1.5 % at B = 32, even at B = 64 (300+300)
     }();
     const bool narrow = (long long)row_tiles * (a.Nout / SN) < narrow_max;
     const bool half = a.epi == 2 && a.Cb && a.C2b && !a.C2;

@@ -1075,9 +1075,7 @@ hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s)
 
 static int persistent_grid(long long wave_tasks)
 {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int cus = device_cus();
     long long wgs = wave_tasks;      // small launches: one workgroup per CU as soon as there is a task for it (tasks go wave-major)
     long long g = wgs < cus ? wgs : cus;
     g = (g + 7) / 8 * 8;   // multiple of the XCD count
@@ -1114,8 +1112,7 @@ bool edge_msg_tile_tasks(int B, int N /* nodes with a task per trajectory */, in
     if (ntile <= 1) return false;
     static const int env = [] { const char *e = getenv("DFM_EDGE_SPLIT"); return e ? atoi(e) : -1; }();      // diagnostics: 0 / 1 force
     if (env >= 0) return env != 0;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int cus = device_cus();
     const long long tasks = (long long)B * N, waves = (long long)cus * EDGE_WAVES;
     const long long rounds_node = (tasks + waves - 1) / waves * ntile, rounds_tile = (tasks * ntile + waves - 1) / waves;
     return rounds_tile < rounds_node;
