@@ -8,7 +8,7 @@ the timed region; one call returns only ~40 B per trajectory.  With N > 1 GPUs e
 B trajectories (weak scaling, no data-path collective) and one tiny all_gather of energy-ranked
 records closes the step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision bf16|f16|fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--precision mfma16|f16|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` with no RANK in the environment starts the N ranks itself (one process per GPU, rendezvous on
@@ -87,13 +87,13 @@ def replayed_counters(args):
     """HBM bytes per launch and pipe-busy fractions of the dominant kernel.  PMC counters cannot be read from inside this
     process: the numbers are REPLAYED from the committed rocprofv3 --pmc run of this exact configuration (profiles/*_traffic.json,
     collected as MI355X_MICROARCH.md prescribes: separate passes, FETCH_SIZE x 2 + WRITE_SIZE) and absent otherwise."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
             continue
         c = t["config"]
-        if (c["R"], c["L"], c["batch"], c["precision"]) == (args.R, args.L, args.batch, args.precision):
+        if (c["R"], c["L"], c["batch"], {"bf16": "mfma16"}.get(c["precision"], c["precision"])) == (args.R, args.L, args.batch, args.precision):
             return t, "replayed profiles/" + name
     return None, None
 
@@ -143,6 +143,8 @@ def spawn_ranks(n):
                 p.wait(timeout=20)
             except subprocess.TimeoutExpired:
                 p.kill()
+        import shutil
+        shutil.rmtree(gather_dir, ignore_errors=True)      # the directory made above for the file-gather fallback
     return rc
 
 
@@ -155,9 +157,9 @@ def main():
     ap.add_argument("--R", type=int, default=300)
     ap.add_argument("--L", type=int, default=300)
     ap.add_argument("--num-steps", type=int, default=40, help="diffusion steps per trajectory")
-    ap.add_argument("--precision", choices=["bf16", "f16", "fp32"], default="bf16",
-                    help="bf16: the 16-bit MFMA engine as shipped (DFM_F_MFMA16; dfm_config_string() in the JSON line says what "
-                         "that is); f16: the same with fp32 A_i; fp32: exact")
+    ap.add_argument("--precision", choices=["mfma16", "bf16", "f16", "fp32"], default="mfma16",
+                    help="mfma16: the 16-bit MFMA engine as shipped (DFM_F_MFMA16: fp16 operands, fp32 accumulation; dfm_config_string() "
+                         "in the JSON line says what that is); f16: the same with fp32 A_i; fp32: exact; bf16: deprecated alias of mfma16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -188,13 +190,14 @@ def main():
     cx = make_complex(args.R, args.L, seed=1)
     model = engine.Model(blob)
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-    bf16 = args.precision == "bf16"
-    f16 = args.precision == "f16"
-    mfma16 = bf16 or f16
+    pk = engine.precision_kwargs(args.precision)      # "bf16" -> "mfma16" with a note on stderr
+    args.precision = engine.canonical_precision(args.precision)
+    f16 = pk["f16"]
+    mfma16 = pk["mfma16"] or f16
     B = args.batch
 
     def one_step(it, profile=False):
-        r = gx.sample(B=B, num_steps=args.num_steps, seed=1000 * (rank + 1) + it, bf16=bf16, f16=f16, profile=profile)
+        r = gx.sample(B=B, num_steps=args.num_steps, seed=1000 * (rank + 1) + it, profile=profile, **pk)
         rec = D.make_records(rank, np.arange(rank * B, (rank + 1) * B), r)      # record id = the rank that sampled it
         allrec = D.gather_records(rec)            # the only collective: ranked energies (RCCL all_gather)
         return r, allrec

@@ -625,11 +625,6 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16)
     return DFM_OK;
 }
 
-__global__ void k_bcast_rows(const float *__restrict__ src, float *__restrict__ dst, long long per, long long total)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i % per];
-}
 __global__ void k_fill(float *dst, float v, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -697,12 +692,10 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         HIPCHK(launch_knn_sample(W.ca4, B, N, cx->knn, cx->nsamp, o.seed, stream_id, W.edges, s));
     }
     HIPCHK(launch_edge_feat(W.pos, W.ca4, W.cb4, W.edges, B, N, R, K, m->hp.mask_dist, W.codes, W.radial, s));
-    {   // h <- node embedding, identical for every trajectory
-        const long long per = (long long)N * H / 4, total = per * B;
-        hipLaunchKernelGGL(k_bcast_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, cx->h0, W.h, per, total);
-        HIPCHK(hipGetLastError());
-    }
-    float *h = W.h, *hn = W.h2;
+    // layer 0 reads the node embedding h0 [N][256] of the complex itself - identical for every trajectory - through a row period
+    // (GemmArgs::a0_period / r_period) instead of a [B][N][256] copy made per evaluation (r01-r03: k_bcast_rows, 157 MB of writes at C3)
+    const float *h = cx->h0;
+    float *hn = W.h, *hspare = W.h2;
     const int M = B * N;
     const bool tile_tasks = o.bf16 && edge_msg_tile_tasks(B, N, K);      // (a ligand-only last layer decides for itself and zeroes agg if it must)
     for (int l = 0; l < depth; ++l) {
@@ -757,7 +750,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         GemmArgs g;
         std::memset(&g, 0, sizeof(g));
         g.A0 = h; g.A1 = W.agg; g.lda = H; g.K = 2 * H; g.pro = 1; g.W = Lw.W3; g.ldw = 2 * H; g.bias = Lw.b3;
-        g.M = M; g.Nout = H; g.C = W.u; g.ldc = H;
+        g.M = M; g.Nout = H; g.C = W.u; g.ldc = H; g.a0_period = l == 0 ? N : 0;
         // 16-bit engines: the GEMM leaves per-tile column sums of u behind, so GraphNorm needs no extra pass over u
         const bool fused_stats = o.bf16 && gemm_rows_per_tile() == 64;
         if (fused_stats) { g.stat_part = W.gn_part; g.rows_per_graph = N; }
@@ -770,9 +763,9 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         if (fused_stats) { g.gn_part = W.gn_part; g.gn_ms = Lw.gn_ms; }
         // tile-task message launches add into a zero agg: its last reader (node_mlp.0) is done, this launch leaves it zeroed for the next layer
         if (o.bf16 && !last && tile_tasks) g.zbuf = W.agg; g.W = Lw.W4; g.ldw = H; g.bias = Lw.b4; g.M = M; g.Nout = H;
-        g.epi = 1; g.R = h; g.C = hn; g.ldc = H;
+        g.epi = 1; g.R = h; g.C = hn; g.ldc = H; g.r_period = l == 0 ? N : 0;
         if (o.bf16) HIPCHK(launch_gemm_split(g, Lw.W4_hi, Lw.W4_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
-        { float *tmp = h; h = hn; hn = tmp; }
+        { float *done = hn; hn = (l == 0) ? hspare : const_cast<float *>(h); h = done; }
         if (l == 0 && o.h_first_out)
             HIPCHK(hipMemcpyAsync(o.h_first_out, h, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (!last) {   // next layer's per-node halves of edge_mlp.0: A = Wa h + b1, Bm = Wb h
@@ -785,7 +778,9 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             if (o.bf16) HIPCHK(launch_gemm_split(g, Ln.Wab_hi, Ln.Wab_lo, s)); else HIPCHK(launch_gemm_f32(g, s));
         }
     }
-    if (h != W.h && o.need_node_out) {   // keep the final node features in W.h (depth odd)
+    // keep the final node features in W.h (depth even).  The pair heads of family 1 read W.h on EVERY evaluation (run_head below),
+    // the heads of family 0 only when somebody asked for the node outputs
+    if (h != W.h && (o.need_node_out || pair_family)) {
         HIPCHK(hipMemcpyAsync(W.h, h, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     if (pair_family) {
@@ -904,7 +899,9 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
         HIPCHK(hipMemcpyAsync(edges_dev, edges, (size_t)B * N * K * 4, hipMemcpyHostToDevice, s));
     }
     if (out->h_first) HIPCHK(tmp.alloc(&h_first_dev, (size_t)B * N * H));
-    if (want_ires && !W.ir1) {      // kept with the workspace: a forward() loop does not pay three hipMalloc / hipFree pairs per call
+    if (want_ires && !W.ir3) {      // kept with the workspace: a forward() loop does not pay three hipMalloc / hipFree pairs per call
+        // (ir3 is the last of the three: a call that failed half-way allocates all of them again; the pool owns the orphans)
+        W.ir1 = W.ir2 = nullptr;
         HIPCHK(W.pool.alloc(&W.ir1, (size_t)W.Bcap * N * 2 * H)); HIPCHK(W.pool.alloc(&W.ir2, (size_t)W.Bcap * N * 2 * H));
         HIPCHK(W.pool.alloc(&W.ir3, (size_t)W.Bcap * N));
     }
@@ -912,7 +909,8 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     FwdOpts o;
     o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
     o.edges_pitch = (int64_t)N * K; o.seed = seed; o.h_first_out = h_first_dev;
-    o.need_node_out = want_energy || want_ires || want_dist || out->h_last != nullptr;
+    // (h_first: a depth-1 model's first layer is its last - the tap needs that layer's node model too)
+    o.need_node_out = want_energy || want_ires || want_dist || out->h_last != nullptr || out->h_first != nullptr;
     HIPCHK(hipEventRecord(cx->ev_total[0], s));
     rc = enqueue_forward(cx, B, o);
     if (rc == DFM_OK) {

@@ -158,6 +158,9 @@ struct GemmArgs {
     // reads any more (agg after node_mlp.0: the next layer's tile-task message launch adds into it atomically and would otherwise
     // need a memset launch per layer)
     float *zbuf;
+    // optional row periods (0 = none): row r of A0 / of the residual R is read at r % period - layer 0's node embedding h0 [N][256] is
+    // the same for every trajectory and is read in place instead of from a per-evaluation [B][N][256] copy
+    int a0_period, r_period;
 };
 hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s);
 // split-bf16 (hi/lo) variant, ~1e-5 relative error; Whi/Wlo = pre-split weights [Nout][ldw] bf16

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a)
         for (int rr = 0; rr < 2; ++rr) {
             const int r = lr + rr * 64;
             const int grow = row0 + r;
+            const int grow_a = a.a0_period ? grow % a.a0_period : grow;      // layer 0: the complex's own h0 rows (GemmArgs::a0_period)
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (grow < a.M) {
 #pragma unroll
@@ -53,9 +54,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a)
                     if (k < a.K) {
                         float x;
                         if (a.pro == 1) {
-                            x = (k < halfK) ? a.A0[(size_t)grow * a.lda + k] : a.A1[(size_t)grow * a.lda + (k - halfK)];
+                            x = (k < halfK) ? a.A0[(size_t)grow_a * a.lda + k] : a.A1[(size_t)grow * a.lda + (k - halfK)];
                         } else {
-                            x = a.A0[(size_t)grow * a.lda + k];
+                            x = a.A0[(size_t)grow_a * a.lda + k];
                             if (a.pro == 2) {
                                 // GraphNorm (torch_geometric 2.6.0, batch=None) + SiLU: egnn.py:72-76
                                 const int g = grow / a.rows_per_graph;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs a)
                 if (row >= a.M) continue;
                 float v = acc[i][j][r] + bias;
                 if (a.epi == 1) {
-                    a.C[(size_t)row * a.ldc + col] = a.R[(size_t)row * a.ldc + col] + v;
+                    a.C[(size_t)row * a.ldc + col] = a.R[(size_t)(a.r_period ? row % a.r_period : row) * a.ldc + col] + v;
                 } else if (a.epi == 2) {
                     if (col < H) a.C[(size_t)row * H + col] = v;
                     else {
@@ -280,6 +281,7 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
     const int halfK = a.K >> 1;
     const bool rv0 = row0 + ar < row_end;
     const size_t gr0 = (size_t)(rv0 ? row0 + ar : 0);
+    const size_t gr0a = a.a0_period ? gr0 % (size_t)a.a0_period : gr0;      // row of A0 (layer 0: the complex's own h0, GemmArgs::a0_period)
 
     // registers of the stage being fetched: activations (rows x 8 k) and 4 x 16 B of hi / lo weights
     float4 xa0, xa1;
@@ -289,8 +291,8 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
 #define GEMM_SPLIT_FETCH(K0)                                                                                          \
     {                                                                                                                 \
         const int k_ = (K0) + kg;                                                                                     \
-        const float *base_ = (a.pro == 1 && k_ >= halfK) ? a.A1 + (k_ - halfK) : a.A0 + k_;                           \
-        const float *s0_ = base_ + gr0 * a.lda;                                                                       \
+        const bool second_ = a.pro == 1 && k_ >= halfK;                                                               \
+        const float *s0_ = second_ ? a.A1 + (k_ - halfK) + gr0 * a.lda : a.A0 + k_ + gr0a * a.lda;                    \
         xa0 = *reinterpret_cast<const float4 *>(s0_); xa1 = *reinterpret_cast<const float4 *>(s0_ + 4);              \
         const size_t wbase_ = ((size_t)((K0) / SK) * 4 * a.Nout + col0 + wcol) * 8;                                   \
         const size_t wq_ = (size_t)a.Nout * 8;                                                                        \
@@ -402,8 +404,9 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const size_t row = (size_t)row0 + wm * 64 + i * 32 + q * 4 + er;
+                    const size_t rrow = a.r_period ? row % (size_t)a.r_period : row;
                     const int col = col0 + (wn * NJ + jp * 2) * 32 + ec;
-                    res[q] = (row < (size_t)row_end && ec < NJ * 32) ? *reinterpret_cast<const float4 *>(a.R + row * a.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    res[q] = (row < (size_t)row_end && ec < NJ * 32) ? *reinterpret_cast<const float4 *>(a.R + rrow * a.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
@@ -528,11 +531,13 @@ hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint1
     if (a.zbuf && a.Nout != SN) return hipErrorInvalidValue;
     const int row_tiles = (a.stat_part || a.pro == 2) ? (a.M / a.rows_per_graph) * ((a.rows_per_graph + 63) / 64) : (a.M + 63) / 64;
     // fewer 64 x 256 workgroups than two per CU: 64 x 128 tiles (NJ = 1) - a lone workgroup is bound by its CU's own memory pipe
-    static const int narrow_max = [] {
+    static const int narrow_env = [] {
         const char *e = getenv("DFM_GEMM_NARROW_MAXWG");      // diagnostics: 64 x 256 workgroup count below which NJ = 1 is used (0 = never)
-        if (e) return atoi(e);
-        return 2 * device_cus();      // measured (profiles/r03_d_small_narrow.txt): +17 % at B = 1, +8.5 % at B = 8, +1.5 % at B = 32, even at B = 64 (300+300)
+        return e ? atoi(e) : -1;
     }();
+    // per call: device_cus() is the CURRENT device's count (a process may drive GPUs of different sizes).  2 per CU measured
+    // (profiles/r03_d_small_narrow.txt): +17 % at B = 1, +8.5 % at B = 8, +1.5 % at B = 32, even at B = 64 (300+300)
+    const int narrow_max = narrow_env >= 0 ? narrow_env : 2 * device_cus();
     const bool narrow = (long long)row_tiles * (a.Nout / SN) < narrow_max;
     const bool half = a.epi == 2 && a.Cb && a.C2b && !a.C2;
     if (narrow) {

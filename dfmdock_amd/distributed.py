@@ -36,6 +36,8 @@ class Group:
         self.backend, self.rank, self.world = backend, rank, world
         self.data_group, self.fallback_reason, self.gather_dir = data_group, fallback_reason, gather_dir
         self._file_round = 0
+        self._token = None          # file backend: the job's name space inside gather_dir (see _file_token)
+        self._prev_file = None      # file backend: this rank's file of the previous round (deleted once the next round is complete)
 
 
 _group = Group("single")
@@ -90,7 +92,9 @@ def _init(device_index, prefer, timeout_s) -> Group:
     try:
         if not dist.is_initialized():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
-    except Exception as e:      # no control plane either: replicas + files, if a directory was provided
+    except Exception as e:      # no control plane either: replicas + files, if a directory was provided.  (gloo connects the full
+        # mesh inside init_process_group: it fails on every rank or on none; a rank that did come up alone would leave its
+        # first collective with a timeout error after timeout_s, not hang)
         if not gather_dir:
             raise
         _group = Group("file", rank, world, gather_dir=gather_dir, fallback_reason=f"gloo init failed: {e}")
@@ -126,6 +130,13 @@ def _init(device_index, prefer, timeout_s) -> Group:
 
 def shutdown():
     global _group
+    if _group.backend == "file" and _group._token:
+        # a closing round (nobody may still be reading this rank's last block when it goes); the closing round's own small file
+        # stays behind under the job's token and is swept by the next job's rank of the same number
+        try:
+            _file_gather(np.zeros((0, RECORD_WIDTH), np.float32), _group)
+        except TimeoutError:
+            pass
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
@@ -135,24 +146,105 @@ def shutdown():
         _group = Group("single")
 
 
-def _file_gather(records: np.ndarray, g: Group, poll_s: float = 0.02, timeout_s: float = 600.0) -> np.ndarray:
-    """SURVEY 8(e) last row: every rank drops its block into a shared directory (atomic rename), then reads all of them."""
+def _sweep_own(g: Group, keep_token=None):
+    """Delete this rank's files of EARLIER jobs in gather_dir (any file named for this rank whose token is not the live one)."""
+    suffixes = (f"_rank{g.rank}.npy", f"_rank{g.rank}.json")
+    for name in os.listdir(g.gather_dir):
+        mine = name.endswith(suffixes) or name.startswith(f"hello_rank{g.rank}_") or (g.rank == 0 and name.startswith("ack_"))
+        if mine and (keep_token is None or not name.startswith(keep_token + "_")):
+            try:
+                os.remove(os.path.join(g.gather_dir, name))
+            except OSError:
+                pass
+
+
+def _service_hellos(g: Group):
+    """Rank 0, inside every wait loop: answer `hello_rank<r>_<nonce>` with `ack_<nonce>` holding the job token.  A nonce is fresh
+    per process, so an ack can only come from the LIVE rank 0 - a stale directory cannot hand out a dead job's token."""
+    for name in os.listdir(g.gather_dir):
+        if name.startswith("hello_rank"):
+            nonce = name.rsplit("_", 1)[1]
+            ack = os.path.join(g.gather_dir, "ack_" + nonce)
+            if not os.path.exists(ack):
+                tmp = os.path.join(g.gather_dir, f".ack_{nonce}.tmp")
+                with open(tmp, "w") as f:
+                    f.write(g._token)
+                os.replace(tmp, ack)
+
+
+def _wait_for(path: str, g: Group, what: str, poll_s: float = 0.02, timeout_s: float = 600.0):
     import time
-    g._file_round += 1
-    tag = f"round{g._file_round:06d}"
+    t0 = time.time()
+    while not os.path.exists(path):
+        if g.rank == 0 and g._token:
+            _service_hellos(g)
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"file gather: {what} never appeared ({path})")
+        time.sleep(poll_s)
+
+
+def _file_token(g: Group) -> str:
+    """Name space of this job's files inside DFM_GATHER_DIR.  The files of a gather are `<token>_round000001_rank0.npy` ...: a
+    second job (or a restarted rank) that reuses the directory must never read the previous run's records as its own, and a
+    barrier must never return on them.  DFM_JOB_ID names the job when the launcher provides one; otherwise rank 0 draws a token
+    and hands it to the other ranks through a nonce handshake (hello / ack, see _service_hellos).  Every rank first removes its
+    own leftovers of earlier jobs."""
+    if g._token:
+        return g._token
+    import uuid
     os.makedirs(g.gather_dir, exist_ok=True)
-    tmp = os.path.join(g.gather_dir, f".{tag}_rank{g.rank}.tmp.npy")
-    np.save(tmp, np.ascontiguousarray(records, np.float32))
-    os.replace(tmp, os.path.join(g.gather_dir, f"{tag}_rank{g.rank}.npy"))
-    out, t0 = [], time.time()
+    env = os.environ.get("DFM_JOB_ID")
+    if env:
+        g._token = "j" + "".join(ch if ch.isalnum() else "-" for ch in env)
+        _sweep_own(g, keep_token=g._token)
+        return g._token
+    _sweep_own(g)
+    if g.rank == 0:
+        g._token = "j" + uuid.uuid4().hex[:12]
+        return g._token
+    nonce = uuid.uuid4().hex[:12]
+    hello = os.path.join(g.gather_dir, f"hello_rank{g.rank}_{nonce}")
+    open(hello, "w").close()
+    ack = os.path.join(g.gather_dir, "ack_" + nonce)
+    _wait_for(ack, g, "rank 0's answer to this rank's hello")
+    g._token = open(ack).read().strip()
+    for pth in (hello, ack):
+        try:
+            os.remove(pth)
+        except OSError:
+            pass
+    return g._token
+
+
+def _file_round(g: Group, kind: str, ext: str, write, read):
+    """One all-to-all round over files: every rank drops its block (atomic rename), then reads all of them.  Once round n is
+    complete every rank has finished READING round n - 1 (it read before it wrote), so this rank's file of round n - 1 goes."""
+    token = _file_token(g)
+    g._file_round += 1
+    tag = f"{token}_{kind}{g._file_round:06d}"
+    mine = os.path.join(g.gather_dir, f"{tag}_rank{g.rank}{ext}")
+    tmp = os.path.join(g.gather_dir, f".{tag}_rank{g.rank}.tmp{ext}")
+    write(tmp)
+    os.replace(tmp, mine)
+    out = []
     for r in range(g.world):
-        path = os.path.join(g.gather_dir, f"{tag}_rank{r}.npy")
-        while not os.path.exists(path):
-            if time.time() - t0 > timeout_s:
-                raise TimeoutError(f"file gather: rank {r} never wrote {path}")
-            time.sleep(poll_s)
-        out.append(np.load(path).reshape(-1, RECORD_WIDTH))
-    return np.concatenate(out, 0)
+        path = os.path.join(g.gather_dir, f"{tag}_rank{r}{ext}")
+        _wait_for(path, g, f"rank {r}'s block of {kind} round {g._file_round}")
+        out.append(read(path))
+    if g._prev_file:
+        try:
+            os.remove(g._prev_file)
+        except OSError:
+            pass
+    g._prev_file = mine
+    return out
+
+
+def _file_gather(records: np.ndarray, g: Group) -> np.ndarray:
+    """SURVEY 8(e) last row: the record gather without any rendezvous, over a shared directory."""
+    blocks = _file_round(g, "round", ".npy", lambda p: np.save(p, np.ascontiguousarray(records, np.float32)),
+                         lambda p: np.load(p).reshape(-1, RECORD_WIDTH))
+    return np.concatenate(blocks, 0)
 
 
 def shard_range(total: int, world: int, rank: int):
@@ -246,22 +338,15 @@ def gather_objects(obj):
     g = _group
     if g.backend == "file":
         import json
-        import time
-        g._file_round += 1
-        tag = f"obj{g._file_round:06d}"
-        os.makedirs(g.gather_dir, exist_ok=True)
-        tmp = os.path.join(g.gather_dir, f".{tag}_rank{g.rank}.tmp")
-        json.dump(obj, open(tmp, "w"), default=float)
-        os.replace(tmp, os.path.join(g.gather_dir, f"{tag}_rank{g.rank}.json"))
-        out, t0 = [], time.time()
-        for r in range(g.world):
-            path = os.path.join(g.gather_dir, f"{tag}_rank{r}.json")
-            while not os.path.exists(path):
-                if time.time() - t0 > 600.0:
-                    raise TimeoutError(f"file gather: rank {r} never wrote {path}")
-                time.sleep(0.02)
-            out.append(json.load(open(path)))
-        return out
+
+        def write(pth):
+            with open(pth, "w") as f:
+                json.dump(obj, f, default=float)
+
+        def read(pth):
+            with open(pth) as f:
+                return json.load(f)
+        return _file_round(g, "obj", ".json", write, read)
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [obj]

@@ -48,7 +48,7 @@ def random_rotation(rec_pos, lig_pos, rng):
     return rotate_complex(rec_pos, lig_pos, Rm)
 
 
-def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0, precision="bf16", global_rotation=True,
+def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0, precision="mfma16", global_rotation=True,
             out_csv=None, traj_dir=None, max_batch=256, **sampler_kw):
     """Sample `num_samples` trajectories for every complex dict (id, rec_x, lig_x, rec_pos, lig_pos[, rec_seq, lig_seq]);
     returns the metric rows of this rank's share; rank 0 writes the gathered CSV when `out_csv` is given."""
@@ -76,8 +76,8 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
         done = t_lo
         while done < t_hi:
             b = min(max_batch, t_hi - done)
-            r = gx.sample(B=b, num_steps=num_steps, seed=seed * 100003 + ci * 1009 + done, bf16=precision == "bf16",
-                          f16=precision == "f16", trace=traj_dir is not None, **sampler_kw)
+            r = gx.sample(B=b, num_steps=num_steps, seed=seed * 100003 + ci * 1009 + done, trace=traj_dir is not None,
+                          **engine.precision_kwargs(precision), **sampler_kw)
             for k in range(b):
                 m = compute_metrics((rec_pos, r["lig_pos"][k]), (rec_pos, lig_pos), native)
                 rows.append({"id": c.get("id", str(ci)), "index": str(done + k), **m, "energy": float(r["energy"][k]),
@@ -110,7 +110,7 @@ def _gather_rows(rows, world):
     return [r for part in D.gather_objects(rows) for r in part]
 
 
-def dock_pair(model: engine.Model, rec, lig, rec_x, lig_x, num_samples=120, num_steps=40, seed=0, precision="bf16",
+def dock_pair(model: engine.Model, rec, lig, rec_x, lig_x, num_samples=120, num_steps=40, seed=0, precision="mfma16",
               out_pdb="output.pdb", max_batch=256):
     """inference() of the reference for two parsed PDB chains (pdbio.backbone_from_atoms dicts) and their
     pre-computed node features; returns {'energy': min energy} and writes the best pose."""
@@ -119,7 +119,7 @@ def dock_pair(model: engine.Model, rec, lig, rec_x, lig_x, num_samples=120, num_
     done = 0
     while done < num_samples:
         b = min(max_batch, num_samples - done)
-        r = gx.sample(B=b, num_steps=num_steps, seed=seed + done, bf16=precision == "bf16", f16=precision == "f16")
+        r = gx.sample(B=b, num_steps=num_steps, seed=seed + done, **engine.precision_kwargs(precision))
         k = int(np.argmin(r["energy"]))
         if best is None or r["energy"][k] < best[0]:     # strict <: the first minimum wins, as in the reference
             best = (float(r["energy"][k]), r["rot_update"][k].copy(), r["tr_update"][k].copy())

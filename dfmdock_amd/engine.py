@@ -17,6 +17,35 @@ def _p(a, t=L.F32P):
     return a.ctypes.data_as(t) if a is not None else None
 
 
+PRECISIONS = ("mfma16", "f16", "fp32")
+_warned_bf16 = False
+
+
+def precision_kwargs(precision: str) -> dict:
+    """Engine selector -> keyword arguments of Complex.score / Complex.sample.
+
+      "mfma16"  the 16-bit MFMA engine as shipped (DFM_F_MFMA16): fp16 MFMA operands, fp32 accumulation (config_string())
+      "f16"     the same with fp32 A_i (DFM_F_F16)
+      "fp32"    exact fp32 (the reference's own arithmetic)
+      "bf16"    DEPRECATED alias of "mfma16" - the name of rounds 1-3, kept so that old command lines keep working; the
+                engine it selects has computed on fp16 operands since r03, which is what the name now says
+    """
+    global _warned_bf16
+    if precision == "bf16":
+        if not _warned_bf16:
+            import sys
+            print('dfmdock_amd: precision "bf16" is a deprecated alias of "mfma16" (fp16 MFMA operands, fp32 accumulation)', file=sys.stderr)
+            _warned_bf16 = True
+        precision = "mfma16"
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS} (or the deprecated alias 'bf16'), got {precision!r}")
+    return {"mfma16": precision == "mfma16", "f16": precision == "f16"}
+
+
+def canonical_precision(precision: str) -> str:
+    return "mfma16" if precision == "bf16" else precision
+
+
 def hparams_c(hp: HParams | None = None) -> L.HParamsC:
     hp = hp or HParams()
     return L.HParamsC(**hp.as_dict())
@@ -114,9 +143,11 @@ class Complex:
         """Value of the 67th ("sym") position channel (positional_embed_dim = 67 models only)."""
         L.check(L.lib().dfm_complex_set_homomer(self._h, int(bool(flag))), "dfm_complex_set_homomer")
 
-    def score(self, lig_pos, t, edges=None, seed=0, bf16=False, energy=True, debug=False, profile=False, f16=False,
-              ires=False, return_edges=False, bf16_ops=False, dist=False):
-        """B score evaluations.  lig_pos [B,L,3,3] (or [L,3,3]), t [B] (or scalar)."""
+    def score(self, lig_pos, t, edges=None, seed=0, mfma16=False, energy=True, debug=False, profile=False, f16=False,
+              ires=False, return_edges=False, bf16_ops=False, dist=False, bf16=False):
+        """B score evaluations.  lig_pos [B,L,3,3] (or [L,3,3]), t [B] (or scalar).  mfma16: the 16-bit MFMA engine
+        (`bf16=` is its deprecated keyword of rounds 1-3)."""
+        mfma16 = mfma16 or bf16
         lig_pos = _f32(lig_pos)
         if lig_pos.ndim == 3:
             lig_pos = lig_pos[None]
@@ -151,7 +182,7 @@ class Complex:
                 e = e[None]
             if e.shape != (B, N, K):
                 raise ValueError(f"edges must be [B,N,K] = {(B, N, K)}, got {e.shape}")
-        flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_ENERGY if energy else 0) | (L.DFM_F_PROFILE if profile else 0) | \
+        flags = (L.DFM_F_MFMA16 if mfma16 else 0) | (L.DFM_F_ENERGY if energy else 0) | (L.DFM_F_PROFILE if profile else 0) | \
                 (L.DFM_F_F16 if f16 else 0) | (L.DFM_F_IRES if ires else 0) | (L.DFM_F_BF16_OPS if bf16_ops else 0) | \
                 (L.DFM_F_DIST if dist else 0)
         rc = L.lib().dfm_score(self._h, B, _p(lig_pos), _p(t), _p(e, L.I32P), int(seed), flags, C.byref(out))
@@ -163,8 +194,10 @@ class Complex:
         return o
 
     def sample(self, B=1, num_steps=40, eps=1e-3, tr_noise_scale=0.5, rot_noise_scale=0.5, noise_annealing=False,
-               use_clash_force=False, ode=False, seed=0, bf16=False, inject=None, trace=False, profile=False, f16=False, bf16_ops=False):
+               use_clash_force=False, ode=False, seed=0, mfma16=False, inject=None, trace=False, profile=False, f16=False, bf16_ops=False,
+               bf16=False):
         """B independent Euler-Maruyama trajectories (inference_base.py:390-468 batched)."""
+        mfma16 = mfma16 or bf16
         Lg, N, K, S = self.L, self.N, self.K, int(num_steps)
         o = dict(lig_pos=np.zeros((B, Lg, 3, 3), np.float32), rot_update=np.zeros((B, 3), np.float32),
                  tr_update=np.zeros((B, 3), np.float32), energy=np.zeros((B,), np.float32),
@@ -190,7 +223,7 @@ class Complex:
                 a = np.ascontiguousarray(inject["edges"], dtype=np.int32).reshape(B, S + 1, N, K)
                 keep.append(a)
                 inj.edges = _p(a, L.I32P)
-        flags = (L.DFM_F_BF16 if bf16 else 0) | (L.DFM_F_NOISE_ANNEALING if noise_annealing else 0) | \
+        flags = (L.DFM_F_MFMA16 if mfma16 else 0) | (L.DFM_F_NOISE_ANNEALING if noise_annealing else 0) | \
                 (L.DFM_F_CLASH_FORCE if use_clash_force else 0) | (L.DFM_F_ODE if ode else 0) | \
                 (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if trace else 0) | (L.DFM_F_F16 if f16 else 0) | \
                 (L.DFM_F_BF16_OPS if bf16_ops else 0)

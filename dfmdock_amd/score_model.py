@@ -97,14 +97,15 @@ class Score_Model:
     reads) and leaves the key out.
     """
 
-    def __init__(self, weights, hp: HParams | None = None, precision: str = "bf16", device_index: int = 0, seed: int = 0,
+    def __init__(self, weights, hp: HParams | None = None, precision: str = "mfma16", device_index: int = 0, seed: int = 0,
                  with_ires: bool = True):
         self.hp = hp or HParams()
         self.with_ires = bool(with_ires)
         blob = weights if isinstance(weights, np.ndarray) and weights.ndim == 1 else pack_blob(weights, self.hp)
         engine.set_device(device_index)
         self.model = engine.Model(blob, self.hp)
-        self.precision = precision
+        engine.precision_kwargs(precision)                      # validates; "bf16" = deprecated alias of "mfma16" (prints a note once)
+        self.precision = engine.canonical_precision(precision)
         self.r3_diffuser = R3Diffuser(self.hp)
         self.so3_diffuser = SO3Diffuser(self.hp)
         self._cx = None
@@ -171,8 +172,8 @@ class Score_Model:
         if t.size != 1:
             raise ValueError("batch['t'] must hold one time value (the reference runs batch_size=1)")
         self._calls += 1
-        r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, bf16=self.precision == "bf16",
-                     f16=self.precision == "f16", energy=True, ires=self.with_ires, dist=getattr(self, "with_dist", False))
+        r = cx.score(_np(batch["lig_pos"]), t, seed=self.seed + self._calls, energy=True, **engine.precision_kwargs(self.precision),
+                     ires=self.with_ires, dist=getattr(self, "with_dist", False))
         out = {"tr_score": torch.from_numpy(r["tr_score"]), "rot_score": torch.from_numpy(r["rot_score"]),
                "energy": torch.tensor(float(r["energy"][0]), dtype=torch.float32), "f": torch.from_numpy(r["f"][0]),
                "num_clashes": torch.tensor(int(r["num_clashes"][0]), dtype=torch.int64)}
@@ -198,7 +199,7 @@ class DFMDock(Score_Model):
     Score_Model, so ``Euler_Maruyama_sampler(model, batch)`` / ``sample_trajectories`` accept this class too.
     """
 
-    def __init__(self, weights, hp: HParams | None = None, precision: str = "bf16", device_index: int = 0, seed: int = 0,
+    def __init__(self, weights, hp: HParams | None = None, precision: str = "mfma16", device_index: int = 0, seed: int = 0,
                  with_ires: bool = True, with_dist: bool = False):
         hp = hp or HParams(family=1, mask_dist=20.0)
         if hp.family != 1:
@@ -249,8 +250,7 @@ def Euler_Maruyama_sampler(model: Score_Model, batch, num_steps=40, device="cpu"
     model._calls += 1
     r = cx.sample(B=1, num_steps=num_steps, eps=eps, tr_noise_scale=tr_noise_scale, rot_noise_scale=rot_noise_scale,
                   noise_annealing=noise_annealing, use_clash_force=use_clash_force,
-                  seed=(model.seed + model._calls) if seed is None else seed, bf16=model.precision == "bf16",
-                  f16=model.precision == "f16")
+                  seed=(model.seed + model._calls) if seed is None else seed, **engine.precision_kwargs(model.precision))
     output = {"energy": torch.tensor(float(r["energy"][0])), "num_clashes": torch.tensor(int(r["num_clashes"][0])),
               "tr_score": torch.from_numpy(r["final_scores"][:, 0:3].copy()),
               "rot_score": torch.from_numpy(r["final_scores"][:, 3:6].copy())}
@@ -270,8 +270,7 @@ def sample_trajectories(model: Score_Model, batch, num_samples=120, num_steps=40
         b = min(max_batch, num_samples - done)
         outs.append(cx.sample(B=b, num_steps=num_steps, eps=eps, tr_noise_scale=tr_noise_scale,
                               rot_noise_scale=rot_noise_scale, noise_annealing=noise_annealing,
-                              use_clash_force=use_clash_force, seed=seed + done, bf16=model.precision == "bf16",
-                              f16=model.precision == "f16"))
+                              use_clash_force=use_clash_force, seed=seed + done, **engine.precision_kwargs(model.precision)))
         done += b
     res = {k: np.concatenate([o[k] for o in outs], 0) for k in ("lig_pos", "rot_update", "tr_update", "energy", "num_clashes")}
     res["best"] = int(np.argmin(res["energy"]))     # `if outputs["energy"] < min_energy` keeps the first minimum

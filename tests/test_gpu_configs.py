@@ -69,7 +69,7 @@ def test_c3_batch256_vs_oracle_and_reference(model, blob):
     B = 256
     poses = rigid_poses(cx, np.random.default_rng(4), B)
     ts = np.linspace(1.0, 0.001, B).astype(np.float32)
-    r16 = gx.score(poses, ts, seed=9, bf16=True, energy=True, return_edges=True)
+    r16 = gx.score(poses, ts, seed=9, mfma16=True, energy=True, return_edges=True)
     assert np.isfinite(r16["f"]).all() and np.isfinite(r16["energy"]).all()
     assert (r16["edges"][0] != r16["edges"][1]).any()
     r32 = gx.score(poses, ts, edges=r16["edges"], energy=True)
@@ -83,7 +83,7 @@ def test_c3_batch256_vs_oracle_and_reference(model, blob):
     g = load_golden("fwd_c3_300_300.npz")
     e = g["edges"].astype(np.int32)
     check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True), 0, 1e-4, 1e-4, "golden fp32")
-    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, bf16=True), 0, 1e-2, 3e-2, "golden bf16")
+    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, mfma16=True), 0, 1e-2, 3e-2, "golden bf16")
     gx.close()
 
 
@@ -99,19 +99,19 @@ def test_c2_7cei_batch64_bf16_sampler(model):
     one = dict(R0=g["R0"].astype(np.float32).reshape(1, 9), tr_draw=g["tr_draw"].reshape(1, 3), z_rot=g["z_rot"][None],
                z_tr=g["z_tr"][None], edges=g["edges"][None])
     many = {k: np.ascontiguousarray(np.repeat(v, B, 0)) for k, v in one.items()}
-    r1 = gx.sample(B=1, num_steps=S, inject=one, trace=True, bf16=True)
-    rb = gx.sample(B=B, num_steps=S, inject=many, trace=True, bf16=True)
+    r1 = gx.sample(B=1, num_steps=S, inject=one, trace=True, mfma16=True)
+    rb = gx.sample(B=B, num_steps=S, inject=many, trace=True, mfma16=True)
     for k in ("lig_pos", "trace_pose", "trace_scores", "energy", "rot_update", "tr_update", "num_clashes"):
         assert (rb[k] == r1[k][0]).all(), k
     ca, ref = rb["trace_pose"][17][:, :, 1, :], g["poses"][:, :, 1, :]
     rmsd = np.sqrt(((ca - ref) ** 2).sum(-1).mean(-1))
     assert rmsd.max() < 0.5, rmsd
-    nat = gx.sample(B=B, num_steps=40, seed=42, bf16=True)
+    nat = gx.sample(B=B, num_steps=40, seed=42, mfma16=True)
     assert np.isfinite(nat["lig_pos"]).all() and np.isfinite(nat["energy"]).all()
     assert np.abs(nat["lig_pos"][0] - nat["lig_pos"][1]).max() > 1.0
-    again = gx.sample(B=B, num_steps=40, seed=42, bf16=True)
+    again = gx.sample(B=B, num_steps=40, seed=42, mfma16=True)
     np.testing.assert_array_equal(nat["lig_pos"], again["lig_pos"])            # counter-based RNG: a pure function of the seed
-    half = gx.sample(B=B // 2, num_steps=40, seed=42, bf16=True)
+    half = gx.sample(B=B // 2, num_steps=40, seed=42, mfma16=True)
     np.testing.assert_array_equal(nat["lig_pos"][: B // 2], half["lig_pos"])   # ... and of the trajectory index, not of B
     gx.close()
 
@@ -128,7 +128,7 @@ def test_c5_large_complex(model, blob):
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
     e = g["edges"].astype(np.int32)
     check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True), 0, 1e-4, 1e-4, "golden fp32")
-    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, bf16=True), 0, 1e-2, 3e-2, "golden bf16")
+    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, mfma16=True), 0, 1e-2, 3e-2, "golden bf16")
     poses = np.stack([g["lig_pos"], g["lig_pos"] + np.float32(2.0)])
     r = gx.score(poses, np.array([0.4, 0.9], np.float32), seed=3, energy=True, return_edges=True)
     for b in range(2):
@@ -142,9 +142,9 @@ def test_c5_large_complex(model, blob):
     o = ora.Oracle(blob, cx)
     ref = o.score(poses[1], 0.9, edges=r["edges"][1])
     check_vs(ref, r, 1, 1e-4, 1e-4, "native graph fp32")
-    r16 = gx.score(poses, np.array([0.4, 0.9], np.float32), edges=r["edges"], energy=True, bf16=True)
+    r16 = gx.score(poses, np.array([0.4, 0.9], np.float32), edges=r["edges"], energy=True, mfma16=True)
     check_vs(ref, r16, 1, 1e-2, 3e-2, "native graph bf16")
-    s = gx.sample(B=32, num_steps=40, seed=5, bf16=True)
+    s = gx.sample(B=32, num_steps=40, seed=5, mfma16=True)
     assert np.isfinite(s["lig_pos"]).all() and np.isfinite(s["energy"]).all() and np.isfinite(s["tr_update"]).all()
     gx.close()
 
@@ -187,7 +187,7 @@ def test_c4_db5_set_one_gpu(model, blob, tmp_path):
                    z_rot=rng.standard_normal((B, S, 3)).astype(np.float32), z_tr=rng.standard_normal((B, S, 3)).astype(np.float32),
                    edges=edges)
         r32 = gx.sample(B=B, num_steps=S, inject=inj, trace=True)
-        r16 = gx.sample(B=B, num_steps=S, inject=inj, trace=True, bf16=True)
+        r16 = gx.sample(B=B, num_steps=S, inject=inj, trace=True, mfma16=True)
         for b in range(B):
             ob = o.sample(num_steps=S, inject={k: (v[b].astype(np.float64) if k == "R0" else v[b]) for k, v in inj.items()}, trace=True)
             rmsd = np.sqrt(((r32["trace_pose"][b][:, :, 1] - ob["trace_pose"][:, :, 1]) ** 2).sum(-1).mean(-1))

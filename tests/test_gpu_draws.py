@@ -15,11 +15,11 @@ from conftest import DRAWS, DRAW_CASES, complex_for, draw_blob, draw_golden, dra
 pytestmark = pytest.mark.gpu
 
 # (f, tr_score, rot_score, energy)
-# "bf16" = the 16-bit MFMA engine as shipped (DFM_F_MFMA16: fp16 operands in every layer, fp16 A_i, three-term node GEMMs): measured
+# "mfma16" = the 16-bit MFMA engine as shipped (DFM_F_MFMA16: fp16 operands in every layer, fp16 A_i, three-term node GEMMs): measured
 # worst over the four draws x two families 5.5e-3 / 3.2e-3 / 3.3e-3 / 2.4e-3 (profiles/r03_tol_report.txt).  "f16" = fp32 A_i:
 # 5.7e-3 / 3.4e-3 / 1.6e-3 / 2.8e-3 - its r02 gates of 3e-3 / 5e-3 were read off ONE draw and are replaced by SURVEY's 16-bit gates.
-TOL = {"fp32": (1e-4, 1e-4, 1e-4, 1e-4), "bf16": (1e-2, 1e-2, 1e-2, 3e-2), "f16": (1e-2, 1e-2, 1e-2, 3e-2)}
-KW = {"fp32": {}, "bf16": dict(bf16=True), "f16": dict(f16=True)}
+TOL = {"fp32": (1e-4, 1e-4, 1e-4, 1e-4), "mfma16": (1e-2, 1e-2, 1e-2, 3e-2), "f16": (8e-3, 8e-3, 8e-3, 1e-2)}      # measured worst 5.7e-3 / 3.4e-3 / 1.6e-3 / 2.8e-3
+KW = {"fp32": {}, "mfma16": dict(mfma16=True), "f16": dict(f16=True)}
 
 
 def rel_inf(a, b):
@@ -67,7 +67,7 @@ def test_score_on_other_weight_draws(case_i, family, draw):
 
 
 @pytest.mark.parametrize("which,steps", [("rollout", 40), ("rollout7", 6)])
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("prec", ["fp32", "mfma16", "f16"])
 @pytest.mark.parametrize("draw", DRAWS)
 @pytest.mark.parametrize("family", [0, 1])
 def test_rollout_on_other_weight_draws(family, draw, prec, which, steps):
@@ -104,8 +104,8 @@ def test_bf16_operand_plan_is_opt_in_and_within_its_stated_bound(family, draw):
             g = draw_golden(family, draw, case)
         cx = complex_for(case)
         gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-        r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32), energy=True, bf16=True, bf16_ops=True)
-        d = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32), energy=True, bf16=True)
+        r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32), energy=True, mfma16=True, bf16_ops=True)
+        d = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32), energy=True, mfma16=True)
         gx.close()
         assert rel_inf(r["f"][0], g["f"]) < 2e-2 and rel_inf(r["tr_score"][0], np.asarray(g["tr_score"]).reshape(3)) < 2e-2, case
         assert rel_inf(r["rot_score"][0], np.asarray(g["rot_score"]).reshape(3)) < 2e-2, case

@@ -41,7 +41,7 @@ def test_odd_sizes_fp32_vs_oracle(R, L, family, blob, blob_pair):
         assert rel_inf(r["rot_score"][b], ref["rot_score"].reshape(3)) < 1e-4 or np.abs(ref["rot_score"]).max() < 1e-6
         assert abs(float(r["energy"][b]) - float(ref["energy"])) < 1e-4
     # the 16-bit engine and the sampler run on these shapes too
-    s = gx.sample(B=3, num_steps=3, seed=5, bf16=True)
+    s = gx.sample(B=3, num_steps=3, seed=5, mfma16=True)
     assert np.isfinite(s["lig_pos"]).all() and np.isfinite(s["energy"]).all()
     gx.close(); m.close()
 
@@ -66,7 +66,7 @@ def test_degenerate_geometry_fp32_vs_oracle(blob):
     assert np.isfinite(r["f"]).all() and np.isfinite(r["tr_score"]).all() and np.isfinite(r["rot_score"]).all()
     assert rel_inf(r["f"][0], o["f"]) < 1e-4 and rel_inf(r["tr_score"][0], o["tr_score"].reshape(3)) < 1e-4
     assert abs(float(r["energy"][0]) - float(o["energy"])) < 1e-4
-    for kw in (dict(bf16=True), dict(f16=True)):
+    for kw in (dict(mfma16=True), dict(f16=True)):
         r16 = gx.score(cx["lig_pos"], 0.5, edges=r["edges"], energy=True, **kw)
         assert np.isfinite(r16["f"]).all() and rel_inf(r16["f"][0], o["f"]) < 2e-2
     gx.close(); m.close()
@@ -90,14 +90,14 @@ def test_randomised_launch_shapes(blob):
         gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
         poses = np.stack([cx["lig_pos"] + rng.normal(0, 1.0, 3).astype(np.float32) for _ in range(B)])
         ref = gx.score(poses, 0.3, seed=it, energy=True, debug=True)
-        full = gx.score(poses, 0.3, edges=ref["edges"], energy=True, bf16=True)
-        lean = gx.score(poses, 0.3, edges=ref["edges"], bf16=True)
+        full = gx.score(poses, 0.3, edges=ref["edges"], energy=True, mfma16=True)
+        lean = gx.score(poses, 0.3, edges=ref["edges"], mfma16=True)
         for k in ("f", "tr_score", "rot_score"):
             assert (full[k] == lean[k]).all(), (R, L, B, k)
         dev = np.abs(full["f"].astype(np.float64) - ref["f"]).max() / max(np.abs(ref["f"]).max(), 1e-30)
         assert dev < 1e-2 and abs(float(np.abs(full["energy"] - ref["energy"]).max())) < 3e-2, (R, L, B, dev)
-        s1 = gx.sample(B=B, num_steps=3, seed=it, bf16=True)
-        s2 = gx.sample(B=1, num_steps=3, seed=it, bf16=True)
+        s1 = gx.sample(B=B, num_steps=3, seed=it, mfma16=True)
+        s2 = gx.sample(B=1, num_steps=3, seed=it, mfma16=True)
         assert np.isfinite(s1["lig_pos"]).all() and (s1["lig_pos"][0] == s2["lig_pos"][0]).all(), (R, L, B)
         gx.close()
     model.close()

@@ -57,16 +57,16 @@ def test_pair_family_fp32_vs_reference_golden(case, blob_pair):
 
 
 # (h_last, f, tr_score, rot_score, energy | confidence)
-PAIR_TOL = {"bf16": (3e-2, 1e-2, 1e-2, 1e-2, 3e-2), "f16": (3e-2, 1e-2, 1e-2, 1e-2, 3e-2)}
+PAIR_TOL = {"mfma16": (3e-2, 1e-2, 1e-2, 1e-2, 3e-2), "f16": (3e-2, 8e-3, 8e-3, 8e-3, 1e-2)}
 
 
-@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("prec", ["mfma16", "f16"])
 @pytest.mark.parametrize("case", CASES)
 def test_pair_family_mfma_vs_reference_golden(case, prec, blob_pair):
     g = load_golden(case + ".npz")
     gx, _ = gpu_complex(case, blob_pair)
     th, tf, ttr, trot, te = PAIR_TOL[prec]
-    r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, bf16=prec == "bf16", f16=prec == "f16", debug=True)
+    r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, mfma16=prec == "mfma16", f16=prec == "f16", debug=True)
     assert rel_inf(r["h_last"][0], g["h_last"]) < th
     assert rel_inf(r["f"][0], g["f"]) < tf
     assert rel_inf(r["tr_score"][0], g["tr_score"].reshape(3)) < ttr
@@ -144,8 +144,8 @@ def test_pair_family_dist_logits_vs_reference(blob_pair):
     for case, key, stride in (("fwd2_syn_24_16", "syn_24_16", 1), ("fwd2_7CEI_p1", "cei_p1_stride8", 8)):
         g = load_golden(case + ".npz")
         gx, cx = gpu_complex(case, blob_pair)
-        for prec, tol in (("fp32", 1e-4), ("bf16", 1e-2), ("f16", 1e-2)):
-            r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, dist=True, bf16=prec == "bf16", f16=prec == "f16")
+        for prec, tol in (("fp32", 1e-4), ("mfma16", 1e-2), ("f16", 1e-2)):
+            r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, dist=True, mfma16=prec == "mfma16", f16=prec == "f16")
             got = r["dist_logits"][0][::stride, ::stride]
             assert got.shape == d[key].shape and rel_inf(got, d[key]) < tol, (case, prec, rel_inf(got, d[key]))
         rb = gx.score(np.stack([g["lig_pos"]] * 2), float(g["t"]), edges=np.stack([g["edges"]] * 2), dist=True)

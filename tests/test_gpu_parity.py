@@ -66,18 +66,18 @@ def test_score_fp32_vs_reference_golden(case, model, blob):
 
 
 # 16-bit MFMA engines: (h_last, f, tr_score, rot_score, energy) gates = SURVEY 8(d)'s for 16-bit kernels (1e-2 on f and both
-# scores, 3e-2 on energy), for the shipped engine ("bf16" = DFM_F_MFMA16: fp16 operands in every layer) and its fp32-A_i variant
+# scores, 3e-2 on energy), for the shipped engine ("mfma16" = DFM_F_MFMA16: fp16 operands in every layer) and its fp32-A_i variant
 # ("f16").  Measured worst over four weight draws x two families: 5.5e-3 / 3.2e-3 / 3.3e-3 / 2.4e-3 (profiles/r03_tol_report.txt).
-MFMA_TOL = {"bf16": (3e-2, 1e-2, 1e-2, 1e-2, 3e-2), "f16": (3e-2, 1e-2, 1e-2, 1e-2, 3e-2)}
+MFMA_TOL = {"mfma16": (3e-2, 1e-2, 1e-2, 1e-2, 3e-2), "f16": (3e-2, 8e-3, 8e-3, 8e-3, 1e-2)}      # f16: its own measured worst case over four draws is 5.7e-3 (f) / 2.8e-3 (energy)
 
 
-@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("prec", ["mfma16", "f16"])
 @pytest.mark.parametrize("case", FWD_CASES)
 def test_score_mfma_vs_reference_golden(case, prec, model):
     g = load_golden(case + ".npz")
     gx, _ = gpu_complex(model, case)
     th, tf, ttr, trot, te = MFMA_TOL[prec]
-    r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, bf16=prec == "bf16", f16=prec == "f16", debug=True)
+    r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, mfma16=prec == "mfma16", f16=prec == "f16", debug=True)
     assert rel_inf(r["h_last"][0], g["h_last"]) < th
     assert rel_inf(r["f"][0], g["f"]) < tf
     assert rel_inf(r["tr_score"][0], g["tr_score"].reshape(3)) < ttr
@@ -92,8 +92,8 @@ def test_batched_equals_single(model):
     poses = np.stack([load_golden(f"fwd_7CEI_p{i}.npz")["lig_pos"] for i in range(4)] * 3)[:11]
     ts = np.linspace(1.0, 0.001, 11).astype(np.float32)
     edges = np.stack([load_golden(f"fwd_7CEI_p{i}.npz")["edges"] for i in range(4)] * 3)[:11]
-    for prec in ("fp32", "bf16", "f16"):
-        kw = dict(bf16=prec == "bf16", f16=prec == "f16")
+    for prec in ("fp32", "mfma16", "f16"):
+        kw = dict(mfma16=prec == "mfma16", f16=prec == "f16")
         rb = gx.score(poses, ts, edges=edges, energy=True, **kw)
         for i in (0, 5, 10):
             r1 = gx.score(poses[i], ts[i], edges=edges[i], energy=True, **kw)
@@ -102,20 +102,20 @@ def test_batched_equals_single(model):
 
 
 @pytest.mark.parametrize("case,steps", [("rollout_syn_24_16", 40), ("rollout_syn_64_48", 40), ("rollout_7CEI", 6)])
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("prec", ["fp32", "mfma16", "f16"])
 def test_sampler_injected_rollout(case, steps, prec, model):
     bf16 = prec != "fp32"
     g = load_golden(case + ".npz")
     gx, _ = gpu_complex(model, case)
     inj = dict(R0=g["R0"].astype(np.float32), tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"])
-    r = gx.sample(B=1, num_steps=steps, inject=inj, trace=True, bf16=prec == "bf16", f16=prec == "f16")
+    r = gx.sample(B=1, num_steps=steps, inject=inj, trace=True, mfma16=prec == "mfma16", f16=prec == "f16")
     np.testing.assert_allclose(r["init_pose"][0], g["init_pose"], atol=3e-5)
     ca, ref = r["trace_pose"][0][:, :, 1, :], g["poses"][:, :, 1, :]
     rmsd = np.sqrt(((ca - ref) ** 2).sum(-1).mean(-1))
     n5 = min(5, steps)
     assert rmsd[:n5].max() < (0.5 if bf16 else 0.05), rmsd[:n5]          # gate 3
     assert rmsd.max() < 0.5, rmsd.max()      # all 40 steps, every engine (measured: 3.4e-2 A bf16, 3.1e-3 A f16)
-    tol = {"fp32": 1e-4, "bf16": 1e-2, "f16": 1e-2}[prec]
+    tol = {"fp32": 1e-4, "mfma16": 1e-2, "f16": 1e-2}[prec]
     assert rel_inf(r["trace_scores"][0][0, 0:3], g["tr_score"][0]) < tol     # first evaluation = same pose
     assert rel_inf(r["trace_scores"][0][0, 3:6], g["rot_score"][0]) < tol
     if not bf16 and rmsd.max() < 1e-3:
@@ -187,9 +187,9 @@ def test_native_noise_statistics(model):
     distribution (E[angle] = pi/2 + 2/pi), reproducibility per seed."""
     gx, cx = gpu_complex(model, "fwd_syn_24_16")
     B = 2048
-    a = gx.sample(B=B, num_steps=2, seed=11, bf16=True, trace=True)
-    b = gx.sample(B=B, num_steps=2, seed=11, bf16=True, trace=True)
-    c = gx.sample(B=B, num_steps=2, seed=12, bf16=True, trace=True)
+    a = gx.sample(B=B, num_steps=2, seed=11, mfma16=True, trace=True)
+    b = gx.sample(B=B, num_steps=2, seed=11, mfma16=True, trace=True)
+    c = gx.sample(B=B, num_steps=2, seed=12, mfma16=True, trace=True)
     np.testing.assert_array_equal(a["lig_pos"], b["lig_pos"])
     assert np.abs(a["lig_pos"] - c["lig_pos"]).max() > 1.0
     c1, c2 = cx["rec_pos"][:, 1].mean(0), cx["lig_pos"][:, 1].mean(0)
@@ -228,8 +228,8 @@ def test_se3_equivariance_full_size(model, blob):
     gx2 = engine.Complex(model, cx2["rec_x"], cx2["lig_x"], cx2["rec_pos"], cx2["lig_pos"])
     B = 8
     base = gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.3, seed=5, energy=True, debug=True)
-    for prec, tol in (("fp32", 2e-3), ("bf16", 3e-2), ("f16", 6e-3)):
-        kw = dict(bf16=prec == "bf16", f16=prec == "f16")
+    for prec, tol in (("fp32", 2e-3), ("mfma16", 3e-2), ("f16", 6e-3)):
+        kw = dict(mfma16=prec == "mfma16", f16=prec == "f16")
         r1 = gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.3, edges=base["edges"], energy=True, **kw)
         r2 = gx2.score(np.repeat(cx2["lig_pos"][None], B, 0), 0.3, edges=base["edges"], energy=True, **kw)
         assert rel_inf(r2["tr_score"], r1["tr_score"] @ Rm.T) < tol

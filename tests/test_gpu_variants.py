@@ -53,17 +53,17 @@ def _inject(g, with_z=True):
     return inj
 
 
-ROLL_GATE = {"fp32": (0.05, 0.5), "bf16": (0.5, 0.5), "f16": (0.5, 0.5)}
+ROLL_GATE = {"fp32": (0.05, 0.5), "mfma16": (0.5, 0.5), "f16": (0.5, 0.5)}
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("prec", ["fp32", "mfma16", "f16"])
 @pytest.mark.parametrize("case,steps", [("rollout_anneal_syn_24_16", 40), ("rollout_anneal_7CEI", 6)])
 def test_noise_annealing_vs_reference(case, steps, prec, model):
     from dfmdock_amd import engine
     g = load_golden(case + ".npz")
     cx = complex_for(case)
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-    r = gx.sample(B=1, num_steps=steps, inject=_inject(g), trace=True, noise_annealing=True, bf16=prec == "bf16", f16=prec == "f16")
+    r = gx.sample(B=1, num_steps=steps, inject=_inject(g), trace=True, noise_annealing=True, mfma16=prec == "mfma16", f16=prec == "f16")
     rmsd = ca_rmsd(r["trace_pose"][0], g["poses"])
     g5, gall = ROLL_GATE[prec]
     assert rmsd[:5].max() < g5 and rmsd.max() < gall, rmsd
@@ -73,7 +73,7 @@ def test_noise_annealing_vs_reference(case, steps, prec, model):
     gx.close()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("prec", ["fp32", "mfma16", "f16"])
 @pytest.mark.parametrize("case,steps", [("rollout_ode_syn_24_16", 40), ("rollout_ode_7CEI", 6)])
 def test_ode_sampler_vs_reference(case, steps, prec, model):
     """The reference's ODE run comes from inference_mlsb.Sampler, which centres both chains first: its poses are this engine's
@@ -82,7 +82,7 @@ def test_ode_sampler_vs_reference(case, steps, prec, model):
     g = load_golden(case + ".npz")
     cx = complex_for(case)
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-    r = gx.sample(B=1, num_steps=steps, inject=_inject(g, with_z=False), trace=True, ode=True, bf16=prec == "bf16", f16=prec == "f16")
+    r = gx.sample(B=1, num_steps=steps, inject=_inject(g, with_z=False), trace=True, ode=True, mfma16=prec == "mfma16", f16=prec == "f16")
     np.testing.assert_allclose(r["init_pose"][0] - g["c1"], g["init_pose"], atol=1e-4)
     rmsd = ca_rmsd(r["trace_pose"][0] - g["c1"], g["poses"])
     g5, gall = ROLL_GATE[prec]
@@ -93,7 +93,7 @@ def test_ode_sampler_vs_reference(case, steps, prec, model):
     gx.close()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("prec", ["fp32", "mfma16", "f16"])
 @pytest.mark.parametrize("case,steps", [("rollout2_syn_24_16", 40), ("rollout2_7CEI", 6)])
 def test_pair_family_sampler_vs_reference(case, steps, prec, model_pair):
     """src/inference.py's sampler: randomize_pose / modify_coords about the all-backbone-atom centroids."""
@@ -102,7 +102,7 @@ def test_pair_family_sampler_vs_reference(case, steps, prec, model_pair):
     g = load_golden(case + ".npz")
     cx = complex_for(case)
     gx = engine.Complex(model_pair, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-    r = gx.sample(B=1, num_steps=steps, inject=_inject(g), trace=True, bf16=prec == "bf16", f16=prec == "f16")
+    r = gx.sample(B=1, num_steps=steps, inject=_inject(g), trace=True, mfma16=prec == "mfma16", f16=prec == "f16")
     np.testing.assert_allclose(r["init_pose"][0], g["init_pose"], atol=5e-5)
     rmsd = ca_rmsd(r["trace_pose"][0], g["poses"])
     g5, gall = ROLL_GATE[prec]
@@ -129,8 +129,8 @@ def test_sym_channel_vs_reference(flag):
     cx = complex_for("syn_24_16")
     gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
     gx.set_homomer(bool(flag))
-    for prec, tol in (("fp32", 1e-4), ("bf16", 1e-2), ("f16", 1e-2)):
-        r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, bf16=prec == "bf16", f16=prec == "f16")
+    for prec, tol in (("fp32", 1e-4), ("mfma16", 1e-2), ("f16", 1e-2)):
+        r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, mfma16=prec == "mfma16", f16=prec == "f16")
         assert rel_inf(r["f"][0], g["f"]) < tol and rel_inf(r["tr_score"][0], g["tr_score"].reshape(3)) < tol, prec
         assert abs(float(r["energy"][0]) - float(g["energy"])) < max(tol, 3e-2 if prec != "fp32" else tol) * max(1.0, abs(float(g["energy"])))
         assert abs(float(r["confidence"][0]) - float(g["confidence_logits"])) < max(tol, 3e-2 if prec != "fp32" else tol)
@@ -158,7 +158,7 @@ def test_ires_vs_reference(case, model):
     r = gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, ires=True)
     assert r["ires"].shape == (1, gx.N)
     assert rel_inf(r["ires"][0], g["ires"][:, 0]) < 1e-4
-    r16 = gx.score(np.stack([g["lig_pos"]] * 3), float(g["t"]), edges=np.stack([e] * 3), energy=False, ires=True, bf16=True)
+    r16 = gx.score(np.stack([g["lig_pos"]] * 3), float(g["t"]), edges=np.stack([e] * 3), energy=False, ires=True, mfma16=True)
     assert rel_inf(r16["ires"][2], g["ires"][:, 0]) < 3e-2
     gx.close()
 
@@ -194,13 +194,13 @@ def test_graphnorm_large_mean_channels(blob):
     o = ora.Oracle(blob2, cx).score(g["lig_pos"], float(g["t"]), edges=g["edges"])
     r32 = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, debug=True)
     assert rel_inf(r32["h_last"][0], o["h_layers"][-1]) < 1e-4 and rel_inf(r32["f"][0], o["f"]) < 1e-4
-    for prec, th, tf in (("f16", 3e-2, 1e-2), ("bf16", 3e-2, 1e-2)):
-        r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, debug=True, bf16=prec == "bf16", f16=prec == "f16")
+    for prec, th, tf in (("f16", 3e-2, 1e-2), ("mfma16", 3e-2, 1e-2)):
+        r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, debug=True, mfma16=prec == "mfma16", f16=prec == "f16")
         assert rel_inf(r["h_last"][0], o["h_layers"][-1]) < th, prec
         assert rel_inf(r["f"][0], o["f"]) < tf and rel_inf(r["tr_score"][0], o["tr_score"].reshape(3)) < tf, prec
     # batched == single stays bit-exact with the new statistics
-    rb = gx.score(np.stack([g["lig_pos"]] * 5), float(g["t"]), edges=np.stack([g["edges"]] * 5), energy=True, bf16=True)
-    r1 = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, bf16=True)
+    rb = gx.score(np.stack([g["lig_pos"]] * 5), float(g["t"]), edges=np.stack([g["edges"]] * 5), energy=True, mfma16=True)
+    r1 = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, mfma16=True)
     for k in ("f", "tr_score", "rot_score", "energy"):
         np.testing.assert_array_equal(rb[k][3], r1[k][0])
     gx.close(); m.close()
@@ -266,7 +266,7 @@ def test_tile_tasks_equal_node_tasks_bitwise(tmp_path):
         cx = make_complex(120, 94, seed=3)
         gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
         B = int(sys.argv[2])
-        r = gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.5, seed=5, bf16=True, energy=True, debug=True)
+        r = gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.5, seed=5, mfma16=True, energy=True, debug=True)
         np.savez(sys.argv[1], **{{k: r[k][0] for k in ("f", "tr_score", "rot_score", "energy", "edges", "h_first", "h_last")}})
     """))
     outs = {}
@@ -298,9 +298,9 @@ def test_engine_variants_stay_within_the_16bit_gate(tmp_path):
         cx = make_complex(150, 110, seed=4)
         gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
         poses = np.repeat(cx["lig_pos"][None], 3, 0)
-        r = gx.score(poses, 0.4, seed=7, bf16=True, energy=True, return_edges=True)
+        r = gx.score(poses, 0.4, seed=7, mfma16=True, energy=True, return_edges=True)
         out = {{"cfg": np.array(engine.config_string())}}
-        for tag, kw in (("", dict(bf16=True)), ("32", {{}}), ("_a32", dict(f16=True)), ("_bf", dict(bf16=True, bf16_ops=True))):
+        for tag, kw in (("", dict(mfma16=True)), ("32", {{}}), ("_a32", dict(f16=True)), ("_bf", dict(mfma16=True, bf16_ops=True))):
             x = gx.score(poses, 0.4, edges=r["edges"], energy=True, **kw)
             out.update({{k + tag: x[k] for k in ("f", "tr_score", "rot_score", "energy")}})
         np.savez(sys.argv[1], **out)
@@ -338,7 +338,7 @@ def test_guards_and_optional_heads(blob):
     gx = engine.Complex(engine.Model(blob), cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
     B = (1 << 31) // (60 * 60 * 4) + 1                     # 149 131 trajectories of 60 nodes
     with pytest.raises(ValueError, match="split the batch"):
-        gx.sample(B=B, num_steps=2, seed=1, bf16=True)
+        gx.sample(B=B, num_steps=2, seed=1, mfma16=True)
     gx.close()
     batch = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in cx.items()}
     batch["t"] = torch.tensor([0.4])
@@ -349,7 +349,7 @@ def test_guards_and_optional_heads(blob):
         assert torch.equal(a[k], b[k]), k
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("prec", ["fp32", "mfma16", "f16"])
 def test_ligand_only_last_layer_changes_nothing(prec, model):
     """When nobody reads the final node features (no energy / ires / debug tap) the last layer computes the messages of the ligand
     nodes only and skips its node model (score_net_mlsb.py:383-398: the force needs pos_out of the ligand nodes alone).  f and both
@@ -357,7 +357,7 @@ def test_ligand_only_last_layer_changes_nothing(prec, model):
     run without traces (ligand-only in its 40 step evaluations) must end on the bitwise same pose as one with traces (full)."""
     from dfmdock_amd import engine
     from dfmdock_amd.synthetic import make_complex
-    kw = dict(bf16=prec == "bf16", f16=prec == "f16")
+    kw = dict(mfma16=prec == "mfma16", f16=prec == "f16")
     for (R, L, B) in [(64, 48, 3), (24, 16, 1), (129, 67, 2)]:
         cx = make_complex(R, L, seed=11)
         gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
@@ -372,6 +372,46 @@ def test_ligand_only_last_layer_changes_nothing(prec, model):
         s_lean = gx.sample(B=B, num_steps=6, seed=9, **kw)
         assert (s_full["lig_pos"] == s_lean["lig_pos"]).all() and (s_full["energy"] == s_lean["energy"]).all(), (R, L, B)
         gx.close()
+
+
+@pytest.mark.parametrize("family", [0, 1])
+@pytest.mark.parametrize("depth", [1, 2, 3, 5])
+def test_other_depths_both_families_lean_equals_full(depth, family):
+    """the final node features end in W.h or W.h2 depending on the parity of the depth, and the pair heads of the
+    second family read W.h on EVERY evaluation - with an odd depth and no energy / debug request they were fed the penultimate
+    layer's features (default depth 6 hid it).  For depth 1 / 2 / 3 / 5 and both families: the fp32 engine against the oracle on the
+    same graph, and for every engine the lean call (no energy, no taps - what the sampler's step evaluations issue) bitwise equal to
+    the full one, including the h_first tap of a depth-1 model (its first layer is its last)."""
+    from dfmdock_amd import engine
+    from dfmdock_amd.synthetic import make_complex
+    from dfmdock_amd.weights import HParams, make_random_weights, pack_blob
+    from oracle import oracle as ora
+    hp = HParams(depth=depth, **({"family": 1, "mask_dist": 20.0} if family else {}))
+    blob = pack_blob(make_random_weights(3, hp), hp)
+    engine.set_device(0)
+    m = engine.Model(blob, hp)
+    cx = make_complex(40, 33, seed=21)
+    gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    poses = np.stack([cx["lig_pos"], cx["lig_pos"] + np.float32(0.8)])
+    full = gx.score(poses, 0.35, seed=2, energy=True, debug=True)
+    o = ora.Oracle(blob, cx, hp)
+    for b in range(2):
+        r = o.score(poses[b], 0.35, edges=full["edges"][b])
+        assert rel_inf(full["f"][b], r["f"]) < 1e-4 and rel_inf(full["tr_score"][b], np.asarray(r["tr_score"]).reshape(3)) < 1e-4, (depth, family, b)
+        assert rel_inf(full["rot_score"][b], np.asarray(r["rot_score"]).reshape(3)) < 1e-4
+        assert abs(float(full["energy"][b]) - float(r["energy"])) < 1e-4 * max(1.0, abs(float(r["energy"])))
+    for kw in ({}, dict(mfma16=True), dict(f16=True)):
+        ref = gx.score(poses, 0.35, edges=full["edges"], energy=True, debug=True, **kw)
+        lean = gx.score(poses, 0.35, edges=full["edges"], energy=False, **kw)
+        for k in ("f", "tr_score", "rot_score"):
+            assert (lean[k] == ref[k]).all(), (depth, family, kw, k)
+        if kw:
+            assert rel_inf(ref["f"], full["f"]) < 1e-2 and rel_inf(ref["tr_score"], full["tr_score"]) < 1e-2
+        s_full = gx.sample(B=2, num_steps=4, seed=9, trace=True, **kw)
+        s_lean = gx.sample(B=2, num_steps=4, seed=9, **kw)
+        assert (s_full["lig_pos"] == s_lean["lig_pos"]).all() and (s_full["energy"] == s_lean["energy"]).all(), (depth, family, kw)
+    gx.close()
+    m.close()
 
 
 def test_narrow_gemm_tiles_equal_wide_tiles_bitwise(tmp_path):
@@ -392,8 +432,8 @@ def test_narrow_gemm_tiles_equal_wide_tiles_bitwise(tmp_path):
         cx = make_complex(120, 94, seed=3)
         gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
         B = int(sys.argv[2])
-        r = gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.5, seed=5, bf16=True, energy=True, debug=True)
-        s = gx.sample(B=B, num_steps=5, seed=4, bf16=True)
+        r = gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.5, seed=5, mfma16=True, energy=True, debug=True)
+        s = gx.sample(B=B, num_steps=5, seed=4, mfma16=True)
         out = {{k: r[k][0] for k in ("f", "tr_score", "rot_score", "energy", "edges", "h_first", "h_last")}}
         out.update(pose=s["lig_pos"][0], final_energy=s["energy"][0])
         np.savez(sys.argv[1], **out)

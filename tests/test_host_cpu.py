@@ -249,6 +249,53 @@ def test_init_falls_back_from_nccl_and_gathers(tmp_path, mode):
     assert a["tmax"] == 2.5 and a["tab"] == [[0.1, 7.0], [0.2, 8.0]]
 
 
+def test_file_gather_ignores_a_previous_jobs_files(tmp_path):
+    """a second job (or a restarted rank) that reuses DFM_GATHER_DIR must not read the earlier run's records, and
+    barrier() must stay a barrier.  Two jobs run back to back in ONE directory, the second with different records, and the
+    directory is salted with files in the old naming scheme (round000001_rank1.npy) holding poison; rank 1 of the second job starts
+    late, so rank 0 would return at once if it accepted anything already lying there."""
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent("""
+        import json, os, sys, time
+        import numpy as np
+        sys.path.insert(0, {root!r})
+        from dfmdock_amd import distributed as D
+        rank, _, world = D.dist_env()
+        time.sleep(float(os.environ.get("START_DELAY", "0")) * rank)
+        g = D.init(prefer="file")
+        base = float(os.environ["JOB_BASE"])
+        rec = np.full((2, D.RECORD_WIDTH), base + rank, np.float32)
+        a = D.gather_records(rec)
+        D.barrier()
+        objs = D.gather_objects({{"rank": rank, "base": base}})
+        json.dump(dict(vals=sorted(set(a[:, 0].tolist())), n=int(a.shape[0]), objs=objs), open(os.path.join({out!r}, f"job{{int(base)}}_{{rank}}.json"), "w"))
+        D.shutdown()
+    """).format(root=ROOT, out=str(tmp_path)))
+    gdir = tmp_path / "gather"
+    gdir.mkdir()
+    poison = np.full((2, 10), -777.0, np.float32)
+    for r in range(2):
+        np.save(gdir / f"round000001_rank{r}.npy", poison)
+        np.save(gdir / f"round000002_rank{r}.npy", poison[:0])
+    for base, delay in ((100, "0"), (200, "1.0")):
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", DFM_GATHER_DIR=str(gdir), JOB_BASE=str(base), START_DELAY=delay)
+            for k in ("MASTER_PORT", "DFM_DIST_BACKEND", "DFM_JOB_ID"):
+                env.pop(k, None)
+            procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+        for r in range(2):
+            o = json.load(open(tmp_path / f"job{base}_{r}.json"))
+            assert o["vals"] == [float(base), float(base + 1)] and o["n"] == 4, o       # this job's records only
+            assert [x["base"] for x in o["objs"]] == [float(base)] * 2 and [x["rank"] for x in o["objs"]] == [0, 1]
+    # a finished job leaves only its closing round behind (two small files), not one file per round and rank
+    left = [n for n in os.listdir(gdir) if not n.startswith("round0")]
+    assert len(left) <= 4, left
+
+
 def test_dfmdock_wrapper_helpers_match_reference():
     """DFMDock.modify_coords / move_to_lig_center (DFMDock.py:246-257) against values produced by the reference."""
     import numpy as np

@@ -19,7 +19,7 @@ for k, (R, L) in enumerate(sizes):
     cxs.append(c)
 out = os.path.join(tempfile.mkdtemp(), "c4.csv")
 t0 = time.perf_counter()
-rows, ranked = driver.run_set(model, cxs, num_samples=40, num_steps=40, seed=0, precision="bf16", out_csv=out)
+rows, ranked = driver.run_set(model, cxs, num_samples=40, num_steps=40, seed=0, precision="mfma16", out_csv=out)
 dt = time.perf_counter() - t0
 n = sum(1 for _ in open(out)) - 1
 print(f"C4-shaped: 24 complexes (N = {min(a+b for a,b in sizes)}..{max(a+b for a,b in sizes)}), 40 trajectories each, 40 steps: "

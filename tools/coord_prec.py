@@ -13,8 +13,8 @@ for case in ["fwd_syn_24_16", "fwd_7CEI_p1", "fwd_db5_1AVX", "fwd_db5_4POU", "fw
     g = load_golden(case + ".npz")
     cx = complex_for(case)
     gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-    for prec in ("fp32", "bf16", "f16"):
-        r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32), energy=True, bf16=prec == "bf16", f16=prec == "f16")
+    for prec in ("fp32", "mfma16", "f16"):
+        r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32), energy=True, mfma16=prec == "mfma16", f16=prec == "f16")
         df = r["f"][0].astype(np.float64) - g["f"]
         print(f"COORD_F16={os.environ.get('DFM_COORD_F16', '0')} {case:16s} {prec:5s} max|f| {np.abs(g['f']).max():.3e} |mean f| {np.abs(g['f'].mean(0)).max():.3e} "
               f"max|df| {np.abs(df).max():.2e} |mean df| {np.abs(df.mean(0)).max():.2e} rms df {np.sqrt((df**2).mean()):.2e} "

@@ -17,8 +17,8 @@ import numpy as np
 from conftest import DRAWS, DRAW_CASES, complex_for, draw_blob, draw_golden, draw_hparams, load_golden, pair_hparams
 
 
-# engine selections: "bf16" = the 16-bit MFMA engine as shipped (DFM_F_MFMA16: fp16 operands), "bf16ops" = + DFM_F_BF16_OPS
-KW = {"fp32": {}, "bf16": dict(bf16=True), "f16": dict(f16=True), "bf16ops": dict(bf16=True, bf16_ops=True)}
+# engine selections: "mfma16" = the 16-bit MFMA engine as shipped (DFM_F_MFMA16: fp16 operands), "bf16ops" = + DFM_F_BF16_OPS
+KW = {"fp32": {}, "mfma16": dict(mfma16=True), "f16": dict(f16=True), "bf16ops": dict(mfma16=True, bf16_ops=True)}
 
 
 def rel(a, b):
@@ -26,7 +26,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def main(fams=(0, 1), draws=("s0",) + tuple(DRAWS), precs=("fp32", "bf16", "f16"), per_case=False):
+def main(fams=(0, 1), draws=("s0",) + tuple(DRAWS), precs=("fp32", "mfma16", "f16"), per_case=False):
     from dfmdock_amd import engine
     from dfmdock_amd.weights import make_random_weights, pack_blob
     engine.set_device(0)

@@ -16,7 +16,7 @@ cx = make_complex(300, 300, seed=1)
 gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
 poses = np.repeat(cx["lig_pos"][None], B, 0)
 for it in range(3):
-    gx.score(poses, 0.5, seed=it, bf16=True, energy=False, profile=True)
+    gx.score(poses, 0.5, seed=it, mfma16=True, energy=False, profile=True)
     p = gx.profile()
     ph = p["phase_cycles"]
     print(f"edge launch avg {p['edge_kernel_ms'] / p['edge_kernel_launches']:.3f} ms | cycles per tile and wave: prologue {ph[0]:.0f}  "

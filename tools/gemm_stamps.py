@@ -9,4 +9,4 @@ m = engine.Model(pack_blob(make_random_weights(0)))
 cx = make_complex(300, 300, seed=1)
 gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.5, seed=1, bf16=True, energy=False)
+gx.score(np.repeat(cx["lig_pos"][None], B, 0), 0.5, seed=1, mfma16=True, energy=False)

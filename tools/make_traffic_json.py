@@ -45,7 +45,7 @@ if res:
     alg = 8 * N * H * B * (6 * E - 0.5 * (E - 1)) / (6 * E)
     tot = sum(d["hbm_bytes"] * d["launches"] for d in res.values()) / sum(d["launches"] for d in res.values())
     w = lambda key: sum(d[key] * d["launches"] for d in res.values()) / sum(d["launches"] for d in res.values())
-    js = {"kernel": " / ".join(sorted(res)), "config": {"R": 300, "L": 300, "batch": 256, "precision": "bf16"},
+    js = {"kernel": " / ".join(sorted(res)), "config": {"R": 300, "L": 300, "batch": 256, "precision": "mfma16"},
           "source": "tools/final_profile.sh on MI355X: rocprofv3 --pmc, one counter set per run, kernel-filtered, no trace domains; "
                     "FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE; busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs and "
                     "SQ_ACTIVE_INST_VALU x 4 / 1024 over GRBM_GUI_ACTIVE / 8",

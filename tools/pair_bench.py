@@ -17,7 +17,7 @@ engine.set_device(0)
 model = engine.Model(pack_blob(make_random_weights(0, hp), hp), hp)
 cases = ["fwd2_syn_24_16", "fwd2_syn_64_48_p0", "fwd2_syn_64_48_p1", "fwd2_syn_64_48_p2", "fwd2_7CEI_p0", "fwd2_7CEI_p1", "fwd2_7CEI_p2"]
 cache = {}
-for prec in ("fp32", "bf16", "f16"):
+for prec in ("fp32", "mfma16", "f16"):
     worst = np.zeros(6)
     for c in cases:
         g = load_golden(c + ".npz")
@@ -25,7 +25,7 @@ for prec in ("fp32", "bf16", "f16"):
         if key not in cache:
             cx = complex_for(c)
             cache[key] = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-        r = cache[key].score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, bf16=prec == "bf16", f16=prec == "f16", debug=True)
+        r = cache[key].score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, mfma16=prec == "mfma16", f16=prec == "f16", debug=True)
         v = np.array([rel(r["h_last"][0], g["h_last"]), rel(r["f"][0], g["f"]), rel(r["tr_score"][0], g["tr_score"][0]),
                       rel(r["rot_score"][0], g["rot_score"][0]), abs(float(r["energy"][0]) - float(g["energy"])) / max(abs(float(g["energy"])), 0.1),
                       abs(float(r["confidence"][0]) - float(g["confidence_logits"]))])
@@ -35,9 +35,9 @@ if len(sys.argv) > 1:
     B = int(sys.argv[1])
     cx = make_complex(300, 300, seed=1)
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-    for prec in ("bf16",):
-        gx.sample(B=B, num_steps=4, seed=1, bf16=True)
+    for prec in ("mfma16",):
+        gx.sample(B=B, num_steps=4, seed=1, mfma16=True)
         t0 = time.perf_counter()
-        gx.sample(B=B, num_steps=40, seed=2, bf16=True)
+        gx.sample(B=B, num_steps=40, seed=2, mfma16=True)
         dt = time.perf_counter() - t0
         print(f"C3-shaped 300+300, B={B}, 40 steps, {prec}: {dt*1e3:.0f} ms -> {B/dt:.1f} trajectories/s")

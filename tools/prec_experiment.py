@@ -16,7 +16,7 @@ model = engine.Model(pack_blob(make_random_weights(0)))
 cases = ["fwd_syn_24_16", "fwd_syn_64_48_p0", "fwd_syn_64_48_p1", "fwd_syn_64_48_p2", "fwd_7CEI_p0", "fwd_7CEI_p1", "fwd_7CEI_p2", "fwd_7CEI_p3"]
 cache = {}
 F16 = len(sys.argv) > 1 and sys.argv[1] == "f16"
-print("MFMA operands:", "fp16" if F16 else "bf16")
+print("MFMA operands:", "fp16" if F16 else "mfma16")
 worst = np.zeros(5)
 for c in cases:
     g = load_golden(c + ".npz")
@@ -24,7 +24,7 @@ for c in cases:
     if key not in cache:
         cx = complex_for(c)
         cache[key] = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-    r = cache[key].score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, bf16=not F16, f16=F16, debug=True)
+    r = cache[key].score(g["lig_pos"], float(g["t"]), edges=g["edges"], energy=True, mfma16=not F16, f16=F16, debug=True)
     v = np.array([rel(r["h_last"][0], g["h_last"]), rel(r["f"][0], g["f"]), rel(r["tr_score"][0], g["tr_score"][0]),
                   rel(r["rot_score"][0], g["rot_score"][0]), abs(float(r["energy"][0]) - float(g["energy"])) / max(abs(float(g["energy"])), 0.1)])
     worst = np.maximum(worst, v)

@@ -12,9 +12,9 @@ for (R, L, Bs) in [(300, 300, (1, 8, 64, 256, 512)), (100, 60, (64, 1024)), (100
     cx = make_complex(R, L, seed=1)
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
     for B in Bs:
-        gx.sample(B=B, num_steps=2, seed=1, bf16=True)
+        gx.sample(B=B, num_steps=2, seed=1, mfma16=True)
         t0 = time.perf_counter()
-        o = gx.sample(B=B, num_steps=40, seed=2, bf16=True)
+        o = gx.sample(B=B, num_steps=40, seed=2, mfma16=True)
         dt = time.perf_counter() - t0
         ok = np.isfinite(o["lig_pos"]).all() and np.isfinite(o["energy"]).all()
         print(f"{R}+{L} B={B:5d}: {dt*1e3:9.1f} ms  {B/dt:8.1f} traj/s  finite={ok}  E[min,mean]={o['energy'].min():.3f},{o['energy'].mean():.3f}")

@@ -23,7 +23,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
     poses = np.stack([cx["lig_pos"] + rng.normal(0, 1.0, 3).astype(np.float32) for _ in range(B)])
     ref = gx.score(poses, 0.3, seed=it, energy=True, debug=True)
-    for tag, kw in (("bf16", dict(bf16=True)), ("f16", dict(f16=True))):
+    for tag, kw in (("mfma16", dict(mfma16=True)), ("f16", dict(f16=True))):
         full = gx.score(poses, 0.3, edges=ref["edges"], energy=True, **kw)
         lean = gx.score(poses, 0.3, edges=ref["edges"], **kw)
         assert all((full[k] == lean[k]).all() for k in ("f", "tr_score", "rot_score")), (R, L, B, tag)
@@ -32,8 +32,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
             assert np.isfinite(d), (R, L, B, tag, k)
             if d > worst.get((tag, k), (0,))[0]:
                 worst[(tag, k)] = (d, R, L, B)
-    s1 = gx.sample(B=B, num_steps=3, seed=it, bf16=True)
-    s2 = gx.sample(B=1, num_steps=3, seed=it, bf16=True)
+    s1 = gx.sample(B=B, num_steps=3, seed=it, mfma16=True)
+    s2 = gx.sample(B=1, num_steps=3, seed=it, mfma16=True)
     assert np.isfinite(s1["lig_pos"]).all() and (s1["lig_pos"][0] == s2["lig_pos"][0]).all(), (R, L, B, "batch-size invariance")
     gx.close()
 for k, v in sorted(worst.items()):

@@ -30,8 +30,8 @@ for fam, bl, hp, cases in ((0, blob, HParams(), ["fwd_syn_9_7", "fwd_syn_24_16",
         g = load_golden(case + ".npz")
         cx = complex_for(case)
         gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-        for prec in ("fp32", "bf16", "f16"):
-            r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32), energy=True, bf16=prec == "bf16", f16=prec == "f16")
+        for prec in ("fp32", "mfma16", "f16"):
+            r = gx.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32), energy=True, mfma16=prec == "mfma16", f16=prec == "f16")
             print(f"fam{fam} {case:20s} {prec:5s} f {rel(r['f'][0], g['f']):.2e} tr {rel(r['tr_score'][0], g['tr_score'].reshape(3)):.2e} "
                   f"rot {rel(r['rot_score'][0], g['rot_score'].reshape(3)):.2e} E {abs(float(r['energy'][0]) - float(g['energy'])) / max(abs(float(g['energy'])), 0.1):.2e}"
                   f"  |rot| {np.abs(g['rot_score']).max():.3e} |tr| {np.abs(g['tr_score']).max():.3e}")
