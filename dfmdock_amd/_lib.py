@@ -32,7 +32,7 @@ EXPORTS = [
     "dfm_last_error", "dfm_config_string", "dfm_device_count", "dfm_set_device", "dfm_default_hparams", "dfm_param_count",
     "dfm_model_create", "dfm_model_destroy", "dfm_complex_create", "dfm_complex_destroy", "dfm_complex_degree",
     "dfm_complex_set_pose", "dfm_complex_set_homomer",
-    "dfm_score", "dfm_sample", "dfm_get_profile", "dfm_diffusion_coef",
+    "dfm_score", "dfm_sample", "dfm_get_profile", "dfm_diffusion_coef", "dfm_complex_selfcheck",
 ]
 
 
@@ -63,6 +63,16 @@ class TrajOutC(C.Structure):
 class ProfileC(C.Structure):
     _fields_ = [("edge_kernel_ms", C.c_double), ("edge_kernel_launches", C.c_int64), ("edge_rows", C.c_int64),
                 ("total_ms", C.c_double), ("phase_cycles", C.c_double * 4), ("slot_cycles", C.c_double * 16)]
+
+
+class SelfcheckC(C.Structure):
+    _fields_ = [("n_eval", C.c_int), ("depth", C.c_int),
+                ("dev_f", C.c_float), ("dev_tr_score", C.c_float), ("dev_rot_score", C.c_float), ("dev_energy", C.c_float),
+                ("cancel_ratio", C.c_float * 2), ("score_bound", C.c_float * 2),
+                ("gate_f", C.c_float), ("gate_score", C.c_float), ("gate_energy", C.c_float), ("limit", C.c_float),
+                ("max_h", C.c_float * 9), ("max_A", C.c_float * 8), ("max_Bm", C.c_float * 8), ("max_tab", C.c_float * 8),
+                ("max_sum16", C.c_float * 8), ("max_pre", C.c_float * 8), ("max_acc", C.c_float * 8), ("headroom", C.c_float),
+                ("saturated", C.c_int64), ("range_ok", C.c_int), ("dev_ok", C.c_int), ("ok", C.c_int)]
 
 
 _lib = None
@@ -101,6 +111,7 @@ def lib():
     L.dfm_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint64,
                              C.POINTER(InjectC), C.POINTER(TrajOutC)]
     L.dfm_get_profile.argtypes = [C.c_void_p, C.POINTER(ProfileC)]
+    L.dfm_complex_selfcheck.argtypes = [C.c_void_p, C.c_int, F32P, C.c_uint64, C.c_uint32, C.POINTER(SelfcheckC)]
     L.dfm_diffusion_coef.argtypes = [C.POINTER(HParamsC), C.c_int, C.c_double, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
     _lib = L

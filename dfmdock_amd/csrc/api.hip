@@ -82,6 +82,7 @@ struct dfm_model {
     PairHeadDev pair[3];             // family 1: 0 to_force, 1 to_energy, 2 to_confidence
     PairHeadDev dist;                // family 1: to_dist (fp32 only; w3 = [256][64], transposed)
     float *ir0_w = nullptr, *ir0_b = nullptr, *ir2_w = nullptr, *ir2_b = nullptr, *ir4_w = nullptr, *ir4_b = nullptr;   // to_ires
+    float tab_max[8][2] = {};        // per layer: largest |entry| of the two merged lookup tables as stored (log2e-scaled; before the fp16 clamp)
 };
 
 struct Workspace {
@@ -340,20 +341,22 @@ extern "C" dfm_model *dfm_model_create(const float *blob, size_t n_floats, const
         // merged fp16 tables of the 16-bit MFMA kernel, pre-multiplied by SILU_S like every other SiLU input there
         const double S = (double)SILU_S;
         std::vector<uint16_t> T2b((size_t)NTAB2 * H);
+        double tmax[2] = {0, 0};      // range telemetry of dfm_complex_selfcheck
 #if DFM_TAB_MERGE
         for (int om = 0; om < 24; ++om)
             for (int th = 0; th < 24; ++th)
                 for (int ph = 0; ph < 12; ++ph) {
                     uint16_t *row = &T2b[(size_t)((om * 24 + th) * 12 + ph) * H];
                     const double *a = &Td[(size_t)(40 + om) * H], *b = &Td[(size_t)(64 + th) * H], *c3 = &Td[(size_t)(88 + ph) * H];
-                    for (int c = 0; c < H; ++c) row[c] = f2h((float)(S * (a[c] + b[c] + c3[c])));
+                    for (int c = 0; c < H; ++c) { const double v = S * (a[c] + b[c] + c3[c]); tmax[0] = std::fmax(tmax[0], std::fabs(v)); row[c] = f2h((float)v); }
                 }
         for (int rp = 0; rp < 66; ++rp)
             for (int d = 0; d < 40; ++d) {
                 uint16_t *row = &T2b[(size_t)(6912 + rp * 40 + d) * H];
                 const double *a = &Td[(size_t)(100 + rp) * H], *b = &Td[(size_t)d * H];
-                for (int c = 0; c < H; ++c) row[c] = f2h((float)(S * (a[c] + b[c])));
+                for (int c = 0; c < H; ++c) { const double v = S * (a[c] + b[c]); tmax[1] = std::fmax(tmax[1], std::fabs(v)); row[c] = f2h((float)v); }
             }
+        m->tab_max[l][0] = (float)tmax[0]; m->tab_max[l][1] = (float)tmax[1];
 #else
         for (int c = 0; c < H; ++c) {
             for (int om = 0; om < 24; ++om)
@@ -671,7 +674,41 @@ struct FwdOpts {
     int64_t edges_pitch = 0;              // elements between trajectories in edges_dev
     uint64_t seed = 0;
     float *h_first_out = nullptr;         // device [B][N][H] tap (dfm_score debug)
+    // dfm_complex_selfcheck only: running maxima (float bits) [depth + 1][8] = per layer |h in|, |A|, |Bm|, |pre-activation 0|,
+    // |pre-activation 2| of the fp32 pass; fp16 values found at the saturation value in A / Bm of a 16-bit pass
+    uint32_t *range = nullptr;
+    unsigned long long *sat = nullptr;
 };
+
+// largest |x| of a buffer -> *out (float bits; non-negative floats order like their bit patterns)
+__global__ void k_absmax(const float *__restrict__ x, long long n, uint32_t *__restrict__ out)
+{
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+// fp16 values at +-65504 (where every conversion of the 16-bit engine clamps) or beyond
+__global__ void k_sat_count(const uint16_t *__restrict__ x, long long n, unsigned long long *__restrict__ out)
+{
+    unsigned c = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) c += (x[i] & 0x7fffu) >= 0x7bffu;
+    for (int k = 32; k >= 1; k >>= 1) c += __shfl_xor(c, k, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+static hipError_t launch_absmax(const float *x, long long n, uint32_t *out, hipStream_t s)
+{
+    const long long want = (n + 255) / 256;
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, x, n, out);
+    return hipGetLastError();
+}
+static hipError_t launch_sat_count(const uint16_t *x, long long n, unsigned long long *out, hipStream_t s)
+{
+    const long long want = (n + 255) / 256;
+    hipLaunchKernelGGL(k_sat_count, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, x, n, out);
+    return hipGetLastError();
+}
 
 // One batched score evaluation of the poses in ws.lig_cur at times ws.t_dev; leaves f in ws.fvec, the
 // node features in ws.h and (optionally) the energy partials.  Everything is enqueued on cx->stream.
@@ -718,6 +755,20 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         e.lig_only = lig_only ? 1 : 0;
         e.agg_is_zero = (l > 0 && tile_tasks) ? 1 : 0;      // zeroed by the previous layer's node_mlp.3 GEMM
         e.stamp = (o.profile && l == 2) ? cx->stamp_dev : nullptr;
+        {   // selfcheck telemetry: what enters this layer
+            const long long nrow = l == 0 ? N : M;      // layer 0's operands are per complex, not per trajectory
+            if (o.range) {
+                uint32_t *rg = o.range + l * 8;
+                HIPCHK(launch_absmax(h, nrow * H, rg + 0, s));
+                HIPCHK(launch_absmax(e.A, nrow * H, rg + 1, s));
+                HIPCHK(launch_absmax(e.Bm, nrow * H, rg + 2, s));
+                e.range = rg + 3;
+            }
+            if (o.sat) {
+                if (e.Ah) HIPCHK(launch_sat_count(e.Ah, nrow * H, o.sat, s));
+                HIPCHK(launch_sat_count(e.Bmb, nrow * H, o.sat, s));
+            }
+        }
         // the per-edge message kernel, bracketed by HIP events on this stream when profiling (dfm_get_profile)
         auto message_launch = [&](const EdgeArgs &ea) -> int {
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -780,6 +831,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
     }
     // keep the final node features in W.h (depth even).  The pair heads of family 1 read W.h on EVERY evaluation (run_head below),
     // the heads of family 0 only when somebody asked for the node outputs
+    if (o.range && (o.need_node_out || pair_family)) HIPCHK(launch_absmax(h, (long long)M * H, o.range + depth * 8, s));
     if (h != W.h && (o.need_node_out || pair_family)) {
         HIPCHK(hipMemcpyAsync(W.h, h, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
@@ -1090,5 +1142,131 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
         if (out->final_scores) std::memcpy(out->final_scores + (size_t)b * 6, &sc[(size_t)b * 8], 6 * sizeof(float));
     }
     if (o.profile) return finish_profile(cx);
+    return DFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Runtime parity evidence for weights the build has never seen (include/dfmdock_amd.h: dfm_selfcheck_out).
+extern "C" int dfm_complex_selfcheck(dfm_complex *cx, int n_eval, const float *t_in, uint64_t seed, uint32_t flags, dfm_selfcheck_out *out)
+{
+    if (!cx || !out) return fail(DFM_E_INVALID, "NULL argument");
+    if (n_eval < 1 || n_eval > 16) return fail(DFM_E_INVALID, "n_eval must be in 1..16");
+    DEVICE_SCOPE(cx->device);
+    const int B = n_eval;
+    int rc = ensure_workspace(cx, B, true);
+    if (rc) return rc;
+    Workspace &W = cx->ws;
+    hipStream_t s = cx->stream;
+    const dfm_model *m = cx->m;
+    const int depth = m->hp.depth;
+    const size_t N = cx->N, L = cx->L, K = cx->K;
+    std::vector<float> t(B);
+    for (int b = 0; b < B; ++b) {
+        t[b] = t_in ? t_in[b] : (B == 1 ? 0.5f : 1.0f + (0.001f - 1.0f) * (float)b / (float)(B - 1));
+        if (!(t[b] >= 0.f && t[b] <= 1.f)) return fail(DFM_E_INVALID, "Invalid t (need 0 <= t <= 1)");
+    }
+    cx->prof = dfm_profile{};
+    cx->ev_used = 0;
+    cx->fwd_counter = 0;
+    DevPool tmp;
+    uint32_t *range_d = nullptr;
+    unsigned long long *sat_d = nullptr;
+    int32_t *edges_d = nullptr;
+    HIPCHK(tmp.alloc(&range_d, (size_t)(depth + 1) * 8)); HIPCHK(tmp.alloc(&sat_d, 1)); HIPCHK(tmp.alloc(&edges_d, (size_t)B * N * K));
+    HIPCHK(hipMemsetAsync(range_d, 0, (size_t)(depth + 1) * 8 * 4, s)); HIPCHK(hipMemsetAsync(sat_d, 0, 8, s));
+    for (int b = 0; b < B; ++b)
+        HIPCHK(hipMemcpyAsync(W.lig_cur + (size_t)b * L * 9, cx->lig0, L * 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(W.t_dev, t.data(), (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+
+    struct Res { std::vector<float> sc, f; };
+    auto run = [&](bool mfma, Res &r) -> int {
+        FwdOpts o;
+        o.bf16 = mfma; o.f16 = mfma && (flags & DFM_F_F16); o.bf16_ops = mfma && !o.f16 && (flags & DFM_F_BF16_OPS);
+        o.want_energy = true; o.need_node_out = true; o.seed = seed;
+        if (mfma) { o.edges_dev = edges_d; o.edges_pitch = (int64_t)N * K; o.sat = sat_d; }
+        else o.range = range_d;
+        int rc2 = enqueue_forward(cx, B, o);
+        if (rc2) return rc2;
+        HeadArgs ha;
+        fill_head_args(cx, B, true, &ha);
+        HIPCHK(launch_heads(ha, s));
+        r.sc.resize((size_t)B * 8); r.f.resize((size_t)B * L * 3);
+        HIPCHK(hipMemcpyAsync(r.sc.data(), W.scores, r.sc.size() * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(r.f.data(), W.fvec, r.f.size() * 4, hipMemcpyDeviceToHost, s));
+        if (!mfma) HIPCHK(hipMemcpyAsync(edges_d, W.edges, (size_t)B * N * K * 4, hipMemcpyDeviceToDevice, s));      // the graphs the fp32 pass drew
+        HIPCHK(hipStreamSynchronize(s));
+        return DFM_OK;
+    };
+    Res r32, r16;
+    std::vector<float4> ca(N);      // centred CA of the (one) pose: r of the torque pooling
+    if ((rc = run(false, r32)) != DFM_OK) { (void)hipStreamSynchronize(s); return rc; }
+    HIPCHK(hipMemcpy(ca.data(), W.ca4, N * sizeof(float4), hipMemcpyDeviceToHost));
+    if ((rc = run(true, r16)) != DFM_OK) { (void)hipStreamSynchronize(s); return rc; }
+    std::vector<uint32_t> rg((size_t)(depth + 1) * 8);
+    unsigned long long sat = 0;
+    HIPCHK(hipMemcpy(rg.data(), range_d, rg.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&sat, sat_d, 8, hipMemcpyDeviceToHost));
+
+    dfm_selfcheck_out &o = *out;
+    std::memset(&o, 0, sizeof(o));
+    o.n_eval = B; o.depth = depth;
+    o.gate_f = 1e-2f; o.gate_score = 1e-2f; o.gate_energy = 3e-2f; o.limit = 6.0e4f;
+    o.cancel_ratio[0] = o.cancel_ratio[1] = 1e30f;
+    auto dev_of = [](const float *a, const float *ref, size_t n) {      // L-inf over L-inf; NaN / inf anywhere -> NaN (never "ok")
+        double d = 0, mx = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (!std::isfinite(a[i]) || !std::isfinite(ref[i])) return std::nanf("");
+            d = std::fmax(d, std::fabs((double)a[i] - (double)ref[i])); mx = std::fmax(mx, std::fabs((double)ref[i]));
+        }
+        return (float)(d / std::fmax(mx, 1e-30));
+    };
+    auto worse = [](float cur, float v) { return (v != v || cur != cur) ? std::nanf("") : std::fmax(cur, v); };
+    const size_t R = cx->R;
+    for (int b = 0; b < B; ++b) {
+        const float *f32 = &r32.f[(size_t)b * L * 3], *f16 = &r16.f[(size_t)b * L * 3];
+        const float df = dev_of(f16, f32, L * 3);
+        o.dev_f = worse(o.dev_f, df);
+        o.dev_tr_score = worse(o.dev_tr_score, dev_of(&r16.sc[(size_t)b * 8], &r32.sc[(size_t)b * 8], 3));
+        o.dev_rot_score = worse(o.dev_rot_score, dev_of(&r16.sc[(size_t)b * 8 + 3], &r32.sc[(size_t)b * 8 + 3], 3));
+        const double e32 = r32.sc[(size_t)b * 8 + 6], e16 = r16.sc[(size_t)b * 8 + 6];
+        o.dev_energy = worse(o.dev_energy, (std::isfinite(e32) && std::isfinite(e16)) ? (float)(std::fabs(e16 - e32) / std::fmax(std::fabs(e32), 0.1)) : std::nanf(""));
+        // pooled force mean_l f and torque mean_l (r_l x f_l) (score_net_mlsb.py:396-405): cancellation ratios and the bounds they give
+        double mf[3] = {0, 0, 0}, mt[3] = {0, 0, 0}, af = 0, at = 0, fmax = 0, rmean = 0;
+        for (size_t l = 0; l < L; ++l) {
+            const float *v = f32 + l * 3;
+            const float4 r4 = ca[R + l];
+            const double r[3] = {r4.x, r4.y, r4.z};
+            const double c[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
+            for (int k = 0; k < 3; ++k) { mf[k] += v[k]; mt[k] += c[k]; fmax = std::fmax(fmax, std::fabs((double)v[k])); }
+            af += std::sqrt((double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2]);
+            at += std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+            rmean += std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        }
+        const double nf = std::sqrt(mf[0] * mf[0] + mf[1] * mf[1] + mf[2] * mf[2]) / (double)L;      // |mean f|
+        const double nt = std::sqrt(mt[0] * mt[0] + mt[1] * mt[1] + mt[2] * mt[2]) / (double)L;      // |mean r x f|
+        af /= (double)L; at /= (double)L; rmean /= (double)L;
+        o.cancel_ratio[0] = std::fmin(o.cancel_ratio[0], (float)(nf / std::fmax(af, 1e-30)));
+        o.cancel_ratio[1] = std::fmin(o.cancel_ratio[1], (float)(nt / std::fmax(at, 1e-30)));
+        const double dabs = std::sqrt(3.0) * (double)df * fmax;      // |d f_l| <= sqrt(3) dev_f max|f| for every l
+        o.score_bound[0] = worse(o.score_bound[0], (float)(dabs / std::fmax(nf, 1e-30)));
+        o.score_bound[1] = worse(o.score_bound[1], (float)(dabs * rmean / std::fmax(nt, 1e-30)));
+    }
+    const float LOG2E = -SILU_S;
+    auto val = [&](int l, int k) { return __builtin_bit_cast(float, rg[(size_t)l * 8 + k]); };
+    float worst = 0.f;
+    for (int l = 0; l <= depth; ++l) o.max_h[l] = val(l, 0);
+    for (int l = 0; l < depth; ++l) {
+        o.max_A[l] = LOG2E * val(l, 1); o.max_Bm[l] = LOG2E * val(l, 2);
+        o.max_tab[l] = std::fmax(m->tab_max[l][0], m->tab_max[l][1]);
+        o.max_sum16[l] = o.max_Bm[l] + m->tab_max[l][0] + m->tab_max[l][1];
+        o.max_pre[l] = LOG2E * val(l, 3); o.max_acc[l] = LOG2E * val(l, 4);
+        for (float v : {o.max_A[l], o.max_Bm[l], o.max_tab[l], o.max_sum16[l], o.max_pre[l], o.max_acc[l]}) worst = (v != v) ? INFINITY : std::fmax(worst, v);
+    }
+    o.headroom = worst > 0.f ? o.limit / worst : INFINITY;
+    o.saturated = (int64_t)sat;
+    o.range_ok = (worst < o.limit && sat == 0) ? 1 : 0;
+    const float gate_tr = std::fmax(o.gate_score, 2.0f * o.score_bound[0]), gate_rot = std::fmax(o.gate_score, 2.0f * o.score_bound[1]);
+    o.dev_ok = (o.dev_f <= o.gate_f && o.dev_energy <= o.gate_energy && o.dev_tr_score <= gate_tr && o.dev_rot_score <= gate_rot) ? 1 : 0;
+    o.ok = o.range_ok && o.dev_ok;
     return DFM_OK;
 }

@@ -56,6 +56,7 @@ struct EdgeKArgs {
     int split;                   // k_edge_msg: 1 = a wave task is one TILE (small launches), agg is pre-zeroed and added to atomically
     int node0, nodes;            // message kernels: the tasks cover nodes node0 .. node0 + nodes - 1 of every trajectory (all of them, or - last
                                  // layer when nobody reads the node outputs - the ligand nodes only: EdgeArgs::lig_only)
+    uint32_t *range;             // k_edge_f32, dfm_complex_selfcheck only: [0] max |pre-activation of edge_mlp.0|, [1] of edge_mlp.2, as float bits
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
     const float Ai = p.A[ab + (size_t)i * H + c];
     const float wr = p.w_r[c];
     // edge_mlp.0 + SiLU  (egnn.py:95-101)
+    float pre_max = 0.f;      // range telemetry (p.range): largest |pre-activation| this thread saw
     for (int s = 0; s < KF; ++s) {
         float v = 0.f;
         if (s < K) {
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
             pre += p.T[(size_t)(64u + ((code >> 11) & 31u)) * H + c];
             pre += p.T[(size_t)(88u + ((code >> 16) & 15u)) * H + c];
             pre += p.T[(size_t)(100u + ((code >> 20) & 127u)) * H + c];
+            pre_max = fmaxf(pre_max, fabsf(pre));
             v = silu_exact(pre);
         }
         rows[s * H + c] = v;
@@ -122,6 +125,17 @@ __global__ __launch_bounds__(256) void k_edge_f32(EdgeKArgs p)
     float acc[KF];
     row_dot(rows, p.W2t, c, p.b2[c], acc);
     __syncthreads();
+    if (p.range) {      // non-negative floats order like their bit patterns: one atomicMax per wave and quantity
+        float acc_max = 0.f;
+#pragma unroll
+        for (int s = 0; s < KF; ++s) acc_max = s < K ? fmaxf(acc_max, fabsf(acc[s])) : acc_max;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            pre_max = fmaxf(pre_max, __shfl_xor(pre_max, m, 64));
+            acc_max = fmaxf(acc_max, __shfl_xor(acc_max, m, 64));
+        }
+        if (lane == 0) { atomicMax(p.range, __float_as_uint(pre_max)); atomicMax(p.range + 1, __float_as_uint(acc_max)); }
+    }
 #pragma unroll
     for (int s = 0; s < KF; ++s) {
         acc[s] = silu_exact(acc[s]);
@@ -1046,7 +1060,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
     k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.stamp = a.stamp; k.split = 0;
     k.node0 = a.lig_only ? a.R : 0; k.nodes = a.lig_only ? a.N - a.R : a.N;
-    k.Ah = a.Ah;
+    k.Ah = a.Ah; k.range = a.range;
     return k;
 }
 // the 16-bit MFMA kernels take the -log2(e)-scaled operands (SILU_S, api.hip)

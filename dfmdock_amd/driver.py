@@ -48,10 +48,32 @@ def random_rotation(rec_pos, lig_pos, rng):
     return rotate_complex(rec_pos, lig_pos, Rm)
 
 
+def checked_precision(gx: engine.Complex, precision: str, name: str, selfcheck=True, on_fail="fp32", log=None, seed=0):
+    """Once per complex, before any trajectory: dfm_complex_selfcheck of the 16-bit engine on the complex's own pose (fp32 vs
+    16-bit on the same graphs + fp16 range telemetry), printed as one line.  A failed check - activations outside the fp16 range
+    or deviations beyond SURVEY 8(d)'s gates, i.e. a checkpoint this engine's precision plan does not hold for - switches the
+    complex to the fp32 ENGINE (`on_fail="fp32"`: slower, the reference's own arithmetic, still the HIP path), raises
+    (`"raise"`) or only warns (`"warn"`).  Returns (precision to use, the check's dict or None)."""
+    import sys
+    if not selfcheck or engine.canonical_precision(precision) == "fp32":
+        return precision, None
+    r = gx.selfcheck(precision=precision, seed=seed)
+    line = engine.format_selfcheck(r, name)
+    (log or (lambda m: print(m, file=sys.stderr, flush=True)))(line)
+    if not r["ok"]:
+        if on_fail == "raise":
+            raise RuntimeError(line)
+        if on_fail == "fp32":
+            (log or (lambda m: print(m, file=sys.stderr, flush=True)))(f"selfcheck {name}: running this complex on the fp32 engine")
+            return "fp32", r
+    return precision, r
+
+
 def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0, precision="mfma16", global_rotation=True,
-            out_csv=None, traj_dir=None, max_batch=256, **sampler_kw):
+            out_csv=None, traj_dir=None, max_batch=256, selfcheck=True, on_selfcheck_fail="fp32", checks_out=None, **sampler_kw):
     """Sample `num_samples` trajectories for every complex dict (id, rec_x, lig_x, rec_pos, lig_pos[, rec_seq, lig_seq]);
-    returns the metric rows of this rank's share; rank 0 writes the gathered CSV when `out_csv` is given."""
+    returns the metric rows of this rank's share; rank 0 writes the gathered CSV when `out_csv` is given.  Every complex is
+    self-checked first (checked_precision); `checks_out` (a list) collects {id, precision used, check dict}."""
     rank, _, world = D.dist_env()
     complexes = list(complexes)
     split_trajectories = world > 1 and len(complexes) < 2 * world
@@ -73,11 +95,14 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
             rec_pos, lig_pos = random_rotation(rec_pos, lig_pos, np.random.default_rng(rots[ci]))
         gx = engine.Complex(model, c["rec_x"], c["lig_x"], rec_pos, lig_pos)
         native = NativeContext((rec_pos, lig_pos))
+        use_prec, chk = checked_precision(gx, precision, str(c.get("id", ci)), selfcheck, on_selfcheck_fail, seed=seed)
+        if checks_out is not None:
+            checks_out.append({"id": c.get("id", str(ci)), "precision": use_prec, "selfcheck": chk})
         done = t_lo
         while done < t_hi:
             b = min(max_batch, t_hi - done)
             r = gx.sample(B=b, num_steps=num_steps, seed=seed * 100003 + ci * 1009 + done, trace=traj_dir is not None,
-                          **engine.precision_kwargs(precision), **sampler_kw)
+                          **engine.precision_kwargs(use_prec), **sampler_kw)
             for k in range(b):
                 m = compute_metrics((rec_pos, r["lig_pos"][k]), (rec_pos, lig_pos), native)
                 rows.append({"id": c.get("id", str(ci)), "index": str(done + k), **m, "energy": float(r["energy"][k]),
@@ -111,10 +136,11 @@ def _gather_rows(rows, world):
 
 
 def dock_pair(model: engine.Model, rec, lig, rec_x, lig_x, num_samples=120, num_steps=40, seed=0, precision="mfma16",
-              out_pdb="output.pdb", max_batch=256):
+              out_pdb="output.pdb", max_batch=256, selfcheck=True, on_selfcheck_fail="fp32"):
     """inference() of the reference for two parsed PDB chains (pdbio.backbone_from_atoms dicts) and their
     pre-computed node features; returns {'energy': min energy} and writes the best pose."""
     gx = engine.Complex(model, rec_x, lig_x, rec["bb_coords"], lig["bb_coords"])
+    precision, chk = checked_precision(gx, precision, "pair", selfcheck, on_selfcheck_fail, seed=seed)
     best = None
     done = 0
     while done < num_samples:
@@ -130,4 +156,5 @@ def dock_pair(model: engine.Model, rec, lig, rec_x, lig_x, num_samples=120, num_
     if out_pdb:
         rec_atoms = [a for a in rec["atoms"]]
         pdbio.write_complex_pdb(out_pdb, rec_atoms, lig["atoms"], lig_aa)
-    return {"energy": best[0], "rot_update": best[1], "tr_update": best[2], "lig_aa_coords": lig_aa}
+    return {"energy": best[0], "rot_update": best[1], "tr_update": best[2], "lig_aa_coords": lig_aa, "precision": precision,
+            "selfcheck": chk}

@@ -74,6 +74,17 @@ def diffusion_coef(which: int, t: float, hp: HParams | None = None):
     return g.value, s.value
 
 
+def format_selfcheck(r: dict, name: str = "") -> str:
+    """One line for logs: what a checkpoint owner reads before trusting the 16-bit engine."""
+    worst = {k: max(r[k]) for k in ("max_A", "max_Bm", "max_sum16", "max_pre", "max_acc")}
+    top = max(worst, key=worst.get)
+    return (f"selfcheck {name}: {r['precision']} vs fp32 on {r['n_eval']} graphs: f {r['dev_f']:.2e} tr {r['dev_tr_score']:.2e} "
+            f"rot {r['dev_rot_score']:.2e} E {r['dev_energy']:.2e} (gates {r['gate_f']:.0e} / {r['gate_score']:.0e} / {r['gate_energy']:.0e}; "
+            f"cancellation tr {r['cancel_ratio'][0]:.3f} rot {r['cancel_ratio'][1]:.3f}, pooled-vector bounds {r['score_bound'][0]:.1e} / "
+            f"{r['score_bound'][1]:.1e}) | fp16 range: max|h| {max(r['max_h']):.3g}, largest stored magnitude {worst[top]:.3g} ({top[4:]}), "
+            f"headroom x{r['headroom']:.3g}, saturated {r['saturated']} | {'OK' if r['ok'] else 'FAILED: ' + ('range ' if not r['range_ok'] else '') + ('deviation' if not r['dev_ok'] else '')}")
+
+
 class Model:
     """Device-resident weights (dfm_model).  `blob` is the flat float32 state_dict (weights.pack_blob)."""
 
@@ -231,6 +242,29 @@ class Complex:
                                 int(seed), C.byref(inj) if inj is not None else None, C.byref(out))
         L.check(rc, "dfm_sample")
         return o
+
+    def selfcheck(self, n_eval=4, t=None, seed=0, precision="mfma16", bf16_ops=False):
+        """dfm_complex_selfcheck: the stored pose through the fp32 engine and the 16-bit engine `precision` names on the same
+        n_eval engine-drawn graphs; deviations, cancellation ratios and the fp16 range telemetry as a dict (include/dfmdock_amd.h:
+        dfm_selfcheck_out).  `ok` False = do not trust the 16-bit engine on this model / complex: run precision="fp32"."""
+        kw = precision_kwargs(precision)
+        if not (kw["mfma16"] or kw["f16"]):
+            raise ValueError("selfcheck compares a 16-bit engine with the fp32 engine: precision must be 'mfma16' or 'f16'")
+        flags = (L.DFM_F_F16 if kw["f16"] else L.DFM_F_MFMA16) | (L.DFM_F_BF16_OPS if bf16_ops else 0)
+        tt = None
+        if t is not None:
+            tt = _f32(t).reshape(-1)
+            n_eval = tt.size
+        out = L.SelfcheckC()
+        L.check(L.lib().dfm_complex_selfcheck(self._h, int(n_eval), _p(tt), int(seed), flags, C.byref(out)), "dfm_complex_selfcheck")
+        d = out.depth
+        r = {k: getattr(out, k) for k in ("n_eval", "depth", "dev_f", "dev_tr_score", "dev_rot_score", "dev_energy", "gate_f", "gate_score",
+                                          "gate_energy", "limit", "headroom", "saturated")}
+        r.update(cancel_ratio=list(out.cancel_ratio), score_bound=list(out.score_bound), max_h=list(out.max_h)[: d + 1],
+                 range_ok=bool(out.range_ok), dev_ok=bool(out.dev_ok), ok=bool(out.ok), precision=canonical_precision(precision))
+        for k in ("max_A", "max_Bm", "max_tab", "max_sum16", "max_pre", "max_acc"):
+            r[k] = list(getattr(out, k))[:d]
+        return r
 
     def profile(self):
         p = L.ProfileC()

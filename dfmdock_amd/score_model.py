@@ -163,6 +163,15 @@ class Score_Model:
                 self._homomer = hom
         return self._cx
 
+    def selfcheck(self, batch, n_eval=4, seed=0):
+        """Runtime parity evidence on THIS checkpoint and THIS complex (no reference counterpart - the reference is fp32 throughout):
+        batch's pose through the fp32 engine and through the 16-bit engine this model was built for, on the same engine-drawn graphs.
+        Returns engine.Complex.selfcheck's dict (deviations of f / tr_score / rot_score / energy against SURVEY 8(d)'s gates, the
+        cancellation ratios that condition the scores, per-layer fp16 range telemetry, `ok`).  A model built with precision="fp32" is
+        checked against the default 16-bit engine - what switching it to "mfma16" would cost."""
+        cx = self.complex_for(batch)
+        return cx.selfcheck(n_eval=n_eval, seed=seed, precision=self.precision if self.precision != "fp32" else "mfma16")
+
     _ires_key = "ires"              # score_net_mlsb.py:413-425
 
     def _score_dict(self, batch):

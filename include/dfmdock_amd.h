@@ -152,6 +152,43 @@ typedef struct {
     double slot_cycles[16];   /* diagnostic builds only: summed cycles between consecutive MFMA slots of chunk 3 (wave 0) */
 } dfm_profile;
 
+/* Output of dfm_complex_selfcheck: how far the 16-bit MFMA engine is from the fp32 engine (the reference's own arithmetic) on THIS
+ * model and THIS complex, and how much of the fp16 range the model's activations use.  No reference call has a counterpart: the
+ * reference computes in fp32 throughout; this is the runtime evidence SURVEY 8(d) gate (5) needs for weights the build has never
+ * seen (src/inference_base.py:611-616 loads whatever checkpoint the user has).
+ *
+ * Deviations: L-inf over L-inf of f / tr_score / rot_score, |dE| / max(|E|, 0.1) of the energy, each the WORST over the n_eval
+ * evaluations (same pose, n_eval engine-drawn graphs, n_eval times t); the gates are SURVEY 8(d)'s for 16-bit kernels.
+ * The two scores are unit vectors of the pooled force mean_l f and torque mean_l (r_l x f_l) times a learned scale
+ * (score_net_mlsb.py:396-411), so their deviation is governed by the force deviation over a cancellation ratio:
+ * |d mean f| / |mean f| <= score_bound[0] = sqrt(3) dev_f max|f| / |mean_l f| and the same with r x f for the torque (rigorous for
+ * the pooled vectors; the unit vector and the scale net add a model-dependent factor of order 1).  A small cancel_ratio means an
+ * ill-conditioned pose - the reference's own fp32 scores are then sensitive to rounding as well - not a broken engine.
+ * Range telemetry (from the fp32 pass, per layer l = 0 .. depth-1; the values as the 16-bit engine STORES them, i.e. times
+ * log2(e) where the stored operand carries that factor): everything the 16-bit engine keeps in fp16 must stay below 65504 -
+ * the engine saturates silently otherwise (conversions clamp).  range_ok = every entry below `limit` (6.0e4). */
+typedef struct {
+    int n_eval, depth;
+    float dev_f, dev_tr_score, dev_rot_score, dev_energy;    /* worst over the evaluations                                   */
+    float cancel_ratio[2];                                   /* |mean_l v| / mean_l |v| for v = f and v = r x f (fp32 pass): the
+                                                                smallest over the evaluations                                */
+    float score_bound[2];                                    /* bound of the relative deviation of the pooled force / torque  */
+    float gate_f, gate_score, gate_energy;                   /* 1e-2, 1e-2, 3e-2                               */
+    float limit;                                             /* 6.0e4                                                        */
+    float max_h[9];       /* |h| entering layer l; [depth] = the final node features                                        */
+    float max_A[8];       /* |log2e (Wa h_i + b1)|           stored fp16 (DFM_F_MFMA16) / fp32 (DFM_F_F16)                   */
+    float max_Bm[8];      /* |log2e Wb h_j|                  stored fp16                                                     */
+    float max_tab[8];     /* largest |entry| of the layer's merged lookup tables (log2e-scaled), stored fp16                 */
+    float max_sum16[8];   /* bound of the packed fp16 sum Bm_j + two table rows: max_Bm + the two tables' maxima             */
+    float max_pre[8];     /* |log2e pre-activation of edge_mlp.0|: the producer SiLU's output is stored fp16                 */
+    float max_acc[8];     /* |log2e pre-activation of edge_mlp.2|: bounds the gated messages the last layer stores as fp16   */
+    float headroom;       /* limit / largest of all the above (>= 1 when range_ok)                                          */
+    int64_t saturated;    /* fp16 values found AT the saturation value (+-65504 or inf) in A / Bm of the 16-bit pass itself   */
+    int range_ok;         /* 1: every tracked magnitude below limit and saturated == 0                                       */
+    int dev_ok;           /* 1: dev_f <= gate_f, dev_energy <= gate_energy, each score deviation <= max(gate_score, 2 score_bound[.]) */
+    int ok;               /* range_ok && dev_ok                                                                              */
+} dfm_selfcheck_out;
+
 const char *dfm_last_error(void);
 /* One line describing the precision plan and every diagnostic environment switch / build knob in force in this process
  * (DFM_EDGE_SPLIT; DFM_LIB is the loader's): benches and tests print it, so that a run under
@@ -195,6 +232,12 @@ int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, float tr_noise_
                uint32_t flags, uint64_t seed, const dfm_inject *inj_or_null, dfm_traj_out *out);
 
 int dfm_get_profile(const dfm_complex *cx, dfm_profile *p);
+
+/* Runs the stored pose of the complex (dfm_complex_create / dfm_complex_set_pose) through the fp32 engine and through the 16-bit
+ * engine `flags` selects (DFM_F_MFMA16, the default when neither is given, or DFM_F_F16; DFM_F_BF16_OPS is honoured) on the same
+ * n_eval (1..16) engine-drawn graphs at times t[n_eval] (NULL: spread over [1, 0.001]) and fills `out` (see dfm_selfcheck_out).
+ * Costs one fp32 + one 16-bit batched evaluation of n_eval poses (about 0.1 s at 300+300); the drivers call it once per complex. */
+int dfm_complex_selfcheck(dfm_complex *cx, int n_eval, const float *t_or_null, uint64_t seed, uint32_t flags, dfm_selfcheck_out *out);
 
 /* which: 0 = R^3 (VE), 1 = SO(3) (logarithmic).  Returns DFM_E_INVALID for t outside [0,1] on SO(3). */
 int dfm_diffusion_coef(const dfm_hparams *hp, int which, double t, double *g_out, double *sigma_out);

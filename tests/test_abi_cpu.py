@@ -26,6 +26,28 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTS) == syms
 
 
+def test_ctypes_structs_have_the_c_layout(tmp_path):
+    """Every public struct of include/dfmdock_amd.h as gcc lays it out against the ctypes mirror in dfmdock_amd/_lib.py: a field added
+    on one side only would shift everything behind it silently."""
+    import subprocess
+    from dfmdock_amd import _lib
+    names = {"dfm_hparams": _lib.HParamsC, "dfm_score_out": _lib.ScoreOutC, "dfm_inject": _lib.InjectC, "dfm_traj_out": _lib.TrajOutC,
+             "dfm_profile": _lib.ProfileC, "dfm_selfcheck_out": _lib.SelfcheckC}
+    src = tmp_path / "sz.c"
+    probes = {"dfm_selfcheck_out": ["dev_f", "cancel_ratio", "max_h", "max_acc", "saturated", "ok"], "dfm_hparams": ["cut_off", "r3_min_sigma", "agg_mean"],
+              "dfm_traj_out": ["init_pose"], "dfm_score_out": ["dist_logits"], "dfm_profile": ["slot_cycles"], "dfm_inject": ["edges"]}
+    body = "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names)
+    body += "".join(f'printf("{n}.{f} %zu\\n", offsetof({n}, {f}));' for n, fs in probes.items() for f in fs)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dfmdock_amd.h"\nint main(void){' + body + "return 0;}\n")
+    exe = str(tmp_path / "sz")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    got = dict(line.split() for line in subprocess.check_output([exe], text=True).splitlines())
+    for n, cls in names.items():
+        assert int(got[n]) == C.sizeof(cls), n
+        for f in probes[n]:
+            assert int(got[f"{n}.{f}"]) == getattr(cls, f).offset, (n, f)
+
+
 def test_param_count_and_default_hparams():
     from dfmdock_amd import _lib, engine
     from dfmdock_amd.weights import HParams, n_params
