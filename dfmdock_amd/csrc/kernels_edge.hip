@@ -426,6 +426,332 @@ __device__ inline f2 silu2s(f2 x)
     return x * r;
 }
 
+// =================================================================================================
+// fp32 engine on the matrix pipe: the same algebra as k_edge_f32, the two 256 x 256 contractions on v_mfma_f32_32x32x2_f32 (exact
+// fp32 products and accumulation - the reference's own arithmetic, src/models/egnn.py:95-137 - at 16x the scalar-FMA rate of one
+// lane).  fp32 weights do not fit the LDS (256 KiB), so the kernel is a synchronous tiled GEMM with the edge model fused around it:
+//
+//   workgroup = 4 waves = 2 nodes = four 32-row tiles (60 edges + 4 masked rows per node); 1 workgroup per CU (105 KiB LDS, 512 registers)
+//   K loop in eight 32-channel chunks, double-buffered through LDS: the weight chunk W2t[32 k][256 n] (32 KiB, shared by the four
+//   waves) and the producer's chunk m1 = SiLU(A_i + Bm_j + w_r r^2 + 5 table rows) [32 k][128 rows] (stride 129: conflict-free both
+//   ways); the global loads of chunk c + 1 (weights + gathers, thread = one row x 16 channels) are in flight under chunk c's 128 MFMAs
+//   epilogue in the C layout like the 16-bit kernel: bias, exact SiLU, attention logits by reduce-scatter, gate, 60-row segment sum
+//   (two tiles of a node combined through LDS), agg store
+//   last layer, ligand nodes: the coordinate MLP as a second K loop whose A operand is the gated message tile, transposed chunk by
+//   chunk through the wave's rows of the staging buffer; clamp, normalised differences, mean -> f
+//
+// Summation order differs from k_edge_f32 (MFMA k order, tree reductions) at the 1e-7 level; DFM_EDGE_F32_SCALAR=1 selects the
+// scalar kernel (A/B timing, profiles/r04_fp32_engine.txt).
+constexpr int FM_LD = 129;                       // floats per k-row of the m1 staging ([k][128 rows] + 1)
+constexpr int FM_W_FLOATS = 32 * 256;            // one weight chunk
+constexpr int FM_M_FLOATS = 32 * FM_LD;          // one staging chunk
+constexpr int LDS_F32M_BYTES = (2 * FM_W_FLOATS + 2 * FM_M_FLOATS + 4 * 256 + 16 + 3 * 128) * 4;
+
+// SiLU on the hardware's 1-ulp exp2 / rcp: x / (1 + exp2(-x log2 e)), ~3 ulp; saturates correctly (exp2 -> inf: x * 0; -> 0: x * 1).
+// silu_exact (expf + IEEE division, ~35 instructions) cost the kernel more VALU time than its MFMAs take
+__device__ inline float silu_f32m(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x)); }
+
+__global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Ws = reinterpret_cast<float *>(smem);              // [2][32][256]
+    float *Ms = Ws + 2 * FM_W_FLOATS;                         // [2][32][129]
+    float *s_part = Ms + 2 * FM_M_FLOATS;                     // [4 waves][256] column sums of a tile
+    float *s_cp = s_part + 4 * 256;                           // [4 waves][4] coordinate partials
+    int *s_j = reinterpret_cast<int *>(s_cp + 16);            // [128]
+    uint32_t *s_code = reinterpret_cast<uint32_t *>(s_j + 128);
+    float *s_rad = reinterpret_cast<float *>(s_code + 128);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+    const int K = p.K;
+#ifdef DFM_F32M_STAMP
+    unsigned long long st[6]; int sti = 0;
+#define FSTAMP() { __builtin_amdgcn_sched_barrier(0); st[sti++] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define FSTAMP()
+#endif
+    FSTAMP()
+    const long long ntask = (long long)p.B * p.nodes;
+    const long long task0 = 2ll * blockIdx.x;
+    // node of every 64-row half of the workgroup tile (the second may not exist: odd task count)
+    auto node_of = [&](int half, int &b, int &i) -> bool {
+        const long long t = task0 + half;
+        const bool valid = t < ntask;
+        const long long tt = valid ? t : task0;
+        b = (int)(tt / p.nodes); i = p.node0 + (int)(tt % p.nodes);
+        return valid;
+    };
+    if (tid < 128) {
+        int b, i;
+        const bool valid = node_of(tid >> 6, b, i);
+        const int s = tid & 63;
+        const bool v = valid && s < K;
+        const size_t e = ((size_t)b * p.N + i) * K + (s < K ? s : 0);
+        s_j[tid] = v ? p.edges[e] : i;
+        s_code[tid] = v ? p.codes[e] : 0u;
+        s_rad[tid] = v ? p.radial[e] : 0.f;
+    }
+    __syncthreads();
+    // producer: thread = 4 rows (it * 32 + tid / 8) x 4 channels ((tid & 7) * 4) of every 32-channel chunk: eight lanes cover one row's
+    // 128-byte line of each gathered operand (a lane per row would touch 64 lines per load instruction: the L1 then carries as many
+    // cycles per chunk as the MFMAs).  LDS stores [k][row] with stride 129: bank (4 x + e + y) % 32 over lanes (x = tid & 7, y = tid / 8)
+    // is conflict-free within each 32-lane pass.
+    const int pr8 = tid >> 3, pch = (tid & 7) * 4;
+    uint32_t oA[2], oBm[4], oT[5][4];
+    float prad[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 32 + pr8;
+        int nb, ni;
+        node_of(row >> 6, nb, ni);
+        const uint32_t ab = (uint32_t)((size_t)nb * p.ab_bstride);
+        if ((it & 1) == 0) oA[it >> 1] = ab + (uint32_t)ni * H + pch;
+        oBm[it] = ab + (uint32_t)s_j[row] * H + pch;
+        const uint32_t code = s_code[row];
+        oT[0][it] = (code & 63u) * H + pch; oT[1][it] = (40u + ((code >> 6) & 31u)) * H + pch;
+        oT[2][it] = (64u + ((code >> 11) & 31u)) * H + pch; oT[3][it] = (88u + ((code >> 16) & 15u)) * H + pch;
+        oT[4][it] = (100u + ((code >> 20) & 127u)) * H + pch;
+        prad[it] = s_rad[row];
+    }
+    float pre_max = 0.f, acc_max = 0.f;      // range telemetry (p.range)
+
+    float4 oa[2], ob[4], ot[5][4], ow;      // operands of the m1 chunk in flight (4 rows x 4 channels)
+    // weight chunk c of Wt ([256 k][256 n] fp32) straight from global memory into LDS buffer `buf` (global_load_lds_dwordx4: no
+    // registers in between - 32 of them spilled otherwise; a wave's 64 lanes fill 1 KiB of contiguous LDS per instruction).  The
+    // caller waits for vmcnt(0) before the barrier that publishes the buffer.
+    auto fetch_w1 = [&](const float *Wt, int c, int buf, int q) {      // one of the eight 16-byte-per-lane pieces of a weight chunk
+        const float4 *src = reinterpret_cast<const float4 *>(Wt + (size_t)c * FM_W_FLOATS) + tid;
+        char *dst = reinterpret_cast<char *>(Ws + buf * FM_W_FLOATS) + wave * 1024;
+        __builtin_amdgcn_global_load_lds(src + q * 256, (__attribute__((address_space(3))) void *)(dst + q * 4096), 16, 0, 0);
+    };
+    auto fetch_w = [&](const float *Wt, int c, int buf) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fetch_w1(Wt, c, buf, q);
+    };
+    auto wait_w = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // the 29 operand loads of a chunk, one per call (j = 0 .. 28): w_r, A_i of the two nodes, then per row Bm_j and five table rows
+    auto fetch_op1 = [&](int c, int j) {
+        const int k0 = c * 32;
+        if (j == 0) ow = *reinterpret_cast<const float4 *>(p.w_r + k0 + pch);
+        else if (j <= 2) oa[j - 1] = *reinterpret_cast<const float4 *>(p.A + oA[j - 1] + k0);
+        else {
+            const int it = (j - 3) / 6, q = (j - 3) % 6;
+            if (q == 0) ob[it] = *reinterpret_cast<const float4 *>(p.Bm + oBm[it] + k0);
+            else ot[q - 1][it] = *reinterpret_cast<const float4 *>(p.T + oT[q - 1][it] + k0);
+        }
+    };
+    auto fetch_ops = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < 27; ++j) fetch_op1(c, j);
+    };
+    // edge_mlp.0 + SiLU (egnn.py:95-101) of element e of this thread's row `it`, same association as k_edge_f32; in two slices so that
+    // it can be laid between MFMAs (a slice must stay below the 64 cycles an MFMA occupies the pipe)
+    float pre_e = 0.f;
+    auto build_slice = [&](int buf, int it, int e, int part) {
+        if (part == 0) {
+            const float4 a4 = oa[it >> 1], b4 = ob[it];
+            const float a = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w)), bm = e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w));
+            const float w = e == 0 ? ow.x : (e == 1 ? ow.y : (e == 2 ? ow.z : ow.w));
+            float pre = a + bm;
+            pre += w * prad[it];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) pre += e == 0 ? ot[q][it].x : (e == 1 ? ot[q][it].y : (e == 2 ? ot[q][it].z : ot[q][it].w));
+            pre_e = pre;
+        } else {
+            pre_max = fmaxf(pre_max, fabsf(pre_e));
+            Ms[buf * FM_M_FLOATS + (pch + e) * FM_LD + it * 32 + pr8] = silu_f32m(pre_e);
+        }
+    };
+    auto build_row = [&](int buf, int it) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { build_slice(buf, it, e, 0); build_slice(buf, it, e, 1); }
+    };
+    typedef float f32x16v __attribute__((ext_vector_type(16)));
+    // 128 MFMAs of one chunk.  `slot(m)` runs after MFMA m = kk * 8 + nt (a few instructions each: requests and producer arithmetic of
+    // the NEXT chunk ride in the shadow of this chunk's MFMAs; a wave issues in order, so whatever sits between two MFMAs must stay
+    // below the 64 cycles one of them occupies the pipe).
+    // The nine LDS reads of k-step kk + 1 go out right after the FIRST MFMA of k-step kk: hipcc waits for them with lgkmcnt(0) (it does
+    // not count past LDS-DMA), so a wait placed directly behind a read drains the matrix pipe (~130 cycles of LDS latency); behind
+    // seven more MFMAs the data is long there and the wait is free.  Left to itself the scheduler sinks every read to just before its
+    // use (profiles/r04_fp32_engine.txt).
+    auto mfma_chunk = [&](int buf, f32x16v (&acc)[8], auto slot) {
+        const float *Mb = Ms + buf * FM_M_FLOATS + wave * 32 + l31 + h * FM_LD, *Wb = Ws + buf * FM_W_FLOATS + l31 + h * 256;
+        float a_c = Mb[0], b_c[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) b_c[nt] = Wb[nt * 32];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a_n = 0.f, b_n[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b_c[0], acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < 16) {
+                a_n = Mb[(2 * kk + 2) * FM_LD];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) b_n[nt] = Wb[(2 * kk + 2) * 256 + nt * 32];
+            }
+            slot(kk * 8);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 1; nt < 8; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b_c[nt], acc[nt], 0, 0, 0);
+                slot(kk * 8 + nt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            a_c = a_n;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) b_c[nt] = b_n[nt];
+        }
+    };
+    auto no_slot = [](int) {};
+
+    f32x16v acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    fetch_w(p.W2t, 0, 0); fetch_ops(0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) build_row(0, it);
+    wait_w();
+    __syncthreads();
+    FSTAMP()
+#pragma unroll 1
+    for (int c = 0; c < 7; ++c) {
+        const int nb = (c + 1) & 1;
+        // slots 1 .. 35 (first k-steps): the next chunk's 8 weight pieces and 27 operand loads, one per MFMA; slots 64 .. 127: its 16
+        // elements in two slices each, one slice after every second MFMA
+        mfma_chunk(c & 1, acc, [&](int m) {
+            if (m >= 1 && m <= 8) fetch_w1(p.W2t, c + 1, nb, m - 1);
+            else if (m >= 9 && m <= 35) fetch_op1(c + 1, m - 9);
+            else if (m >= 64 && (m & 1)) { const int j = (m - 64) >> 1; build_slice(nb, j >> 3, (j >> 1) & 3, j & 1); }
+        });
+        wait_w();
+        __syncthreads();
+    }
+    mfma_chunk(1, acc, no_slot);
+    __syncthreads();
+    FSTAMP()
+
+    // ---- epilogue of the wave's 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) = (r & 3) + 8 (r >> 2) + 4 h
+    int wb, wi;
+    const bool wvalid = node_of(wave >> 1, wb, wi);
+    const int mt = wave & 1;
+    const bool do_coord_wg = p.last != 0;
+    if (do_coord_wg) fetch_w(p.Wc1t, 0, 0);      // flies under the epilogue (every wave is past the last chunk's reads: barrier above)
+    float part[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        const float bias = p.b2[nt * 32 + l31], av = p.att_w[nt * 32 + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float x = acc[nt][r] + bias;
+            acc_max = fmaxf(acc_max, fabsf(x));
+            const float m = silu_f32m(x);       // edge_mlp.2 + SiLU
+            acc[nt][r] = m;
+            part[r] = fmaf(m, av, part[r]);
+        }
+    }
+    {   // attention gate (egnn.py:102-104): computed by the lane that ends up with the row's sum, handed back by ds_bpermute
+        const float logit = half_reduce_scatter(part, lane);
+        const int rs_j = rs_index(lane), rs_row = (rs_j & 3) + 8 * (rs_j >> 2) + 4 * h, bp_base = (lane & 32) * 4;
+        const float gate = (wvalid && mt * 32 + rs_row < K) ? sigmoid_exact(logit + p.att_b) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int src = ((r & 8) >> 3) | ((r & 4) >> 1) | ((r & 2) << 1) | ((r & 1) << 3);
+            part[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_base + src * 4, __builtin_bit_cast(int, gate)));
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        float cs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[nt][r] *= part[r]; cs += acc[nt][r]; }      // gated messages; unsorted_segment_sum over the tile's rows
+        cs += __shfl_xor(cs, 32, 64);
+        if (h == 0) s_part[wave * 256 + nt * 32 + l31] = cs;
+    }
+    __syncthreads();
+    if (mt == 0 && wvalid) {
+        float *out = p.agg + ((size_t)wb * p.N + wi) * H;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q * 64 + lane] = s_part[wave * 256 + q * 64 + lane] + s_part[(wave + 1) * 256 + q * 64 + lane];
+    }
+    if (p.range) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            pre_max = fmaxf(pre_max, __shfl_xor(pre_max, m, 64));
+            acc_max = fmaxf(acc_max, __shfl_xor(acc_max, m, 64));
+        }
+        if (lane == 0) { atomicMax(p.range, __float_as_uint(pre_max)); atomicMax(p.range + 1, __float_as_uint(acc_max)); }
+    }
+    FSTAMP()
+#ifdef DFM_F32M_STAMP
+    if (blockIdx.x == gridDim.x / 2 + 7 && tid == 0)
+        printf("f32m stamps (cycles of a 100 MHz clock x ~24): prologue %llu  K loop %llu  epilogue %llu\n", st[1] - st[0], st[2] - st[1], st[3] - st[2]);
+#endif
+    if (!do_coord_wg) return;
+    {   // any ligand node in this workgroup?  (workgroup-uniform: the second K loop has barriers)
+        int b0, i0, b1, i1;
+        node_of(0, b0, i0);
+        const bool v1 = node_of(1, b1, i1);
+        if (!(i0 >= p.R || (v1 && i1 >= p.R))) return;
+    }
+    // ---- coord_model (egnn.py:118-137): second contraction, A operand = the gated message tile, chunk c = the wave's acc[c]
+    f32x16v cacc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cacc[nt][r] = 0.f;
+    auto stage_gated = [&](int buf, const f32x16v &g) {      // [k = l31][row = wave*32 + rowof(r)]: banks (k + row) % 32
+        float *dst = Ms + buf * FM_M_FLOATS + l31 * FM_LD + wave * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(r & 3) + 8 * (r >> 2)] = g[r];
+    };
+    stage_gated(0, acc[0]);
+    wait_w();
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (c + 1 < 8) { fetch_w(p.Wc1t, c + 1, (c + 1) & 1); stage_gated((c + 1) & 1, acc[(c + 1) & 7]); }
+        mfma_chunk(c & 1, cacc, no_slot);
+        wait_w();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        const float bias = p.bc1[nt * 32 + l31], w2 = p.wc2[nt * 32 + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] = fmaf(silu_f32m(cacc[nt][r] + bias), w2, part[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[r] = half_sum_dpp(part[r]);      // every lane of the half holds the row's sum
+    float w = part[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) w = l31 == r ? part[r] : w;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    const int lrow = mt * 32 + (l31 & 3) + 8 * ((l31 >> 2) & 3) + 4 * h;      // one lane per row: lanes l31 < 16 take register row l31
+    const float4 *ca = p.ca4 + (size_t)wb * p.N;
+    const float4 xi = ca[wi];
+    if (l31 < 16 && lrow < K) {
+        const float4 xj = ca[s_j[(wave >> 1) * 64 + lrow]];
+        w = fminf(fmaxf(w, -2.0f), 2.0f);                                       // clamp_(-2, 2)
+        const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+        const float nrm = sqrtf((dx * dx + dy * dy) + dz * dz + 1e-8f) + 1.0f;   // coord2radial, normalize=True
+        c0 = dx / nrm * w; c1 = dy / nrm * w; c2 = dz / nrm * w;
+    }
+    c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+    if (lane == 0) { s_cp[wave * 4 + 0] = c0; s_cp[wave * 4 + 1] = c1; s_cp[wave * 4 + 2] = c2; }
+    __syncthreads();
+    if (mt == 0 && wvalid && wi >= p.R && lane < 3) {
+        const float a = (s_cp[wave * 4 + lane] + s_cp[(wave + 1) * 4 + lane]) / (float)(K > 1 ? K : 1);      // unsorted_segment_mean
+        const float xd = lane == 0 ? xi.x : (lane == 1 ? xi.y : xi.z);
+        p.fout[((size_t)wb * p.L + (wi - p.R)) * 3 + lane] = (xd + a) - xd;      // f = pos_out - r
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // Message kernel (edge_mlp + attention gate + segment sum; on the last layer also the store of the gated messages of the ligand
 // nodes in the A-fragment order k_edge_coord reads).  Software-pipelined ACROSS tiles: with a per-tile prologue (wait for the edge
@@ -1076,6 +1402,16 @@ static EdgeKArgs to_kargs_mfma(const EdgeArgs &a, int mode)
 
 hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s)
 {
+    static const bool scalar = [] { const char *e = getenv("DFM_EDGE_F32_SCALAR"); return e && atoi(e) != 0; }();      // diagnostics: the r01-r03 kernel
+    if (!scalar) {
+        static std::atomic<bool> attr_m[MAX_DEVICES];
+        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_f32m), LDS_F32M_BYTES, attr_m);
+        if (e != hipSuccess) return e;
+        const EdgeKArgs k = to_kargs(a);
+        const long long tasks = (long long)a.B * k.nodes;
+        hipLaunchKernelGGL(k_edge_f32m, dim3((unsigned)((tasks + 1) / 2)), dim3(256), LDS_F32M_BYTES, s, k);
+        return hipGetLastError();
+    }
     static std::atomic<bool> attr_done[MAX_DEVICES];
     const int lds = KF * H * 4 + 4 * 64 * 4;
     {

@@ -1,12 +1,15 @@
 #!/bin/bash
-# Counter passes for one kernel family at the bench configuration: KREGEX='k_gemm_split' bash tools/pmc_kernel.sh
-# Separate --pmc passes (no trace domains), each under its own timeout.  TA_* counters are avoided (they wedged rocprofv3 here).
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-KREGEX=${KREGEX:-k_gemm_split}
-OUT=gpurun_out/pmc_${TAG:-kernel}; rm -rf $OUT; mkdir -p $OUT
-CMD="python bench.py --steps 1 --warmup 0 --batch 256 --num-steps 2 --no-cpu-baseline"
-for c in "GRBM_GUI_ACTIVE SQ_WAVES" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_WAIT_ANY SQ_INST_CYCLES_VMEM"; do
-  n=$(echo $c | tr ' ' '_')
-  timeout 200 rocprofv3 --pmc $c --kernel-include-regex "$KREGEX" --output-format csv -d $OUT -o $n -- $CMD > $OUT/$n.log 2>&1 || echo "pass $c failed/timeout"
+# PMC passes for one kernel of a bench.py run (one --pmc set per run, kernel-filtered, no trace domains):
+#   bash tools/pmc_kernel.sh <out dir under gpurun_out> <kernel regex> <bench.py args...>      -> <out dir>.txt (tools/pmc_summary.py)
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+dir=gpurun_out/$1; kr=$2; shift 2
+mkdir -p $dir
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
+         "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
+         "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE" \
+         "SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS SQ_INST_CYCLES_VMEM"; do
+  n=$(echo $c | cut -d' ' -f1-2 | tr ' ' '_')
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-include-regex "$kr" --output-format csv -d $GRAFT_REPO_ROOT/$dir -o $n -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $GRAFT_REPO_ROOT/$dir/$n.log 2>&1 ) || echo "pass $c failed/timeout"
 done
-python tools/pmc_summary.py $OUT
+python tools/pmc_summary.py $dir > $dir.txt 2>&1
+cat $dir.txt
