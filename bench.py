@@ -161,6 +161,7 @@ def main():
                     help="mfma16: the 16-bit MFMA engine as shipped (DFM_F_MFMA16: fp16 operands, fp32 accumulation; dfm_config_string() "
                          "in the JSON line says what that is); f16: the same with fp32 A_i; fp32: exact; bf16: deprecated alias of mfma16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-l0-table", action="store_true", help="A/B: layer 0 evaluated edge by edge (DFM_F_NO_L0_TABLE)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -197,7 +198,7 @@ def main():
     B = args.batch
 
     def one_step(it, profile=False):
-        r = gx.sample(B=B, num_steps=args.num_steps, seed=1000 * (rank + 1) + it, profile=profile, **pk)
+        r = gx.sample(B=B, num_steps=args.num_steps, seed=1000 * (rank + 1) + it, profile=profile, l0_table=not args.no_l0_table, **pk)
         rec = D.make_records(rank, np.arange(rank * B, (rank + 1) * B), r)      # record id = the rank that sampled it
         allrec = D.gather_records(rec)            # the only collective: ranked energies (RCCL all_gather)
         return r, allrec
@@ -211,6 +212,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     edge_ms, edge_launches, edge_rows = 0.0, 0, 0
+    l0 = dict(l0_evals=0, l0_edges=0, l0_miss_rows=0, l0_rows_ms=0.0, l0_gather_ms=0.0)
     allrec = None
     for it in range(args.steps):
         _, allrec = one_step(args.warmup + it, profile=True)
@@ -218,6 +220,8 @@ def main():
         edge_ms += p["edge_kernel_ms"]
         edge_launches += p["edge_kernel_launches"]
         edge_rows += p["edge_rows"]
+        for k in l0:
+            l0[k] += p[k]
     barrier()
     elapsed = time.perf_counter() - t0
     per_rank = D.allgather_scalars([elapsed, float(dev)])      # max over ranks of the time; which device every rank ran on
@@ -259,7 +263,11 @@ def main():
                        "work": "41 score evaluations per trajectory through dfm_sample: the 40 step evaluations return f and the two scores "
                                "(all the sampler reads, inference_base.py:425-448), so their last layer runs over the ligand nodes only and "
                                "without its node model - bitwise the same f / scores as the full evaluation (tests/test_gpu_variants.py); "
-                               "the final evaluation runs in full with the energy head",
+                               "the final evaluation runs in full with the energy head"
+                               + ("; layer 0 through the per-complex message table: the gated message of an intra-chain edge is a "
+                                  "function of the residue pair alone there (pose-independent embedding, rigid chains), so it is gathered "
+                                  "from a table built once per complex; inter-chain edges and bin mismatches go through the edge model "
+                                  "(tests/test_gpu_l0_table.py)" if l0["l0_evals"] else ""),
                        "precision": (("16-bit MFMA engine" + (" with fp32 A_i (DFM_F_F16)" if f16 else "") + ": ") if mfma16 else "fp32 engine; library plan: ")
                                     + engine.config_string(),
                        "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DFM_") and k not in
@@ -279,6 +287,14 @@ def main():
                                  "run, see traffic_source; algorithmic bytes per launch = 8*N*H per trajectory (SURVEY 8d)"},
             "best_energy": float(allrec[:, 2].min()),
         }
+        if l0["l0_evals"]:      # layer 0 behind the message table: its launches are not part of `roofline` (HIP events, live)
+            n = l0["l0_evals"]
+            out["layer0_table"] = {"evaluations": int(n), "edge_model_fraction": l0["l0_miss_rows"] / max(l0["l0_edges"], 1),
+                                   "rows_launch_ms": l0["l0_rows_ms"] / n, "gather_launch_ms": l0["l0_gather_ms"] / n,
+                                   "gather_bytes_per_launch": 512 * l0["l0_edges"] / n,
+                                   "gather_tbps": 512 * l0["l0_edges"] / max(l0["l0_gather_ms"], 1e-9) / 1e9,
+                                   "note": "per evaluation: k_edge_msg<1,1,1> over the row list (inter-chain edges + bin mismatches) and "
+                                           "k_l0_gather (K rows of 512 B per node, out of L2 / the Infinity Cache) replace one full message launch"}
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(blob, cx, args.num_steps)
         print(json.dumps(out), flush=True)

@@ -27,6 +27,8 @@ DFM_F_F16 = 1 << 7
 DFM_F_IRES = 1 << 8
 DFM_F_BF16_OPS = 1 << 9
 DFM_F_DIST = 1 << 10
+DFM_F_L0_TABLE = 1 << 11       # dfm_score: layer 0 through the per-complex message table
+DFM_F_NO_L0_TABLE = 1 << 12    # dfm_sample: layer 0 evaluated directly
 
 EXPORTS = [
     "dfm_last_error", "dfm_config_string", "dfm_device_count", "dfm_set_device", "dfm_default_hparams", "dfm_param_count",
@@ -62,7 +64,9 @@ class TrajOutC(C.Structure):
 
 class ProfileC(C.Structure):
     _fields_ = [("edge_kernel_ms", C.c_double), ("edge_kernel_launches", C.c_int64), ("edge_rows", C.c_int64),
-                ("total_ms", C.c_double), ("phase_cycles", C.c_double * 4), ("slot_cycles", C.c_double * 16)]
+                ("total_ms", C.c_double), ("phase_cycles", C.c_double * 4), ("slot_cycles", C.c_double * 16),
+                ("l0_evals", C.c_int64), ("l0_edges", C.c_int64), ("l0_miss_rows", C.c_int64),
+                ("l0_rows_ms", C.c_double), ("l0_gather_ms", C.c_double), ("l0_build_ms", C.c_double)]
 
 
 class SelfcheckC(C.Structure):

@@ -97,6 +97,10 @@ struct Workspace {
     float *fpart = nullptr, *cpart = nullptr, *conf = nullptr;    // family 1: force partials per receptor tile, confidence
     float *scores = nullptr, *lig_cur = nullptr, *tr_update = nullptr, *rot_update = nullptr, *t_dev = nullptr;
     float *ir1 = nullptr, *ir2 = nullptr, *ir3 = nullptr;      // to_ires scratch, allocated on the first DFM_F_IRES call
+    // layer 0 behind the message table (allocated on first use): per edge the source of its gated message, the row list of the
+    // edges the edge model still evaluates, their messages, the list's length and the running total for the profile
+    uint32_t *l0_src = nullptr; uint4 *l0_rows = nullptr; uint16_t *l0_x = nullptr; uint32_t *l0_counter = nullptr;
+    unsigned long long *l0_miss_total = nullptr;
 };
 
 struct dfm_complex {
@@ -117,6 +121,13 @@ struct dfm_complex {
     dfm_profile prof = {};
     unsigned long long *stamp_dev = nullptr;   // [8 waves][4 phases] (diagnostic builds)
     uint32_t fwd_counter = 0;
+    // layer-0 message table of the 16-bit engine (kernels_edge.hip: k_l0_gather): gated messages of every intra-chain ordered pair
+    // [R*R + L*L][256] fp16 and the feature code each entry was built with; rebuilt after set_pose / set_homomer
+    DevPool l0_pool;
+    uint16_t *l0_table = nullptr; uint32_t *l0_code0 = nullptr;
+    bool l0_valid = false;
+    std::vector<hipEvent_t> ev_l0;   // profiling events of the table path (triples: before rows | between | after gather)
+    size_t ev_l0_used = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -548,6 +559,7 @@ extern "C" void dfm_complex_destroy(dfm_complex *cx)
     DeviceScope ds(cx->device);
     if (cx->stream) { (void)hipStreamSynchronize(cx->stream); (void)hipStreamDestroy(cx->stream); }
     for (hipEvent_t e : cx->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : cx->ev_l0) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (cx->ev_total[i]) (void)hipEventDestroy(cx->ev_total[i]);
     delete cx;
 }
@@ -560,6 +572,7 @@ extern "C" int dfm_complex_set_pose(dfm_complex *cx, const float *rec_pos, const
     HIPCHK(hipStreamSynchronize(cx->stream));
     if (rec_pos) HIPCHK(hipMemcpy(cx->rec_pos, rec_pos, (size_t)cx->R * 9 * sizeof(float), hipMemcpyHostToDevice));
     if (lig_pos) HIPCHK(hipMemcpy(cx->lig0, lig_pos, (size_t)cx->L * 9 * sizeof(float), hipMemcpyHostToDevice));
+    cx->l0_valid = false;      // the intra-chain geometry may have changed: the layer-0 message table is rebuilt on next use
     return DFM_OK;
 }
 
@@ -575,6 +588,7 @@ extern "C" int dfm_complex_set_homomer(dfm_complex *cx, int flag)
     // usable and a retry with the same flag does the work again instead of returning DFM_OK on stale operands
     const int old = cx->homomer;
     cx->homomer = flag;
+    cx->l0_valid = false;      // A0 carries the flag's bias: the layer-0 message table is rebuilt on next use
     hipError_t e = project_layer0(cx);
     if (e == hipSuccess) e = hipStreamSynchronize(cx->stream);
     if (e != hipSuccess) {
@@ -589,7 +603,19 @@ extern "C" int dfm_complex_set_homomer(dfm_complex *cx, int flag)
 extern "C" int dfm_complex_degree(const dfm_complex *cx) { return cx ? cx->K : -1; }
 
 // ------------------------------------------------------------------------------------------------
-static int ensure_workspace(dfm_complex *cx, int B, bool bf16)
+// Layer 0 behind the message table: budgets.  The table costs 516 B per intra-chain ordered pair (8 M pairs = 4.1 GB: 2000 + 2000
+// residues), the per-batch buffers 532 B per edge of a batched evaluation (32 M edges = 17 GB: B = 890 at 300+300) - sized for
+// 288 GB of HBM.  Beyond either budget layer 0 is evaluated directly (DFM_L0_TABLE=0 in the environment: always).
+constexpr long long L0_MAX_PAIRS = 8ll << 20, L0_MAX_EDGES = 32ll << 20;
+static bool l0_eligible(const dfm_complex *cx, int B)
+{
+    static const bool env_off = [] { const char *e = getenv("DFM_L0_TABLE"); return e && atoi(e) == 0; }();
+    if (env_off || cx->m->hp.depth < 2) return false;      // (a depth-1 model's first layer is its last: it stores messages for the coordinate MLP)
+    const long long pairs = (long long)cx->R * cx->R + (long long)cx->L * cx->L;
+    return pairs <= L0_MAX_PAIRS && (long long)B * cx->N * cx->K <= L0_MAX_EDGES;
+}
+
+static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
 {
     Workspace &W = cx->ws;
     // the 16-bit message kernel addresses edges / codes / radial through buffer descriptors rooted at the whole [B][N][K] arrays with
@@ -598,7 +624,7 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16)
         return fail(DFM_E_INVALID, "B * N * K * 4 must stay below 2^31: split the batch");
     const bool wants_mbuf = bf16 && cx->m->hp.family == 0;    // gated messages for the coordinate MLP (family 0 only)
     const bool need_mbuf = wants_mbuf && !W.mbuf;
-    if (B <= W.Bcap && !need_mbuf) return DFM_OK;
+    if (B <= W.Bcap && !need_mbuf && !(l0 && !W.l0_src)) return DFM_OK;
     if (B > W.Bcap) {
         HIPCHK(hipStreamSynchronize(cx->stream));
         W.pool.release();
@@ -625,6 +651,52 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16)
         W.Bcap = B;
     }
     if (wants_mbuf && !W.mbuf) HIPCHK(W.pool.alloc(&W.mbuf, (size_t)W.Bcap * cx->L * KPAD * H));
+    if (l0 && !W.l0_src) {
+        const size_t cap = (size_t)W.Bcap * cx->N * cx->K;      // every edge of a batched evaluation may miss the table
+        HIPCHK(W.pool.alloc(&W.l0_src, cap)); HIPCHK(W.pool.alloc(&W.l0_rows, cap));
+        HIPCHK(W.pool.alloc(&W.l0_x, (cap + 32) * H));          // the last tile of the row list stores all of its 32 rows
+        HIPCHK(W.pool.alloc(&W.l0_counter, 1)); HIPCHK(W.pool.alloc(&W.l0_miss_total, 1));
+        HIPCHK(hipMemsetAsync(W.l0_counter, 0, sizeof(uint32_t), cx->stream));
+        HIPCHK(hipMemsetAsync(W.l0_miss_total, 0, sizeof(unsigned long long), cx->stream));
+    }
+    return DFM_OK;
+}
+
+// operands of layer 0's message kernel in the shipped 16-bit plan: the complex's own, pose-independent A0 / Bm0 (no batch stride)
+static EdgeArgs layer0_edge_args(const dfm_complex *cx)
+{
+    EdgeArgs e;
+    std::memset(&e, 0, sizeof(e));
+    e.A = cx->A0s; e.Bm = cx->Bm0; e.Bmb = cx->Bmb0; e.Ah = cx->A0h; e.ab_bstride = 0;
+    e.B = 1; e.N = cx->N; e.R = cx->R; e.K = cx->K; e.lw = &cx->m->layers[0]; e.f16 = 1;
+    return e;
+}
+
+// Builds the layer-0 message table of the complex: every intra-chain ordered pair (i, j) through the edge model once, features from
+// the stored pose (any rigid placement of the ligand gives the same intra-chain geometry; k_edge_feat checks the bins per pose).
+// Uses trajectory slot 0 of the workspace (ensure_workspace first) and overwrites ws.lig_cur's first pose.  Synchronises.
+static int build_l0_table(dfm_complex *cx, float *build_ms)
+{
+    Workspace &W = cx->ws;
+    hipStream_t s = cx->stream;
+    const size_t R = cx->R, L = cx->L, P = R * R + L * L;
+    cx->l0_valid = false;
+    HIPCHK(hipStreamSynchronize(s));
+    cx->l0_pool.release();
+    HIPCHK(cx->l0_pool.alloc(&cx->l0_table, ((P + 31) / 32 * 32) * H));
+    HIPCHK(cx->l0_pool.alloc(&cx->l0_code0, P));
+    DevPool tmp;
+    uint4 *rows = nullptr;
+    HIPCHK(tmp.alloc(&rows, P));
+    HIPCHK(hipEventRecord(cx->ev_total[0], s));
+    HIPCHK(hipMemcpyAsync(W.lig_cur, cx->lig0, L * 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(launch_prep_pose(cx->rec_pos, W.lig_cur, 1, cx->R, cx->L, cx->m->hp.family == 1 ? 1 : 0, W.pos, W.ca4, W.cb4, s));
+    HIPCHK(launch_l0_pairs(W.pos, W.ca4, W.cb4, cx->R, cx->L, cx->m->hp.mask_dist, cx->l0_code0, rows, s));
+    HIPCHK(launch_edge_rows(layer0_edge_args(cx), rows, nullptr, (uint32_t)P, cx->l0_table, s));
+    HIPCHK(hipEventRecord(cx->ev_total[1], s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (build_ms) HIPCHK(hipEventElapsedTime(build_ms, cx->ev_total[0], cx->ev_total[1]));
+    cx->l0_valid = true;
     return DFM_OK;
 }
 
@@ -668,6 +740,7 @@ extern "C" const char *dfm_config_string(void)
 struct FwdOpts {
     bool bf16 = false, f16 = false, want_energy = false, profile = false;   // bf16: 16-bit MFMA engine; f16: ... with fp32 A_i
     bool bf16_ops = false;                // bf16 MFMA operands in every layer but the last (DFM_F_BF16_OPS)
+    bool l0_table = false;                // layer 0 through the complex's message table (cx->l0_valid, workspace l0 buffers allocated)
     bool need_node_out = true;            // false: nobody reads the final node features (no energy / ires / debug tap) - the last layer then
                                           // computes the messages of the ligand nodes only (all the coordinate update reads) and no node model
     const int32_t *edges_dev = nullptr;   // [B][N][K] already on device (or nullptr = sample natively)
@@ -728,7 +801,10 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
     } else {
         HIPCHK(launch_knn_sample(W.ca4, B, N, cx->knn, cx->nsamp, o.seed, stream_id, W.edges, s));
     }
-    HIPCHK(launch_edge_feat(W.pos, W.ca4, W.cb4, W.edges, B, N, R, K, m->hp.mask_dist, W.codes, W.radial, s));
+    L0Classify cls;
+    std::memset(&cls, 0, sizeof(cls));
+    if (o.l0_table) { cls.code0 = cx->l0_code0; cls.src = W.l0_src; cls.rows = W.l0_rows; cls.counter = W.l0_counter; }
+    HIPCHK(launch_edge_feat(W.pos, W.ca4, W.cb4, W.edges, B, N, R, K, m->hp.mask_dist, W.codes, W.radial, cls, s));
     // layer 0 reads the node embedding h0 [N][256] of the complex itself - identical for every trajectory - through a row period
     // (GemmArgs::a0_period / r_period) instead of a [B][N][256] copy made per evaluation (r01-r03: k_bcast_rows, 157 MB of writes at C3)
     const float *h = cx->h0;
@@ -792,8 +868,26 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         {
             // (Running the last layer in trajectory chunks so that the stored messages stay in the Infinity Cache was measured and
             // dropped: 15 extra launch pairs per evaluation cost more - weight refills, partial rounds - than the round trip.)
-            int rc2 = message_launch(e);
-            if (rc2) return rc2;
+            if (l == 0 && o.l0_table) {
+                // layer 0 behind the message table: the edge model over the row list k_edge_feat left (inter-chain edges + bin
+                // mismatches), then the K-row gather-sum in slot order from the table and that list's messages
+                hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
+                if (o.profile) {
+                    while (cx->ev_l0_used + 3 > cx->ev_l0.size()) { hipEvent_t a; HIPCHK(hipEventCreate(&a)); cx->ev_l0.push_back(a); }
+                    t0 = cx->ev_l0[cx->ev_l0_used++]; t1 = cx->ev_l0[cx->ev_l0_used++]; t2 = cx->ev_l0[cx->ev_l0_used++];
+                    HIPCHK(hipEventRecord(t0, s));
+                }
+                HIPCHK(launch_edge_rows(e, W.l0_rows, W.l0_counter, (uint32_t)((size_t)B * N * K), W.l0_x, s));
+                if (o.profile) HIPCHK(hipEventRecord(t1, s));
+                HIPCHK(launch_l0_gather(cx->l0_table, W.l0_x, W.l0_src, W.agg, B, N, K, W.l0_counter, W.l0_miss_total, s));
+                if (o.profile) {
+                    HIPCHK(hipEventRecord(t2, s));
+                    cx->prof.l0_evals += 1; cx->prof.l0_edges += (int64_t)B * N * K;
+                }
+            } else {
+                int rc2 = message_launch(e);
+                if (rc2) return rc2;
+            }
             if (coord && o.bf16) HIPCHK(launch_coord_bf16(e, s));
         }
         if (lig_only) break;      // the node model of the last layer feeds heads nobody asked for
@@ -899,6 +993,17 @@ static int finish_profile(dfm_complex *cx)
         HIPCHK(hipEventElapsedTime(&ms, cx->ev[i], cx->ev[i + 1]));
         cx->prof.edge_kernel_ms += ms;
     }
+    for (size_t i = 0; i + 2 < cx->ev_l0_used; i += 3) {
+        HIPCHK(hipEventElapsedTime(&ms, cx->ev_l0[i], cx->ev_l0[i + 1]));
+        cx->prof.l0_rows_ms += ms;
+        HIPCHK(hipEventElapsedTime(&ms, cx->ev_l0[i + 1], cx->ev_l0[i + 2]));
+        cx->prof.l0_gather_ms += ms;
+    }
+    if (cx->prof.l0_evals > 0 && cx->ws.l0_miss_total) {
+        unsigned long long tot = 0;
+        HIPCHK(hipMemcpy(&tot, cx->ws.l0_miss_total, sizeof(tot), hipMemcpyDeviceToHost));
+        cx->prof.l0_miss_rows = (int64_t)tot;
+    }
 #ifdef DFM_EDGE_STAMP
     if (cx->stamp_dev) {
         unsigned long long st[48];
@@ -933,14 +1038,26 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     const bool want_dist = (flags & DFM_F_DIST) && out->dist_logits;
     if (want_dist && cx->m->hp.family != 1) return fail(DFM_E_INVALID, "DFM_F_DIST needs a family-1 model (EGNN_Net has to_dist, Score_Net does not)");
     DEVICE_SCOPE(cx->device);
-    int rc = ensure_workspace(cx, B, bf16);
+    // layer 0 through the message table: on request only (dfm_score stays a pure function of its arguments and flags)
+    const bool l0 = (flags & DFM_F_L0_TABLE) != 0;
+    if (l0 && !(bf16 && !f16 && !(flags & DFM_F_BF16_OPS) && l0_eligible(cx, B)))
+        return fail(DFM_E_INVALID, "DFM_F_L0_TABLE needs the DFM_F_MFMA16 engine (no DFM_F_F16 / DFM_F_BF16_OPS), depth >= 2 and a complex / batch within the table budgets");
+    int rc = ensure_workspace(cx, B, bf16, l0);
     if (rc) return rc;
     Workspace &W = cx->ws;
     hipStream_t s = cx->stream;
     const size_t N = cx->N, L = cx->L, K = cx->K;
     cx->prof = dfm_profile{};
-    cx->ev_used = 0;
+    cx->ev_used = 0; cx->ev_l0_used = 0;
     cx->fwd_counter = 0;   // RNG streams are a pure function of (seed, trajectory, evaluation index)
+    if (l0) {
+        if (!cx->l0_valid) {
+            float bms = 0.f;
+            if ((rc = build_l0_table(cx, &bms)) != DFM_OK) return rc;
+            cx->prof.l0_build_ms = bms;
+        }
+        HIPCHK(hipMemsetAsync(W.l0_miss_total, 0, sizeof(unsigned long long), s));
+    }
     HIPCHK(hipMemcpyAsync(W.lig_cur, lig_pos, (size_t)B * L * 9 * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(W.t_dev, t, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
     DevPool tmp;   // per-call device buffers (injected edges, debug tap); released on every return path
@@ -960,7 +1077,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     float *ir1 = W.ir1, *ir2 = W.ir2, *ir3 = W.ir3;
     FwdOpts o;
     o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.want_energy = want_energy; o.profile = flags & DFM_F_PROFILE; o.edges_dev = edges_dev;
-    o.edges_pitch = (int64_t)N * K; o.seed = seed; o.h_first_out = h_first_dev;
+    o.edges_pitch = (int64_t)N * K; o.seed = seed; o.h_first_out = h_first_dev; o.l0_table = l0;
     // (h_first: a depth-1 model's first layer is its last - the tap needs that layer's node model too)
     o.need_node_out = want_energy || want_ires || want_dist || out->h_last != nullptr || out->h_first != nullptr;
     HIPCHK(hipEventRecord(cx->ev_total[0], s));
@@ -1038,15 +1155,26 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     if (B < 1 || num_steps < 2) return fail(DFM_E_INVALID, "need B >= 1 and num_steps >= 2");
     const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_MFMA16) || f16;
     DEVICE_SCOPE(cx->device);
-    int rc = ensure_workspace(cx, B, bf16);
+    // layer 0 through the complex's message table whenever the shipped 16-bit plan runs and the complex is eligible - a property of
+    // the complex, not of the batch (below the edge budget), so a trajectory's result does not depend on the batch it is sampled in
+    const bool l0 = bf16 && !f16 && !(flags & (DFM_F_BF16_OPS | DFM_F_NO_L0_TABLE)) && l0_eligible(cx, B);
+    int rc = ensure_workspace(cx, B, bf16, l0);
     if (rc) return rc;
     Workspace &W = cx->ws;
     hipStream_t s = cx->stream;
     const dfm_hparams &hp = cx->m->hp;
     const size_t N = cx->N, L = cx->L, K = cx->K, S = num_steps;
     cx->prof = dfm_profile{};
-    cx->ev_used = 0;
+    cx->ev_used = 0; cx->ev_l0_used = 0;
     cx->fwd_counter = 0;   // evaluation i of this call draws its graph from Philox stream i
+    if (l0) {
+        if (!cx->l0_valid) {
+            float bms = 0.f;
+            if ((rc = build_l0_table(cx, &bms)) != DFM_OK) return rc;
+            cx->prof.l0_build_ms = bms;
+        }
+        HIPCHK(hipMemsetAsync(W.l0_miss_total, 0, sizeof(unsigned long long), s));
+    }
 
     // time grid: torch.linspace(1, eps, num_steps) in float32; dt = t[0] - t[1]   (inference_base.py:404-405)
     std::vector<float> ts(S);
@@ -1086,6 +1214,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     }
     FwdOpts o;
     o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.profile = flags & DFM_F_PROFILE; o.seed = seed; o.edges_pitch = (int64_t)(S + 1) * N * K;
+    o.l0_table = l0;
     const bool step_energy = (flags & DFM_F_STEP_ENERGY) != 0;
     for (int i = 0; i < num_steps; ++i) {
         const bool is_last = (i == num_steps - 1);
@@ -1166,7 +1295,7 @@ extern "C" int dfm_complex_selfcheck(dfm_complex *cx, int n_eval, const float *t
         if (!(t[b] >= 0.f && t[b] <= 1.f)) return fail(DFM_E_INVALID, "Invalid t (need 0 <= t <= 1)");
     }
     cx->prof = dfm_profile{};
-    cx->ev_used = 0;
+    cx->ev_used = 0; cx->ev_l0_used = 0;
     cx->fwd_counter = 0;
     DevPool tmp;
     uint32_t *range_d = nullptr;

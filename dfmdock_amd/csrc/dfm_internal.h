@@ -172,8 +172,18 @@ hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, i
                             float4 *ca4, float4 *cb4, hipStream_t s);
 hipError_t launch_knn_sample(const float4 *ca4, int B, int N, int knn, int nsamp, uint64_t seed, uint32_t stream_id,
                              int32_t *edges, hipStream_t s);
+// layer 0 behind the per-complex message table (kernels_edge.hip: k_l0_gather): k_edge_feat's classification of every edge into
+// table hits (src = pair index) and row-list entries (src = 0x80000000 | position).  code0 == nullptr: no classification.
+struct L0Classify {
+    const uint32_t *code0;   // [pairs] feature code each table entry was built with
+    uint32_t *src;           // [B][N][K]
+    uint4 *rows;             // [capacity] (i, j, code, radial bits) of the misses
+    uint32_t *counter;       // rows appended so far (zero at the start of an evaluation: k_l0_gather resets it)
+};
 hipError_t launch_edge_feat(const float *pos, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B,
-                            int N, int R, int K, float mask_dist, uint32_t *codes, float *radial, hipStream_t s);
+                            int N, int R, int K, float mask_dist, uint32_t *codes, float *radial, const L0Classify &cls, hipStream_t s);
+hipError_t launch_l0_pairs(const float *pos, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint32_t *code0,
+                           uint4 *rows, hipStream_t s);
 
 struct EdgeArgs {
     const float *A;        // [Ab][N][256]  Wa h_i + b1   (Ab = 1 when a_bstride == 0)
@@ -201,6 +211,10 @@ hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s);
 bool edge_msg_tile_tasks(int B, int N, int K);   // does launch_edge_bf16 run tile tasks (atomic adds into a zero agg) for this size?
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s);
+// row-list form of the message kernel and the slot-order gather-sum of layer 0 behind the message table (kernels_edge.hip)
+hipError_t launch_edge_rows(const EdgeArgs &a, const uint4 *rows, const uint32_t *n_rows_dev, uint32_t n_rows_cap, uint16_t *out, hipStream_t s);
+hipError_t launch_l0_gather(const uint16_t *table, const uint16_t *X, const uint32_t *src, float *agg, int B, int N, int K,
+                            uint32_t *counter, unsigned long long *miss_total, hipStream_t s);
 
 // fold_w / fold_b non-null: write the folded affine (den := w/den, shift := b - w*shift/den) for launch_gemm_split
 // GraphNorm statistics from the per-tile column statistics the node_mlp.0 GEMM left in stat_part (no second pass over u)

@@ -57,6 +57,12 @@ struct EdgeKArgs {
     int node0, nodes;            // message kernels: the tasks cover nodes node0 .. node0 + nodes - 1 of every trajectory (all of them, or - last
                                  // layer when nobody reads the node outputs - the ligand nodes only: EdgeArgs::lig_only)
     uint32_t *range;             // k_edge_f32, dfm_complex_selfcheck only: [0] max |pre-activation of edge_mlp.0|, [1] of edge_mlp.2, as float bits
+    // k_edge_msg<1, 1, 1> (row-list form, layer 0 only: A / Bm are the complex's own, pose-independent operands): the tasks are 32-row
+    // tiles of a flat list of edges (i, j, code, radial bits); the gated messages go out row-major as fp16 [row][256]
+    const uint4 *rows;
+    const uint32_t *n_rows_dev;  // row count on the device (filled by k_edge_feat's classification), or nullptr: n_rows
+    uint32_t n_rows;
+    uint16_t *rows_out;
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -770,14 +776,29 @@ __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
 // AW16: A_i comes as fp16 (one 16-byte load per chunk instead of two; bf16 operands only).  w_r stays fp32: its product with the
 // radial |x_i - x_j|^2 (thousands of A^2) is the one large term of the pre-activation, and an fp16 w_r moved the worst force
 // deviation of the bf16 engine from 7.2e-3 to 8.8e-3
-template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg(EdgeKArgs p)
+//
+// ROWS = 1 (layer 0 behind the per-complex message table, see k_l0_gather): the same pipeline over a flat LIST of edges instead of the
+// K edges of a node - the intra-chain edges whose table entry does not apply and every inter-chain edge of an evaluation, or all
+// intra-chain pairs of the complex when the table is built.  A task is one 32-row tile of the list, every row carries its own
+// (i, j, code, radial), A_i is gathered per row like Bm_j, and instead of the segment sum the gated messages are stored row-major
+// as fp16 (S * gate * m, the unit of the last layer's message buffer).  Rows are independent in the contraction, so a row's result
+// does not depend on which other rows share its tile.
+template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg(EdgeKArgs p)
 {
+    static_assert(!ROWS || (F16 && AW16), "the row-list form exists for the shipped 16-bit plan only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *Wf = reinterpret_cast<uint4 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform BY ANALYSIS too: the tile walk below stays in SGPRs
     char *stage = smem + LDS_WF_BYTES + wave * LDS_STAGE_BYTES;
     const int h = lane >> 5, l31 = lane & 31;
+    uint32_t n_rows = 0, n_row_tiles = 0;
+    if constexpr (ROWS) {
+        n_rows = __builtin_amdgcn_readfirstlane(p.n_rows_dev ? *p.n_rows_dev : p.n_rows);
+        n_row_tiles = (n_rows + 31u) >> 5;
+        if (blockIdx.x >= n_row_tiles) return;      // tasks go wave-major (wave w of workgroup g starts at tile w * grid + g): nothing for this
+                                                    // workgroup - leave before the 128 KiB weight fill (the launch is sized for the capacity)
+    }
     for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
     __syncthreads();
 
@@ -788,15 +809,16 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
     // give every wave a few nodes - a single tile, whose partial segment sum is added to the pre-zeroed agg atomically.  Both
     // forms produce bitwise the same agg: per tile x_t = inv_s * (sum over its rows), agg = x_0 + x_1 (two addends: commutative).
     const int K = p.K, ntile = (K + 31) >> 5;
-    const bool split = p.split != 0;
+    const bool split = ROWS || p.split != 0;
     const int NT = split ? p.nodes * ntile : p.nodes;
     const int nsplit = p.B >= 8 ? 1 : (8 + p.B - 1) / p.B;
-    const int NTc = (NT + nsplit - 1) / nsplit;
+    const int NTc = ROWS ? 1 : (NT + nsplit - 1) / nsplit;
     const int U = p.B * nsplit;
     const int nb_x = U > xcd ? (U - xcd + 7) >> 3 : 0;
-    const unsigned ntask = (unsigned)nb_x * (unsigned)NTc;
-    const unsigned tstride = (unsigned)wg_per_xcd * EDGE_WAVES;
+    const unsigned ntask = ROWS ? n_row_tiles : (unsigned)nb_x * (unsigned)NTc;
+    const unsigned tstride = ROWS ? gridDim.x * EDGE_WAVES : (unsigned)wg_per_xcd * EDGE_WAVES;
     auto task_tile = [&](unsigned tt, int &b, int &i, int &mt) -> bool {      // first tile of task tt
+        if constexpr (ROWS) { b = 0; i = (int)tt; mt = 0; return true; }      // row-list form: "node" i = the tile of the list
         const unsigned tq = tt / (unsigned)NTc, tr = tt - tq * (unsigned)NTc;
         const int u = xcd + 8 * (int)tq;
         b = __builtin_amdgcn_readfirstlane(u / nsplit);
@@ -817,21 +839,32 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
     onef.u = make_uint4(h == 0 ? (F16 ? 0x3c003c00u : 0x3f803f80u) : 0u, 0u, 0u, 0u);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(p.T2b), rs_w = make_rsrc(p.w_r);
-    const __amdgpu_buffer_rsrc_t rs_e = make_rsrc(p.edges), rs_c = make_rsrc(p.codes), rs_r = make_rsrc(p.radial);
+    const __amdgpu_buffer_rsrc_t rs_e = make_rsrc(ROWS ? (const void *)p.rows : (const void *)p.edges), rs_c = make_rsrc(p.codes), rs_r = make_rsrc(p.radial);
     const int r16 = lane >> 2, c4 = lane & 3;
     const uint32_t oc4 = c4 * 32;
     // epilogue constants: the row (inside a tile) whose sum this lane ends up with in half_reduce_scatter; byte address of lane 0 of
     // this lane's half for ds_bpermute
     const int rs_j = rs_index(lane), rs_row = (rs_j & 3) + 8 * (rs_j >> 2) + 4 * h, bp_base = (lane & 32) * 4;
 
-    unsigned tt = (unsigned)wave * (unsigned)wg_per_xcd + (unsigned)slot;      // wave-major: a launch with fewer tasks than waves spreads over ALL workgroups
+    unsigned tt = ROWS ? (unsigned)wave * gridDim.x + blockIdx.x
+                       : (unsigned)wave * (unsigned)wg_per_xcd + (unsigned)slot;      // wave-major: a launch with fewer tasks than waves spreads over ALL workgroups
                                                                                // (a few waves each, a SIMD to themselves) instead of filling the first ones
     int b = 0, i = 0, mt = 0;
     if (!next_task(tt, b, i, mt)) return;
 
     // raw edge data of the tile in lookahead (rows past K read the node's last edge and are masked in set_tile)
     int jqn[2]; uint32_t codeqn[2]; float radqn[2];
+    int iqn[2] = {0, 0};      // row-list form: the row's own node
     auto load_idx = [&](int tb, int ti, int tm) {
+        if constexpr (ROWS) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t s = (uint32_t)ti * 32u + (uint32_t)(q * 16 + r16);
+                const u32x4v rec = __builtin_amdgcn_raw_buffer_load_b128(rs_e, (int)((s < n_rows ? s : n_rows - 1u) * 16u), 0, 0);
+                iqn[q] = (int)rec.x; jqn[q] = (int)rec.y; codeqn[q] = rec.z; radqn[q] = __uint_as_float(rec.w);
+            }
+            return;
+        }
         const uint32_t ebase = ((uint32_t)tb * (uint32_t)p.N + (uint32_t)ti) * (uint32_t)K;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -847,18 +880,21 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
 #if !DFM_TAB_MERGE
     uint32_t ot2[2];
 #endif
+    uint32_t oa[2] = {0u, 0u};      // row-list form: byte offset of the row's own A_i
     float radq[2], radq_nx[2];
     __amdgpu_buffer_rsrc_t rs_bm = rs_t, rs_a = rs_t;
     auto set_tile = [&](int tb, int ti, int tm) {      // from jqn / codeqn / radqn of that tile
         const size_t ab = (size_t)tb * p.ab_bstride;
         rs_bm = make_rsrc(p.Bmb + ab);
-        rs_a = AW16 ? make_rsrc(p.Ah + ab + (size_t)ti * H) : make_rsrc(p.A + ab + (size_t)ti * H);
+        if constexpr (ROWS) rs_a = make_rsrc(p.Ah);
+        else rs_a = AW16 ? make_rsrc(p.Ah + ab + (size_t)ti * H) : make_rsrc(p.A + ab + (size_t)ti * H);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {      // masked rows (>= K): self edge, zero features -> finite values, gate forced to 0
-            const bool v = tm * 32 + q * 16 + r16 < K;
-            const int j = v ? jqn[q] : ti;
+        for (int q = 0; q < 2; ++q) {      // masked rows (>= K; row-list form: past the end of the list): self edge, zero features -> finite values, gate forced to 0
+            const bool v = ROWS ? (uint32_t)ti * 32u + (uint32_t)(q * 16 + r16) < n_rows : tm * 32 + q * 16 + r16 < K;
+            const int j = v ? jqn[q] : (ROWS ? 0 : ti);
             const uint32_t code = v ? codeqn[q] : 0u;
             radq_nx[q] = v ? radqn[q] : 0.f;
+            if constexpr (ROWS) oa[q] = (uint32_t)(v ? iqn[q] : 0) * (H * 2) + c4 * 16;
             obm[q] = (uint32_t)j * (H * 2) + c4 * 16;
 #if DFM_TAB_MERGE
             ot0[q] = ((((code >> 6) & 31u) * 24u + ((code >> 11) & 31u)) * 12u + ((code >> 16) & 15u)) * (H * 2) + c4 * 16;
@@ -894,7 +930,8 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
 #ifndef DFM_EDGE_A_NT      // 1: the A_i row carries the non-temporal hint like the single-pass streams; 0 (shipped): cached - the node's second
 #define DFM_EDGE_A_NT 0     // tile and the other half of each 128-byte line re-read it: 2.187 vs 2.221 ms per launch, same box
 #endif
-        if constexpr (AW16) a0 = DFM_EDGE_A_NT ? bload16f_stream(rs_a, c4 * 16, c * 64) : bload16f(rs_a, c4 * 16, c * 64);
+        if constexpr (ROWS) { a0 = bload16f(rs_a, oa[0], c * 64); a1 = bload16f(rs_a, oa[1], c * 64); }      // a row of A per pass
+        else if constexpr (AW16) a0 = DFM_EDGE_A_NT ? bload16f_stream(rs_a, c4 * 16, c * 64) : bload16f(rs_a, c4 * 16, c * 64);
         else { a0 = bload16f_stream(rs_a, oc4, c * 128); a1 = bload16f_stream(rs_a, oc4, c * 128 + 16); }
         w0 = bload16f(rs_w, oc4, c * 128); w1 = bload16f(rs_w, oc4, c * 128 + 16);
     };
@@ -937,7 +974,7 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
 #ifdef DFM_EDGE_DENSE_UB
                 const float4 &aq = q == 1 ? a1 : a0;
 #else
-                const float4 &aq = a0;
+                const float4 &aq = (ROWS && q == 1) ? a1 : a0;
 #endif
                 const uint32_t ah = __float_as_uint(e == 0 ? aq.x : (e == 1 ? aq.y : (e == 2 ? aq.z : aq.w)));
                 pv[e] = (f2){fma_half_lo(wv.x, radq[q], ah), fma_half_hi(wv.y, radq[q], ah)};
@@ -1098,13 +1135,47 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
             // that holds the row's sum, then handed to every lane of the half (ds_bpermute: no VALU issue slot)
             const float logit = half_reduce_scatter(part, lane);
             const int rown = mt * 32 + rs_row;
-            const float gate = rown < K ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(logit + p.att_b)) : 0.f;
+            const bool row_live = ROWS ? (uint32_t)i * 32u + (uint32_t)rs_row < n_rows : rown < K;
+            const float gate = row_live ? __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(logit + p.att_b)) : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int src = ((r & 8) >> 3) | ((r & 4) >> 1) | ((r & 2) << 1) | ((r & 1) << 3);      // the lane (of 16) with rs_index == r
                 part[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_base + src * 4, __builtin_bit_cast(int, gate)));
             }
         }
+        if constexpr (ROWS) {
+            // Row-list form: the gated messages of the tile's 32 rows, row-major fp16 [row][256] (512 B per row).  Same transposition
+            // through the wave's free staging buffer as the last layer's store below; a unit (8 channels of one row, 16 B) goes to
+            // uint4 slot row * 32 + nt * 4 + unit-of-the-n-tile.  Cached stores: k_l0_gather reads the rows back out of L2 / the
+            // Infinity Cache within the same evaluation (the table build keeps its rows for the life of the complex).
+            char *tb = stage + 2048;
+            uint4 *Rout = reinterpret_cast<uint4 *>(p.rows_out) + (size_t)i * (32 * 32);
+            const int u = l31 >> 3;
+            int wbase[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) wbase[x] = u * 512 + ((x ^ u) + 4 * h) * 16 + (l31 & 7) * 2;
+            int rd[2], wr[2];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const int unit = lane + 64 * k2, uu = unit >> 5, row = unit & 31;
+                rd[k2] = uu * 512 + (row ^ uu) * 16;
+                wr[k2] = row * 32 + uu;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const uint32_t pk = pack_f16_sat_lo(acc[nt][r] * part[r], acc[nt][r + 1] * part[r + 1]);
+                    *reinterpret_cast<uint16_t *>(tb + wbase[r & 3] + (r >> 2) * 128) = (uint16_t)pk;
+                    *reinterpret_cast<uint16_t *>(tb + wbase[(r + 1) & 3] + (r >> 2) * 128) = (uint16_t)(pk >> 16);
+                }
+                wave_lds_fence();
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(tb + rd[0]), v1 = *reinterpret_cast<const uint4 *>(tb + rd[1]);
+                wave_lds_fence();      // the reads have returned before the next n-tile overwrites the buffer
+                Rout[wr[0] + nt * 4] = v0;
+                Rout[wr[1] + nt * 4] = v1;
+            }
+        } else {
         if (p.last && i >= p.R) {
             // Gated messages of a ligand node in the A-fragment order k_edge_coord reads: [k-step 16][lane half 2][row 32][8 channels].
             // An n-tile (32 channels) is one contiguous 2 KiB of that: 4 units (k-step, half) x 32 rows x 16 B.  A lane owns ONE
@@ -1185,6 +1256,7 @@ template <int F16, int AW16> __global__ __launch_bounds__(EDGE_WAVES * 64) void 
                 colsum[nt] = 0.f;
             }
         }
+        }      // !ROWS
         STAMP(3);
         if (!have_next) break;
         // the rest of the next tile's chunk 1 (kept out of the epilogue's register budget): the second pass is first used at slot 8
@@ -1488,6 +1560,82 @@ hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
     const EdgeKArgs k = to_kargs_mfma(a, 1);
     const long long tasks = (long long)a.B * (a.N - a.R);
     return a.f16 ? launch_coord_t<1>(k, tasks, s) : launch_coord_t<0>(k, tasks, s);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Layer 0 behind the per-complex message table (src/models/egnn.py:95-104 evaluated once per intra-chain pair instead of once per
+// edge, trajectory and step).  In layer 0 the node features are the embedding h0 of the complex (score_net_mlsb.py:365-366: no pose,
+// no time in it), so the gated message of an edge (i, j) is a function of the pair's geometry alone - and for two residues of the
+// SAME chain that geometry never changes under the rigid motion of the ligand.  M0 [pairs][256] (fp16, S * gate * m like the last
+// layer's message buffer) holds it for every intra-chain ordered pair; an evaluation then needs
+//   k_edge_feat      (kernels_geom.hip) classifies every edge: intra-chain AND its per-pose feature code equal to the table's code0 ->
+//                    src = pair index; anything else (inter-chain edges; the rare pair whose fp32 features land in another bin in this
+//                    pose than in the table's) -> appended to a row list, src = MISS | position
+//   k_edge_msg<1,1,1> the edge model on the row list -> X [position][256]
+//   k_l0_gather      agg[b][i] = (1 / S) * sum over the node's K slots IN SLOT ORDER of M0[src] or X[position]: no atomics, and the value
+//                    of a row does not depend on its position in the list, so the result is a pure function of (pose, graph)
+// At 300+300 that is 0.55 ms of gather-sum out of L2 / the Infinity Cache plus a message launch over 2 - 13 % of the edges instead of
+// 2.2 ms (profiles/r04_l0_table.txt).  The only approximation against the direct kernel is the fp16 rounding of each stored message
+// before the 60-row sum (the direct kernel sums fp32 registers).
+constexpr uint32_t L0_MISS = 0x80000000u;
+
+__global__ __launch_bounds__(256) void k_l0_gather(const uint2 *__restrict__ table, const uint2 *__restrict__ X, const uint32_t *__restrict__ src,
+                                                   float4 *__restrict__ agg, int B, int N, int K, float inv_s, uint32_t *counter,
+                                                   unsigned long long *miss_total)
+{
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t == 0 && lane == 0) {      // this evaluation's row list is consumed: keep the count for the profile, reset it for the next evaluation
+        *miss_total += *counter;
+        *counter = 0u;
+    }
+    if (t >= (long long)B * N) return;
+    // node-major task order: neighbouring waves handle the same node of neighbouring trajectories, whose kNN slots are the same
+    // table rows (the chain is rigid) - they are re-read from this XCD's L2 instead of from the Infinity Cache
+    const int i = (int)(t / B), b = (int)(t - (long long)i * B);
+    const size_t node = (size_t)b * N + i;
+    const uint32_t my = lane < K ? src[node * K + lane] : 0u;      // K <= 60: one slot per lane
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < K; s0 += 6) {      // six rows in flight per lane (8-byte loads: a wave instruction covers one 512-byte row)
+        uint2 v[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my, (s0 + q) < K ? s0 + q : 0);      // wave-uniform: scalar base address
+            const uint2 *row = (id & L0_MISS) ? X + (size_t)(id & ~L0_MISS) * 64 : table + (size_t)id * 64;
+            v[q] = (s0 + q) < K ? row[lane] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (s0 + q < K) {
+                acc.x = add_half_lo(acc.x, v[q].x); acc.y = add_half_hi(acc.y, v[q].x);
+                acc.z = add_half_lo(acc.z, v[q].y); acc.w = add_half_hi(acc.w, v[q].y);
+            }
+        }
+    }
+    agg[node * 64 + lane] = make_float4(acc.x * inv_s, acc.y * inv_s, acc.z * inv_s, acc.w * inv_s);
+}
+
+hipError_t launch_l0_gather(const uint16_t *table, const uint16_t *X, const uint32_t *src, float *agg, int B, int N, int K,
+                            uint32_t *counter, unsigned long long *miss_total, hipStream_t s)
+{
+    const long long waves = (long long)B * N;
+    hipLaunchKernelGGL(k_l0_gather, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const uint2 *>(table),
+                       reinterpret_cast<const uint2 *>(X), src, reinterpret_cast<float4 *>(agg), B, N, K, 1.0f / SILU_S, counter, miss_total);
+    return hipGetLastError();
+}
+
+// the edge model over a row list (a = layer 0's EdgeArgs: the complex's own A0h / Bmb0, ab_bstride 0); n_rows_dev = nullptr: exactly
+// n_rows_cap rows.  `out` must hold the row count rounded up to 32 rows (the last tile stores all of its rows).
+hipError_t launch_edge_rows(const EdgeArgs &a, const uint4 *rows, const uint32_t *n_rows_dev, uint32_t n_rows_cap, uint16_t *out, hipStream_t s)
+{
+    if (!a.Ah || !a.f16 || a.ab_bstride != 0 || n_rows_cap == 0) return hipErrorInvalidValue;
+    EdgeKArgs k = to_kargs_mfma(a, 0);
+    k.rows = rows; k.n_rows_dev = n_rows_dev; k.n_rows = n_rows_cap; k.rows_out = out; k.last = 0;
+    static std::atomic<bool> attr_done[MAX_DEVICES];
+    hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_msg<1, 1, 1>), LDS_EDGE_BYTES, attr_done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_edge_msg<1, 1, 1>), dim3(persistent_grid(((long long)n_rows_cap + 31) / 32)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
+    return hipGetLastError();
 }
 
 }  // namespace dfm

@@ -303,17 +303,10 @@ __device__ inline int bin_angle(float a)
     return b;
 }
 
-__global__ __launch_bounds__(256) void k_edge_feat(const float *__restrict__ pos, const float4 *__restrict__ ca4,
-                                                   const float4 *__restrict__ cb4, const int32_t *__restrict__ edges,
-                                                   long long total, int N, int R, int K, float mask_dist,
-                                                   uint32_t *__restrict__ codes, float *__restrict__ radial)
+// features of one ordered pair (i, j) of trajectory `base / N`: packed bin code + radial
+__device__ inline void edge_feature(const float *__restrict__ pos, const float4 *__restrict__ ca4, const float4 *__restrict__ cb4,
+                                    size_t base, int i, int j, int R, float mask_dist, uint32_t &code, float &r2_out)
 {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const long long node = e / K;
-    const int b = (int)(node / N), i = (int)(node % N);
-    const int j = edges[e];
-    const size_t base = (size_t)b * N;
     const float4 cai4 = ca4[base + i], caj4 = ca4[base + j], cbi4 = cb4[base + i], cbj4 = cb4[base + j];
     const float *pi = pos + (base + i) * 9;
     const v3 Ni{pi[0], pi[1], pi[2]};
@@ -339,16 +332,103 @@ __global__ __launch_bounds__(256) void k_edge_feat(const float *__restrict__ pos
     int off = i - j + 32;
     off = off < 0 ? 0 : (off > 64 ? 64 : off);
     const int rp = same ? off : 65;
-    codes[e] = pack_code(bd, bo, bt, bp, rp);
-    radial[e] = r2;
+    code = pack_code(bd, bo, bt, bp, rp);
+    r2_out = r2;
+}
+
+// index of the intra-chain ordered pair (i, j) in the layer-0 message table: the receptor block [R][R], then the ligand block [L][L]
+__device__ inline uint32_t l0_pair_index(int i, int j, int R, int L)
+{
+    return i < R ? (uint32_t)i * (uint32_t)R + (uint32_t)j : (uint32_t)R * (uint32_t)R + (uint32_t)(i - R) * (uint32_t)L + (uint32_t)(j - R);
+}
+
+// cls.code0 set (layer 0 behind the message table, kernels_edge.hip: k_l0_gather): the edge is a table HIT when both residues are of
+// one chain and the code just computed from THIS pose equals the code the table entry was built with - the bins are discontinuous
+// functions of fp32 geometry, and a rigidly moved chain can land on the other side of a boundary in the last bit; such an edge is
+// evaluated like an inter-chain one, so the bins the engine uses are always those of the pose at hand.  Misses are appended to the
+// row list (one atomic per wave; the position of a row has no influence on its value).
+template <int CLS>      // CLS 1: with the table classification, 1024 threads per workgroup (one list reservation per workgroup)
+__global__ __launch_bounds__(CLS ? 1024 : 256) void k_edge_feat(const float *__restrict__ pos, const float4 *__restrict__ ca4,
+                                                   const float4 *__restrict__ cb4, const int32_t *__restrict__ edges,
+                                                   long long total, int N, int R, int K, float mask_dist,
+                                                   uint32_t *__restrict__ codes, float *__restrict__ radial, L0Classify cls)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e < total;
+    if (!CLS && !live) return;
+    int i = 0, j = 0;
+    uint32_t code = 0u;
+    float r2 = 0.f;
+    if (live) {
+        const long long node = e / K;
+        const int b = (int)(node / N);
+        i = (int)(node % N);
+        j = edges[e];
+        edge_feature(pos, ca4, cb4, (size_t)b * N, i, j, R, mask_dist, code, r2);
+        codes[e] = code;
+        radial[e] = r2;
+    }
+    if constexpr (CLS) {
+        // positions in the row list: wave ballot -> one LDS add per wave -> ONE global add per workgroup.  (One global add per wave -
+        // 144 k returning atomics on one address per evaluation at C3 - serialises in the L2: 1.2 ms, profiles/r04_l0_table.txt.)
+        __shared__ uint32_t s_cnt, s_base;
+        if (threadIdx.x == 0) s_cnt = 0u;
+        __syncthreads();
+        const bool same = (i < R) == (j < R);
+        const uint32_t idx = (live && same) ? l0_pair_index(i, j, R, N - R) : 0u;
+        const bool hit = live && same && cls.code0[idx] == code;
+        const bool is_miss = live && !hit;
+        const unsigned long long miss = __ballot(is_miss);
+        const int lane = threadIdx.x & 63;
+        uint32_t wbase = 0u;
+        if (miss && lane == 0) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(miss));
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(cls.counter, s_cnt) : 0u;
+        __syncthreads();
+        if (is_miss) {
+            const uint32_t at = s_base + wbase + (uint32_t)__popcll(miss & ((1ull << lane) - 1ull));
+            cls.rows[at] = make_uint4((uint32_t)i, (uint32_t)j, code, __float_as_uint(r2));
+            cls.src[e] = 0x80000000u | at;
+        } else if (hit) cls.src[e] = idx;
+    }
 }
 
 hipError_t launch_edge_feat(const float *pos, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B, int N,
-                            int R, int K, float mask_dist, uint32_t *codes, float *radial, hipStream_t s)
+                            int R, int K, float mask_dist, uint32_t *codes, float *radial, const L0Classify &cls, hipStream_t s)
 {
     const long long total = (long long)B * N * K;
-    hipLaunchKernelGGL(k_edge_feat, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pos, ca4, cb4, edges, total,
-                       N, R, K, mask_dist, codes, radial);
+    if (cls.code0)
+        hipLaunchKernelGGL(k_edge_feat<1>, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, pos, ca4, cb4, edges, total,
+                           N, R, K, mask_dist, codes, radial, cls);
+    else
+        hipLaunchKernelGGL(k_edge_feat<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pos, ca4, cb4, edges, total,
+                           N, R, K, mask_dist, codes, radial, cls);
+    return hipGetLastError();
+}
+
+// every intra-chain ordered pair of the complex (self pairs included: slot 0 of a node is the node itself) as a row list for the table
+// build, features from the prepared pose of trajectory 0; code0 = the code each table entry is built with
+__global__ __launch_bounds__(256) void k_l0_pairs(const float *__restrict__ pos, const float4 *__restrict__ ca4, const float4 *__restrict__ cb4,
+                                                  int R, int L, float mask_dist, uint32_t *__restrict__ code0, uint4 *__restrict__ rows)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x, RR = (uint32_t)R * (uint32_t)R, P = RR + (uint32_t)L * (uint32_t)L;
+    if (q >= P) return;
+    int i, j;
+    if (q < RR) { i = (int)(q / (uint32_t)R); j = (int)(q - (uint32_t)i * (uint32_t)R); }
+    else { const uint32_t w = q - RR; const int il = (int)(w / (uint32_t)L); i = R + il; j = R + (int)(w - (uint32_t)il * (uint32_t)L); }
+    uint32_t code;
+    float r2;
+    edge_feature(pos, ca4, cb4, 0, i, j, R, mask_dist, code, r2);
+    code0[q] = code;
+    rows[q] = make_uint4((uint32_t)i, (uint32_t)j, code, __float_as_uint(r2));
+}
+
+hipError_t launch_l0_pairs(const float *pos, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint32_t *code0,
+                           uint4 *rows, hipStream_t s)
+{
+    const long long P = (long long)R * R + (long long)L * L;
+    hipLaunchKernelGGL(k_l0_pairs, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, pos, ca4, cb4, R, L, mask_dist, code0, rows);
     return hipGetLastError();
 }
 

@@ -155,9 +155,10 @@ class Complex:
         L.check(L.lib().dfm_complex_set_homomer(self._h, int(bool(flag))), "dfm_complex_set_homomer")
 
     def score(self, lig_pos, t, edges=None, seed=0, mfma16=False, energy=True, debug=False, profile=False, f16=False,
-              ires=False, return_edges=False, bf16_ops=False, dist=False, bf16=False):
+              ires=False, return_edges=False, bf16_ops=False, dist=False, bf16=False, l0_table=False):
         """B score evaluations.  lig_pos [B,L,3,3] (or [L,3,3]), t [B] (or scalar).  mfma16: the 16-bit MFMA engine
-        (`bf16=` is its deprecated keyword of rounds 1-3)."""
+        (`bf16=` is its deprecated keyword of rounds 1-3).  l0_table: layer 0 through the per-complex message table
+        (DFM_F_L0_TABLE; mfma16 only - `sample` uses it by default, `score` only on request)."""
         mfma16 = mfma16 or bf16
         lig_pos = _f32(lig_pos)
         if lig_pos.ndim == 3:
@@ -195,7 +196,7 @@ class Complex:
                 raise ValueError(f"edges must be [B,N,K] = {(B, N, K)}, got {e.shape}")
         flags = (L.DFM_F_MFMA16 if mfma16 else 0) | (L.DFM_F_ENERGY if energy else 0) | (L.DFM_F_PROFILE if profile else 0) | \
                 (L.DFM_F_F16 if f16 else 0) | (L.DFM_F_IRES if ires else 0) | (L.DFM_F_BF16_OPS if bf16_ops else 0) | \
-                (L.DFM_F_DIST if dist else 0)
+                (L.DFM_F_DIST if dist else 0) | (L.DFM_F_L0_TABLE if l0_table else 0)
         rc = L.lib().dfm_score(self._h, B, _p(lig_pos), _p(t), _p(e, L.I32P), int(seed), flags, C.byref(out))
         L.check(rc, "dfm_score")
         if debug:
@@ -206,8 +207,9 @@ class Complex:
 
     def sample(self, B=1, num_steps=40, eps=1e-3, tr_noise_scale=0.5, rot_noise_scale=0.5, noise_annealing=False,
                use_clash_force=False, ode=False, seed=0, mfma16=False, inject=None, trace=False, profile=False, f16=False, bf16_ops=False,
-               bf16=False):
-        """B independent Euler-Maruyama trajectories (inference_base.py:390-468 batched)."""
+               bf16=False, l0_table=True):
+        """B independent Euler-Maruyama trajectories (inference_base.py:390-468 batched).  l0_table=False: DFM_F_NO_L0_TABLE
+        (layer 0 evaluated edge by edge even where the per-complex message table applies)."""
         mfma16 = mfma16 or bf16
         Lg, N, K, S = self.L, self.N, self.K, int(num_steps)
         o = dict(lig_pos=np.zeros((B, Lg, 3, 3), np.float32), rot_update=np.zeros((B, 3), np.float32),
@@ -237,7 +239,7 @@ class Complex:
         flags = (L.DFM_F_MFMA16 if mfma16 else 0) | (L.DFM_F_NOISE_ANNEALING if noise_annealing else 0) | \
                 (L.DFM_F_CLASH_FORCE if use_clash_force else 0) | (L.DFM_F_ODE if ode else 0) | \
                 (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if trace else 0) | (L.DFM_F_F16 if f16 else 0) | \
-                (L.DFM_F_BF16_OPS if bf16_ops else 0)
+                (L.DFM_F_BF16_OPS if bf16_ops else 0) | (0 if l0_table else L.DFM_F_NO_L0_TABLE)
         rc = L.lib().dfm_sample(self._h, int(B), S, float(eps), float(tr_noise_scale), float(rot_noise_scale), flags,
                                 int(seed), C.byref(inj) if inj is not None else None, C.byref(out))
         L.check(rc, "dfm_sample")
@@ -270,4 +272,6 @@ class Complex:
         p = L.ProfileC()
         L.check(L.lib().dfm_get_profile(self._h, C.byref(p)), "dfm_get_profile")
         return dict(edge_kernel_ms=p.edge_kernel_ms, edge_kernel_launches=p.edge_kernel_launches,
-                    edge_rows=p.edge_rows, total_ms=p.total_ms, phase_cycles=list(p.phase_cycles), slot_cycles=list(p.slot_cycles))
+                    edge_rows=p.edge_rows, total_ms=p.total_ms, phase_cycles=list(p.phase_cycles), slot_cycles=list(p.slot_cycles),
+                    l0_evals=p.l0_evals, l0_edges=p.l0_edges, l0_miss_rows=p.l0_miss_rows, l0_rows_ms=p.l0_rows_ms,
+                    l0_gather_ms=p.l0_gather_ms, l0_build_ms=p.l0_build_ms)

@@ -92,10 +92,20 @@ enum {
     DFM_F_IRES = 1u << 8,            /* dfm_score: also evaluate the interface-residue head (score_net_mlsb.py:383) */
     DFM_F_DIST = 1u << 10,           /* dfm_score, family 1: also evaluate dist_logits = to_dist(cat[h_r, h_l, D]) over all R x L pairs
                                         (egnn_net.py:347-352,:447; a training-loss input, never read by a sampler); fp32 in every engine */
-    DFM_F_BF16_OPS = 1u << 9         /* with DFM_F_MFMA16: bf16 instead of fp16 MFMA operands in layers 0..depth-2 (the r02
+    DFM_F_BF16_OPS = 1u << 9,        /* with DFM_F_MFMA16: bf16 instead of fp16 MFMA operands in layers 0..depth-2 (the r02
                                         plan; ~3 % faster).  OUTSIDE SURVEY 8(d)'s 1e-2 gate: measured up to 1.5e-2 on f /
                                         tr_score / rot_score over four weight draws (profiles/r03_tol_report.txt) - an opt-in
                                         for callers who accept that; tested at 2e-2                                      */
+    /* Layer 0 behind the per-complex message table (DFM_F_MFMA16 engine only; src/models/egnn.py:95-104 evaluated once per
+       intra-chain residue pair instead of once per edge, trajectory and step - in layer 0 the node features are the pose-independent
+       embedding, and the geometry of two residues of one chain does not change under the rigid motion of the ligand).  dfm_sample
+       uses the table whenever the complex is eligible (depth >= 2, (R^2 + L^2) * 516 B and the per-batch row buffers within the
+       budgets in api.hip), whatever the batch size; dfm_score is a pure function of its arguments and uses it only on request.
+       Inter-chain edges, and intra-chain edges whose feature bins in the pose at hand differ from the table's, go through the edge
+       model as before.  Against the direct evaluation the only difference is the fp16 rounding of each stored message before the
+       K-row sum (measured: tests/test_gpu_l0_table.py).                                                                  */
+    DFM_F_L0_TABLE = 1u << 11,       /* dfm_score: use (and if necessary build) the table                                */
+    DFM_F_NO_L0_TABLE = 1u << 12     /* dfm_sample: evaluate layer 0 directly                                            */
 };
 
 /* Output of dfm_score.  Required: tr_score, rot_score.  Any other pointer may be NULL. */
@@ -150,6 +160,13 @@ typedef struct {
                                  message kernel's third launch, mean over the 8 waves of workgroup 0:
                                  prologue | chunks 0-6 | chunk 7 + bias | epilogue                */
     double slot_cycles[16];   /* diagnostic builds only: summed cycles between consecutive MFMA slots of chunk 3 (wave 0) */
+    /* layer 0 behind the message table (DFM_F_L0_TABLE): its launches are NOT part of edge_kernel_* above */
+    int64_t l0_evals;         /* evaluations whose layer 0 ran through the table                                 */
+    int64_t l0_edges;         /* edges of those layer-0 passes (B*N*K each)                                       */
+    int64_t l0_miss_rows;     /* of which evaluated by the edge model (inter-chain + bin mismatches)              */
+    double l0_rows_ms;        /* summed HIP-event time of the row-list message launches                           */
+    double l0_gather_ms;      /* ... of the gather-sum launches                                                  */
+    double l0_build_ms;       /* table build of this call (0 when the table already existed)                      */
 } dfm_profile;
 
 /* Output of dfm_complex_selfcheck: how far the 16-bit MFMA engine is from the fp32 engine (the reference's own arithmetic) on THIS
