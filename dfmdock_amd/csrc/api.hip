@@ -96,6 +96,8 @@ struct Workspace {
     float *fvec = nullptr, *en_part = nullptr; int32_t *clash_part = nullptr;
     float *fpart = nullptr, *cpart = nullptr, *conf = nullptr;    // family 1: force partials per receptor tile, confidence
     float *scores = nullptr, *lig_cur = nullptr, *tr_update = nullptr, *rot_update = nullptr, *t_dev = nullptr;
+    float *hid_base = nullptr;       // [max(Bcap, 1024)][2][128]: time-dependent half of the score-scale MLPs (k_time_embed), per trajectory
+                                     // (dfm_score) or per step of the time grid (dfm_sample)
     float *ir1 = nullptr, *ir2 = nullptr, *ir3 = nullptr;      // to_ires scratch, allocated on the first DFM_F_IRES call
     // layer 0 behind the message table (allocated on first use): per edge the source of its gated message, the row list of the
     // edges the edge model still evaluates, their messages, the list's length and the running total for the profile
@@ -615,6 +617,7 @@ static bool l0_eligible(const dfm_complex *cx, int B)
     return pairs <= L0_MAX_PAIRS && (long long)B * cx->N * cx->K <= L0_MAX_EDGES;
 }
 
+constexpr int MAX_TIME_GRID = 4096;      // steps of a dfm_sample call whose time embeddings fit the workspace (more: DFM_E_INVALID)
 static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
 {
     Workspace &W = cx->ws;
@@ -647,7 +650,8 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
             HIPCHK(W.pool.alloc(&W.conf, b));
         }
         HIPCHK(W.pool.alloc(&W.lig_cur, b * L * 9)); HIPCHK(W.pool.alloc(&W.tr_update, b * 3));
-        HIPCHK(W.pool.alloc(&W.rot_update, b * 3)); HIPCHK(W.pool.alloc(&W.t_dev, b));
+        HIPCHK(W.pool.alloc(&W.rot_update, b * 3)); HIPCHK(W.pool.alloc(&W.t_dev, b > MAX_TIME_GRID ? b : (size_t)MAX_TIME_GRID));
+        HIPCHK(W.pool.alloc(&W.hid_base, (b > MAX_TIME_GRID ? b : (size_t)MAX_TIME_GRID) * 2 * HI));
         W.Bcap = B;
     }
     if (wants_mbuf && !W.mbuf) HIPCHK(W.pool.alloc(&W.mbuf, (size_t)W.Bcap * cx->L * KPAD * H));
@@ -698,12 +702,6 @@ static int build_l0_table(dfm_complex *cx, float *build_ms)
     if (build_ms) HIPCHK(hipEventElapsedTime(build_ms, cx->ev_total[0], cx->ev_total[1]));
     cx->l0_valid = true;
     return DFM_OK;
-}
-
-__global__ void k_fill(float *dst, float v, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = v;
 }
 
 // Precision plan of the 16-bit MFMA engine (DFM_F_MFMA16).  Chosen on FOUR weight draws run through the reference - three
@@ -972,7 +970,7 @@ static void fill_head_args(dfm_complex *cx, int B, bool want_energy, HeadArgs *a
 {
     Workspace &W = cx->ws;
     std::memset(a, 0, sizeof(*a));
-    a->fvec = W.fvec; a->ca4 = W.ca4; a->B = B; a->R = cx->R; a->L = cx->L; a->t = W.t_dev; a->hw = &cx->m->heads;
+    a->fvec = W.fvec; a->ca4 = W.ca4; a->B = B; a->R = cx->R; a->L = cx->L; a->hid_base = W.hid_base; a->hid_bstride = 2 * HI; a->hw = &cx->m->heads;
     a->scores = W.scores; a->want_energy = want_energy; a->en_part = W.en_part; a->clash_part = W.clash_part;
     a->lig_cur = W.lig_cur; a->tr_update = W.tr_update; a->rot_update = W.rot_update;
     const dfm_hparams &hp = cx->m->hp;
@@ -1060,6 +1058,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     }
     HIPCHK(hipMemcpyAsync(W.lig_cur, lig_pos, (size_t)B * L * 9 * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(W.t_dev, t, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_time_embed(W.t_dev, B, &cx->m->heads, W.hid_base, s));      // one entry per trajectory (fill_head_args: stride 2 * HI)
     DevPool tmp;   // per-call device buffers (injected edges, debug tap); released on every return path
     int32_t *edges_dev = nullptr;
     float *h_first_dev = nullptr;
@@ -1153,6 +1152,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
 {
     if (!cx || !out) return fail(DFM_E_INVALID, "NULL argument");
     if (B < 1 || num_steps < 2) return fail(DFM_E_INVALID, "need B >= 1 and num_steps >= 2");
+    if (num_steps > MAX_TIME_GRID) return fail(DFM_E_INVALID, "num_steps above 4096");
     const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_MFMA16) || f16;
     DEVICE_SCOPE(cx->device);
     // layer 0 through the complex's message table whenever the shipped 16-bit plan runs and the complex is eligible - a property of
@@ -1205,6 +1205,9 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     if (out->trace_pose) HIPCHK(tmp.alloc(&tp_d, (size_t)B * S * L * 9));
     if (out->trace_scores) HIPCHK(tmp.alloc(&tsc_d, (size_t)B * (S + 1) * 8));
 
+    // every trajectory of a step shares its time: the time-dependent half of the score-scale MLPs for the whole grid, once per call
+    HIPCHK(hipMemcpyAsync(W.t_dev, ts.data(), S * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_time_embed(W.t_dev, num_steps, &cx->m->heads, W.hid_base, s));
     HIPCHK(hipEventRecord(cx->ev_total[0], s));
     HIPCHK(launch_init_pose(cx->rec_pos, cx->lig0, B, cx->R, cx->L, hp.family == 1, R0_d, trd_d, seed, W.lig_cur, W.tr_update,
                             W.rot_update, s));
@@ -1218,14 +1221,13 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     const bool step_energy = (flags & DFM_F_STEP_ENERGY) != 0;
     for (int i = 0; i < num_steps; ++i) {
         const bool is_last = (i == num_steps - 1);
-        hipLaunchKernelGGL(k_fill, dim3((B + 255) / 256), dim3(256), 0, s, W.t_dev, ts[i], B);
-        HIPCHK(hipGetLastError());
         o.edges_dev = ed_d ? ed_d + (size_t)i * N * K : nullptr;
         o.want_energy = step_energy; o.need_node_out = step_energy;
         rc = enqueue_forward(cx, B, o);
         if (rc) return rc;
         HeadArgs ha;
         fill_head_args(cx, B, step_energy, &ha);
+        ha.hid_base = W.hid_base + (size_t)i * 2 * HI; ha.hid_bstride = 0;      // this step's time for the whole batch
         ha.do_update = 1;
         ha.g2_r = (float)(gr[i] * gr[i]); ha.g_r = (float)gr[i]; ha.hg2_r = (float)(0.5 * (gr[i] * gr[i]));
         ha.g2_t = (float)(gt[i] * gt[i]); ha.g_t = (float)gt[i]; ha.hg2_t = (float)(0.5 * (gt[i] * gt[i]));
@@ -1252,6 +1254,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     {
         HeadArgs ha;
         fill_head_args(cx, B, true, &ha);
+        ha.hid_base = W.hid_base + (size_t)(num_steps - 1) * 2 * HI; ha.hid_bstride = 0;      // same t as the last step
         if (tsc_d) { ha.trace_scores = tsc_d + (size_t)num_steps * 8; ha.trace_s_bstride = (int64_t)(S + 1) * 8; }
         HIPCHK(launch_heads(ha, s));
     }
@@ -1306,6 +1309,7 @@ extern "C" int dfm_complex_selfcheck(dfm_complex *cx, int n_eval, const float *t
     for (int b = 0; b < B; ++b)
         HIPCHK(hipMemcpyAsync(W.lig_cur + (size_t)b * L * 9, cx->lig0, L * 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(W.t_dev, t.data(), (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_time_embed(W.t_dev, B, &cx->m->heads, W.hid_base, s));
 
     struct Res { std::vector<float> sc, f; };
     auto run = [&](bool mfma, Res &r) -> int {

@@ -244,7 +244,8 @@ struct HeadArgs {
     const float *fvec;       // [B][L][3]
     const float4 *ca4;       // [B][N]
     int B, R, L;
-    const float *t;          // [B] device
+    const float *hid_base;   // time-dependent half of the scale MLPs' first Linear (launch_time_embed): [.][2][128]
+    int64_t hid_bstride;     // elements between trajectories in hid_base (0: the whole batch shares one time)
     const HeadsDev *hw;
     float *scores;           // [B][8] tr(3) rot(3) energy clashes
     // energy (optional)
@@ -274,6 +275,8 @@ struct HeadArgs {
     int64_t trace_s_bstride;
 };
 hipError_t launch_heads(const HeadArgs &a, hipStream_t s);
+// base[n][2][128] for the n times t_dev[n] (kernels_heads.hip: k_time_embed)
+hipError_t launch_time_embed(const float *t_dev, int n, const HeadsDev *hw, float *base, hipStream_t s);
 
 hipError_t launch_energy_pairs(const float *enA, const float *enB, const float4 *ca4, int B, int R, int L,
                                float cut_off, const HeadsDev *hw, int want_energy, float *en_part,

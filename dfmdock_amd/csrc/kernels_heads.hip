@@ -72,11 +72,51 @@ hipError_t launch_energy_pairs(const float *enA, const float *enB, const float4 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Time-dependent half of the two score-scale MLPs, off the per-evaluation critical path: for every time t[n]
+//   t_embed = Sigmoid(Linear(GaussianFourierProjection(t)))                  (score_net_mlsb.py:407, :162-172)
+//   base[n][g][c] = sum_k t_embed[k] * W_g[c][1 + k]      g = 0 translation / 1 rotation scale net, first Linear(129 -> 128)
+// so that k_heads only adds the norm column: hid = W_g[c][0] * |pred| + base.  dfm_sample calls it ONCE for its whole time grid
+// (every trajectory of a step shares t), dfm_score once per call for its B times.  r01-r03 evaluated both Linears inside k_heads
+// with one thread per output row: 256 dependent, uncoalesced row reads per evaluation (64 cache lines per wave instruction) - most
+// of that kernel's 25-33 us, which small batches cannot hide.  Here a wave owns an output and reads its row coalesced.
+__global__ __launch_bounds__(256) void k_time_embed(const float *__restrict__ t, HeadsDev hw, float *__restrict__ base)
+{
+    __shared__ float s_four[HI], s_temb[HI];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float tv = t[n];
+    if (tid < HI / 2) {
+        const float xp = ((tv * hw.t_W[tid]) * 2.0f) * 3.14159265358979323846f;
+        s_four[tid] = sinf(xp);
+        s_four[HI / 2 + tid] = cosf(xp);
+    }
+    __syncthreads();
+    for (int o = wave; o < HI; o += 4) {
+        const float *row = hw.t_lin + (size_t)o * HI;
+        const float v = wave_sum(fmaf(s_four[lane], row[lane], s_four[64 + lane] * row[64 + lane]));
+        if (lane == 0) s_temb[o] = sigmoid_exact(v);
+    }
+    __syncthreads();
+    for (int q = wave; q < 2 * HI; q += 4) {
+        const int g = q >> 7, c = q & (HI - 1);
+        const float *row = (g ? hw.rots0 : hw.trs0) + (size_t)c * (HI + 1) + 1;
+        const float v = wave_sum(fmaf(s_temb[lane], row[lane], s_temb[64 + lane] * row[64 + lane]));
+        if (lane == 0) base[(size_t)n * (2 * HI) + q] = v;
+    }
+}
+
+hipError_t launch_time_embed(const float *t_dev, int n, const HeadsDev *hw, float *base, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_time_embed, dim3(n), dim3(256), 0, s, t_dev, *hw, base);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 struct HeadKArgs {
     const float *fvec;
     const float4 *ca4;
     int R, L;
-    const float *t;
+    const float *hid_base;       // [.][2][128] from k_time_embed; trajectory b reads entry b * hid_bstride (0: one time for the batch)
+    long long hid_bstride;
     HeadsDev hw;
     float *scores;
     int want_energy;
@@ -109,14 +149,35 @@ __device__ inline float group_sum(float v, float *scratch, int tid)
     return scratch[g * 2] + scratch[g * 2 + 1];
 }
 
+// NV block sums (256 threads) behind ONE pair of barriers; per value the arithmetic of block_sum_d (wave butterfly, then the four
+// wave sums in wave order)
+template <int NV> __device__ inline void block_sum_dn(double (&v)[NV], double *scratch /*[4 * NV]*/)
+{
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum_d(v[k]);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) scratch[w * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = ((scratch[k] + scratch[NV + k]) + scratch[2 * NV + k]) + scratch[3 * NV + k];
+}
+
 __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
 {
-    __shared__ double dscr[8];
-    __shared__ float s_four[HI], s_temb[HI], s_red[4], s_pred[8], s_score[8], s_upd[16];
+    __shared__ double dscr[4 * 12];
+    __shared__ float s_red[4], s_pred[8], s_score[8], s_upd[16];
     const int b = blockIdx.x, tid = threadIdx.x, R = p.R, L = p.L, N = R + L;
+    float *lig = p.lig_cur + (size_t)b * L * 9;
 
-    // :396-404  f = pos_out[lig] - r ;  tr_pred = mean f ; rot_pred = mean (r x f)
-    double a[6] = {0, 0, 0, 0, 0, 0};
+    // every reduction over the trajectory's residues in one pass and one exchange (r01-r03: fifteen block sums in sequence):
+    //  [0..5]  :396-404  f = pos_out[lig] - r ;  tr_pred = mean f ; rot_pred = mean (r x f)
+    //  [6..8]  centre of the pose BEFORE this step's update (modify_coords, inference_base.py:342-352)
+    //  [9..11] energy = sum(e * mask) / (sum(mask) + 1e-6) ; num_clashes
+    double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int q = tid; q < L; q += blockDim.x) {
         const float *f = p.fvec + ((size_t)b * L + q) * 3;
         const float4 r = p.ca4[(size_t)b * N + R + q];
@@ -125,26 +186,35 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
         a[4] += r.z * f[0] - r.x * f[2];
         a[5] += r.x * f[1] - r.y * f[0];
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) a[k] = block_sum_d(a[k], dscr);
+    if (p.do_update) {
+        if (p.all_atoms) {   // second family: centre = mean over all backbone atoms (src/inference.py:245, DFMDock.py:247)
+            for (int q = tid; q < L * 3; q += blockDim.x) { a[6] += lig[q * 3]; a[7] += lig[q * 3 + 1]; a[8] += lig[q * 3 + 2]; }
+        } else {
+            for (int q = tid; q < L; q += blockDim.x) { a[6] += lig[q * 9 + 3]; a[7] += lig[q * 9 + 4]; a[8] += lig[q * 9 + 5]; }
+        }
+    }
+    if (p.want_energy) {
+        for (int r = tid; r < p.n_part; r += blockDim.x) {
+            a[9] += p.en_part[((size_t)b * p.n_part + r) * 2];
+            a[10] += p.en_part[((size_t)b * p.n_part + r) * 2 + 1];
+            a[11] += p.clash_part[(size_t)b * p.n_part + r];
+        }
+    }
+    block_sum_dn<12>(a, dscr);
     if (tid < 6) s_pred[tid] = (float)(a[tid] / p.pool_div);
-
-    // :407  t_embed = Sigmoid(Linear(GaussianFourierProjection(t)))
-    const float t = p.t[b];
-    if (tid < HI / 2) {
-        const float xp = ((t * p.hw.t_W[tid]) * 2.0f) * 3.14159265358979323846f;
-        s_four[tid] = sinf(xp);
-        s_four[HI / 2 + tid] = cosf(xp);
-    }
-    __syncthreads();
-    if (tid < HI) {
-        float acc = 0.f;
-        for (int k = 0; k < HI; ++k) acc = fmaf(s_four[k], p.hw.t_lin[tid * HI + k], acc);
-        s_temb[tid] = sigmoid_exact(acc);
+    if (tid == 0) {
+        if (p.want_energy) {
+            s_score[6] = p.en_mode == 0 ? (float)a[9] / ((float)a[10] + 1e-6f)
+                                        : (p.en_mode == 1 ? (float)a[9] / fmaxf((float)a[10], 1.0f) : (float)a[9]);
+            s_score[7] = (float)a[11];
+        } else {
+            s_score[6] = 0.f; s_score[7] = 0.f;
+        }
     }
     __syncthreads();
 
-    // :408-411  two scale MLPs in parallel: threads 0..127 translation, 128..255 rotation
+    // :408-411  two scale MLPs in parallel: threads 0..127 translation, 128..255 rotation; the t_embed half of the first Linear
+    // comes from k_time_embed
     {
         const int g = tid >> 7, c = tid & 127;
         const float *pred = s_pred + g * 3;
@@ -152,8 +222,7 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
         const float *lw = g ? p.hw.rots_ln_w : p.hw.trs_ln_w, *lb = g ? p.hw.rots_ln_b : p.hw.trs_ln_b;
         const float *w4 = g ? p.hw.rots4 : p.hw.trs4;
         const float nrm = sqrtf((pred[0] * pred[0] + pred[1] * pred[1]) + pred[2] * pred[2]);
-        float hid = w0[c * (HI + 1)] * nrm;
-        for (int k = 0; k < HI; ++k) hid = fmaf(s_temb[k], w0[c * (HI + 1) + 1 + k], hid);
+        const float hid = fmaf(w0[c * (HI + 1)], nrm, p.hid_base[(size_t)b * p.hid_bstride + tid]);
         const float mean = group_sum(hid, s_red, tid) * (1.0f / HI);
         const float d = hid - mean;
         const float var = group_sum(d * d, s_red, tid) * (1.0f / HI);
@@ -165,25 +234,6 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
         }
     }
     __syncthreads();
-
-    // energy = sum(e * mask) / (sum(mask) + 1e-6) ; num_clashes
-    if (p.want_energy) {
-        double es = 0, cs = 0, ks = 0;
-        for (int r = tid; r < p.n_part; r += blockDim.x) {
-            es += p.en_part[((size_t)b * p.n_part + r) * 2];
-            cs += p.en_part[((size_t)b * p.n_part + r) * 2 + 1];
-            ks += p.clash_part[(size_t)b * p.n_part + r];
-        }
-        es = block_sum_d(es, dscr); cs = block_sum_d(cs, dscr); ks = block_sum_d(ks, dscr);
-        if (tid == 0) {
-            s_score[6] = p.en_mode == 0 ? (float)es / ((float)cs + 1e-6f)
-                                        : (p.en_mode == 1 ? (float)es / fmaxf((float)cs, 1.0f) : (float)es);
-            s_score[7] = (float)ks;
-        }
-    } else if (tid == 0) {
-        s_score[6] = 0.f; s_score[7] = 0.f;
-    }
-    __syncthreads();
     if (tid < 8) {
         p.scores[(size_t)b * 8 + tid] = s_score[tid];
         if (p.trace_scores) p.trace_scores[(size_t)b * p.trace_s_bstride + tid] = s_score[tid];
@@ -191,14 +241,7 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
     if (!p.do_update) return;
 
     // ---- Euler-Maruyama step (inference_base.py:439-456) ---------------------------------------
-    float *lig = p.lig_cur + (size_t)b * L * 9;
-    double c0 = 0, c1 = 0, c2 = 0;
-    if (p.all_atoms) {   // second family: centre = mean over all backbone atoms (src/inference.py:245, DFMDock.py:247)
-        for (int q = tid; q < L * 3; q += blockDim.x) { c0 += lig[q * 3]; c1 += lig[q * 3 + 1]; c2 += lig[q * 3 + 2]; }
-    } else {
-        for (int q = tid; q < L; q += blockDim.x) { c0 += lig[q * 9 + 3]; c1 += lig[q * 9 + 4]; c2 += lig[q * 9 + 5]; }
-    }
-    c0 = block_sum_d(c0, dscr); c1 = block_sum_d(c1, dscr); c2 = block_sum_d(c2, dscr);
+    const double c0 = a[6], c1 = a[7], c2 = a[8];
     const int ncen = p.all_atoms ? L * 3 : L;
     if (tid == 0) {
         float zr[3], zt[3];
@@ -263,7 +306,7 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
 hipError_t launch_heads(const HeadArgs &a, hipStream_t s)
 {
     HeadKArgs k;
-    k.fvec = a.fvec; k.ca4 = a.ca4; k.R = a.R; k.L = a.L; k.t = a.t; k.hw = *a.hw; k.scores = a.scores;
+    k.fvec = a.fvec; k.ca4 = a.ca4; k.R = a.R; k.L = a.L; k.hid_base = a.hid_base; k.hid_bstride = a.hid_bstride; k.hw = *a.hw; k.scores = a.scores;
     k.want_energy = a.want_energy; k.en_part = a.en_part; k.clash_part = a.clash_part; k.do_update = a.do_update;
     k.n_part = a.n_part; k.en_mode = a.en_mode; k.pool_div = a.pool_div;
     k.g2_r = a.g2_r; k.g_r = a.g_r; k.hg2_r = a.hg2_r; k.g2_t = a.g2_t; k.g_t = a.g_t; k.hg2_t = a.hg2_t;
