@@ -29,6 +29,7 @@ DFM_F_BF16_OPS = 1 << 9
 DFM_F_DIST = 1 << 10
 DFM_F_L0_TABLE = 1 << 11       # dfm_score: layer 0 through the per-complex message table
 DFM_F_NO_L0_TABLE = 1 << 12    # dfm_sample: layer 0 evaluated directly
+DFM_F_GRAPH = 1 << 13          # dfm_sample: replay one captured step as a hipGraph (opt-in)
 
 EXPORTS = [
     "dfm_last_error", "dfm_config_string", "dfm_device_count", "dfm_set_device", "dfm_default_hparams", "dfm_param_count",

@@ -125,7 +125,7 @@ def success_table(rows):
                     "best_DockQ": float(max(r["DockQ"] for r in rs)), "mean_DockQ": float(np.mean([r["DockQ"] for r in rs]))}
     n = max(len(per), 1)
     table = {name: {"threshold": thr, "top1": sum(p["top1_DockQ"] >= thr for p in per.values()) / n,
-                    "oracle": sum(p["best_DockQ"] >= thr for p in per.values()) / n} for name, thr in DOCKQ_THRESHOLDS}
+                    "best_of_n": sum(p["best_DockQ"] >= thr for p in per.values()) / n} for name, thr in DOCKQ_THRESHOLDS}
     return per, table
 
 
@@ -135,7 +135,7 @@ def format_table(per, table):
         lines.append(f"{cid:8s} {p['n']:4d} {p['top1_DockQ']:11.4f} {p['best_DockQ']:11.4f} {p['top1_energy']:12.4f}")
     lines.append(f"success rate over {len(per)} complexes (DockQ of the minimum-energy trajectory | best of the trajectories):")
     for name, t in table.items():
-        lines.append(f"  {name:10s} DockQ >= {t['threshold']:.2f}: {100 * t['top1']:5.1f} % | {100 * t['oracle']:5.1f} %")
+        lines.append(f"  {name:10s} DockQ >= {t['threshold']:.2f}: {100 * t['top1']:5.1f} % | {100 * t['best_of_n']:5.1f} %")
     return "\n".join(lines)
 
 

@@ -103,6 +103,8 @@ struct Workspace {
     // edges the edge model still evaluates, their messages, the list's length and the running total for the profile
     uint32_t *l0_src = nullptr; uint4 *l0_rows = nullptr; uint16_t *l0_x = nullptr; uint32_t *l0_counter = nullptr;
     unsigned long long *l0_miss_total = nullptr;
+    // replayed step graph: {evaluations started, seed lo, seed hi, -} and the per-step scalars of the call's time grid
+    uint32_t *step_ctl = nullptr; StepParams *step_params = nullptr;
 };
 
 struct dfm_complex {
@@ -130,6 +132,13 @@ struct dfm_complex {
     bool l0_valid = false;
     std::vector<hipEvent_t> ev_l0;   // profiling events of the table path (triples: before rows | between | after gather)
     size_t ev_l0_used = 0;
+    // One step of dfm_sample (score evaluation + heads + Euler-Maruyama update [+ clash force]) captured as a hipGraph and replayed
+    // num_steps times: every per-step / per-call scalar is read from device memory (ws.step_ctl, ws.step_params), so the nodes are
+    // the same in every step AND every call - the executable graph is kept until the buffers it points into move
+    hipGraphExec_t step_exec = nullptr;
+    uint64_t step_key = 0;       // (B, engine flags) the graph was captured for
+    uint64_t buf_gen = 0;        // bumped whenever a buffer a captured launch points into is re-allocated (workspace, message table)
+    uint64_t step_gen = ~0ull;   // buf_gen at capture
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -560,6 +569,7 @@ extern "C" void dfm_complex_destroy(dfm_complex *cx)
     if (!cx) return;
     DeviceScope ds(cx->device);
     if (cx->stream) { (void)hipStreamSynchronize(cx->stream); (void)hipStreamDestroy(cx->stream); }
+    if (cx->step_exec) (void)hipGraphExecDestroy(cx->step_exec);
     for (hipEvent_t e : cx->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : cx->ev_l0) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (cx->ev_total[i]) (void)hipEventDestroy(cx->ev_total[i]);
@@ -632,6 +642,7 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
         HIPCHK(hipStreamSynchronize(cx->stream));
         W.pool.release();
         W = Workspace();
+        cx->buf_gen++;
         const size_t N = cx->N, L = cx->L, R = cx->R, K = cx->K, b = B;
         HIPCHK(W.pool.alloc(&W.pos, b * N * 9)); HIPCHK(W.pool.alloc(&W.ca4, b * N)); HIPCHK(W.pool.alloc(&W.cb4, b * N));
         HIPCHK(W.pool.alloc(&W.edges, b * N * K)); HIPCHK(W.pool.alloc(&W.codes, b * N * K));
@@ -652,10 +663,12 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
         HIPCHK(W.pool.alloc(&W.lig_cur, b * L * 9)); HIPCHK(W.pool.alloc(&W.tr_update, b * 3));
         HIPCHK(W.pool.alloc(&W.rot_update, b * 3)); HIPCHK(W.pool.alloc(&W.t_dev, b > MAX_TIME_GRID ? b : (size_t)MAX_TIME_GRID));
         HIPCHK(W.pool.alloc(&W.hid_base, (b > MAX_TIME_GRID ? b : (size_t)MAX_TIME_GRID) * 2 * HI));
+        HIPCHK(W.pool.alloc(&W.step_ctl, 4)); HIPCHK(W.pool.alloc(&W.step_params, (size_t)MAX_TIME_GRID));
         W.Bcap = B;
     }
-    if (wants_mbuf && !W.mbuf) HIPCHK(W.pool.alloc(&W.mbuf, (size_t)W.Bcap * cx->L * KPAD * H));
+    if (wants_mbuf && !W.mbuf) { HIPCHK(W.pool.alloc(&W.mbuf, (size_t)W.Bcap * cx->L * KPAD * H)); cx->buf_gen++; }
     if (l0 && !W.l0_src) {
+        cx->buf_gen++;
         const size_t cap = (size_t)W.Bcap * cx->N * cx->K;      // every edge of a batched evaluation may miss the table
         HIPCHK(W.pool.alloc(&W.l0_src, cap)); HIPCHK(W.pool.alloc(&W.l0_rows, cap));
         HIPCHK(W.pool.alloc(&W.l0_x, (cap + 32) * H));          // the last tile of the row list stores all of its 32 rows
@@ -687,6 +700,7 @@ static int build_l0_table(dfm_complex *cx, float *build_ms)
     cx->l0_valid = false;
     HIPCHK(hipStreamSynchronize(s));
     cx->l0_pool.release();
+    cx->buf_gen++;
     HIPCHK(cx->l0_pool.alloc(&cx->l0_table, ((P + 31) / 32 * 32) * H));
     HIPCHK(cx->l0_pool.alloc(&cx->l0_code0, P));
     DevPool tmp;
@@ -738,6 +752,7 @@ extern "C" const char *dfm_config_string(void)
 struct FwdOpts {
     bool bf16 = false, f16 = false, want_energy = false, profile = false;   // bf16: 16-bit MFMA engine; f16: ... with fp32 A_i
     bool bf16_ops = false;                // bf16 MFMA operands in every layer but the last (DFM_F_BF16_OPS)
+    uint32_t *ctl = nullptr;              // replayed step graph: device {evaluation index, seed} block (ws.step_ctl) instead of by-value seed / stream id
     bool l0_table = false;                // layer 0 through the complex's message table (cx->l0_valid, workspace l0 buffers allocated)
     bool need_node_out = true;            // false: nobody reads the final node features (no energy / ires / debug tap) - the last layer then
                                           // computes the messages of the ligand nodes only (all the coordinate update reads) and no node model
@@ -797,12 +812,12 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         HIPCHK(hipMemcpy2DAsync(W.edges, (size_t)N * K * 4, o.edges_dev, (size_t)o.edges_pitch * 4, (size_t)N * K * 4, B,
                                 hipMemcpyDeviceToDevice, s));
     } else {
-        HIPCHK(launch_knn_sample(W.ca4, B, N, cx->knn, cx->nsamp, o.seed, stream_id, W.edges, s));
+        HIPCHK(launch_knn_sample(W.ca4, B, N, cx->knn, cx->nsamp, o.seed, stream_id, W.edges, o.ctl, s));
     }
     L0Classify cls;
     std::memset(&cls, 0, sizeof(cls));
     if (o.l0_table) { cls.code0 = cx->l0_code0; cls.src = W.l0_src; cls.rows = W.l0_rows; cls.counter = W.l0_counter; }
-    HIPCHK(launch_edge_feat(W.pos, W.ca4, W.cb4, W.edges, B, N, R, K, m->hp.mask_dist, W.codes, W.radial, cls, s));
+    HIPCHK(launch_edge_feat(W.pos, W.ca4, W.cb4, W.edges, B, N, R, K, m->hp.mask_dist, W.codes, W.radial, cls, o.ctl, s));
     // layer 0 reads the node embedding h0 [N][256] of the complex itself - identical for every trajectory - through a row period
     // (GemmArgs::a0_period / r_period) instead of a [B][N][256] copy made per evaluation (r01-r03: k_bcast_rows, 157 MB of writes at C3)
     const float *h = cx->h0;
@@ -1219,13 +1234,9 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     o.bf16 = bf16; o.f16 = f16; o.bf16_ops = bf16 && !f16 && (flags & DFM_F_BF16_OPS); o.profile = flags & DFM_F_PROFILE; o.seed = seed; o.edges_pitch = (int64_t)(S + 1) * N * K;
     o.l0_table = l0;
     const bool step_energy = (flags & DFM_F_STEP_ENERGY) != 0;
-    for (int i = 0; i < num_steps; ++i) {
+    // the by-value arguments of step i's k_heads launch
+    auto step_head_args = [&](int i, HeadArgs &ha) {
         const bool is_last = (i == num_steps - 1);
-        o.edges_dev = ed_d ? ed_d + (size_t)i * N * K : nullptr;
-        o.want_energy = step_energy; o.need_node_out = step_energy;
-        rc = enqueue_forward(cx, B, o);
-        if (rc) return rc;
-        HeadArgs ha;
         fill_head_args(cx, B, step_energy, &ha);
         ha.hid_base = W.hid_base + (size_t)i * 2 * HI; ha.hid_bstride = 0;      // this step's time for the whole batch
         ha.do_update = 1;
@@ -1239,6 +1250,58 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
         ha.z_bstride = (int64_t)S * 3; ha.seed = seed; ha.step = (uint32_t)i;
         if (tp_d) { ha.trace_pose = tp_d + (size_t)i * L * 9; ha.trace_bstride = (int64_t)S * L * 9; }
         if (tsc_d) { ha.trace_scores = tsc_d + (size_t)i * 8; ha.trace_s_bstride = (int64_t)(S + 1) * 8; }
+    };
+    // Replayed step graph (DFM_F_GRAPH, or DFM_GRAPH=1 in the environment): nothing injected, traced or timed per launch.  Same
+    // kernels with the same arguments as the plain path - bitwise the same trajectories (tests/test_gpu_graph.py).
+    static const bool graph_env_on = [] { const char *e = getenv("DFM_GRAPH"); return e && atoi(e) != 0; }();
+    const bool use_graph = (graph_env_on || (flags & DFM_F_GRAPH)) && !(flags & (DFM_F_PROFILE | DFM_F_STEP_ENERGY)) && !inj && !tp_d && !tsc_d;
+    if (use_graph) {
+        std::vector<StepParams> sp(S);
+        for (int i = 0; i < num_steps; ++i) {
+            HeadArgs ha;
+            step_head_args(i, ha);
+            sp[i] = StepParams{ha.g2_r, ha.g_r, ha.hg2_r, ha.g2_t, ha.g_t, ha.hg2_t, ha.dt, ha.sqrt_dt, ha.rot_noise, ha.tr_noise, ha.step, 0u};
+        }
+        const uint32_t ctl_h[4] = {0u, (uint32_t)seed, (uint32_t)(seed >> 32), 0u};
+        HIPCHK(hipMemcpyAsync(W.step_params, sp.data(), S * sizeof(StepParams), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(W.step_ctl, ctl_h, sizeof(ctl_h), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));      // (pageable sources: the copies have read them)
+        const uint64_t key = ((uint64_t)(uint32_t)B << 32) | (uint64_t)(flags & (DFM_F_MFMA16 | DFM_F_F16 | DFM_F_BF16_OPS | DFM_F_CLASH_FORCE | DFM_F_ODE | DFM_F_NO_L0_TABLE))
+                             | (l0 ? 1ull << 31 : 0ull);
+        if (!cx->step_exec || cx->step_key != key || cx->step_gen != cx->buf_gen) {
+            if (cx->step_exec) { (void)hipGraphExecDestroy(cx->step_exec); cx->step_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            o.ctl = W.step_ctl; o.edges_dev = nullptr; o.want_energy = false; o.need_node_out = false;
+            int crc = enqueue_forward(cx, B, o);
+            if (crc == DFM_OK) {
+                HeadArgs ha;
+                step_head_args(0, ha);
+                ha.hid_base = W.hid_base; ha.step_params = W.step_params; ha.ctl = W.step_ctl;
+                hipError_t e = launch_heads(ha, s);
+                if (e == hipSuccess && (flags & DFM_F_CLASH_FORCE)) e = launch_clash_force(cx->rec_pos, B, cx->R, cx->L, W.lig_cur, W.tr_update, s);
+                if (e != hipSuccess) crc = fail(DFM_E_HIP, hipGetErrorString(e));
+            }
+            const std::string keep = g_err;
+            hipError_t ee = hipStreamEndCapture(s, &graph);      // always: a stream left in capture mode is unusable
+            o.ctl = nullptr;
+            if (crc != DFM_OK) { if (graph) (void)hipGraphDestroy(graph); g_err = keep; return crc; }
+            if (ee != hipSuccess) return fail(DFM_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ee));
+            ee = hipGraphInstantiate(&cx->step_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ee != hipSuccess) { cx->step_exec = nullptr; return fail(DFM_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ee)); }
+            cx->step_key = key; cx->step_gen = cx->buf_gen;
+        }
+        for (int i = 0; i < num_steps; ++i) HIPCHK(hipGraphLaunch(cx->step_exec, s));
+        cx->fwd_counter = (uint32_t)num_steps;      // the final evaluation below draws its graph from Philox stream num_steps
+    } else
+    for (int i = 0; i < num_steps; ++i) {
+        o.edges_dev = ed_d ? ed_d + (size_t)i * N * K : nullptr;
+        o.want_energy = step_energy; o.need_node_out = step_energy;
+        rc = enqueue_forward(cx, B, o);
+        if (rc) return rc;
+        HeadArgs ha;
+        step_head_args(i, ha);
         HIPCHK(launch_heads(ha, s));
         if (flags & DFM_F_CLASH_FORCE) {   // inference_base.py:458-461
             HIPCHK(launch_clash_force(cx->rec_pos, B, cx->R, cx->L, W.lig_cur, W.tr_update, s));

@@ -170,8 +170,9 @@ int gemm_rows_per_tile();   // 64: the row tile of k_gemm_split (tiles of the fu
 
 hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, int all_atoms, float *pos,
                             float4 *ca4, float4 *cb4, hipStream_t s);
+// ctl (or nullptr): device words {evaluation index, seed lo, seed hi} that override seed / stream_id (replayed step graph)
 hipError_t launch_knn_sample(const float4 *ca4, int B, int N, int knn, int nsamp, uint64_t seed, uint32_t stream_id,
-                             int32_t *edges, hipStream_t s);
+                             int32_t *edges, const uint32_t *ctl, hipStream_t s);
 // layer 0 behind the per-complex message table (kernels_edge.hip: k_l0_gather): k_edge_feat's classification of every edge into
 // table hits (src = pair index) and row-list entries (src = 0x80000000 | position).  code0 == nullptr: no classification.
 struct L0Classify {
@@ -181,7 +182,8 @@ struct L0Classify {
     uint32_t *counter;       // rows appended so far (zero at the start of an evaluation: k_l0_gather resets it)
 };
 hipError_t launch_edge_feat(const float *pos, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B,
-                            int N, int R, int K, float mask_dist, uint32_t *codes, float *radial, const L0Classify &cls, hipStream_t s);
+                            int N, int R, int K, float mask_dist, uint32_t *codes, float *radial, const L0Classify &cls,
+                            uint32_t *eval_ctr /* or nullptr: incremented once per launch (replayed step graph) */, hipStream_t s);
 hipError_t launch_l0_pairs(const float *pos, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint32_t *code0,
                            uint4 *rows, hipStream_t s);
 
@@ -240,6 +242,9 @@ hipError_t launch_pair_dist(const float *P, const float *Q, const float4 *ca4, i
 hipError_t launch_pair_finish(const float *fpart, int B, int R, int L, float inv_pool, float *fvec, const float *cpart,
                               float *conf, hipStream_t s);
 
+// per-step scalars of the Euler-Maruyama update as k_heads reads them from device memory when the step loop is a replayed graph
+struct StepParams { float g2_r, g_r, hg2_r, g2_t, g_t, hg2_t, dt, sqrt_dt, rot_noise, tr_noise; uint32_t step, pad; };
+
 struct HeadArgs {
     const float *fvec;       // [B][L][3]
     const float4 *ca4;       // [B][N]
@@ -273,6 +278,10 @@ struct HeadArgs {
     int64_t trace_bstride;
     float *trace_scores;     // [B][steps+1][8] or nullptr (already offset)
     int64_t trace_s_bstride;
+    // replayed step graph: ctl = device words {evaluations started, seed lo, seed hi}; the step's scalars are step_params[ctl[0] - 1],
+    // its time embedding hid_base + (ctl[0] - 1) * 256 (the by-value fields above are then ignored)
+    const StepParams *step_params;
+    const uint32_t *ctl;
 };
 hipError_t launch_heads(const HeadArgs &a, hipStream_t s);
 // base[n][2][128] for the n times t_dev[n] (kernels_heads.hip: k_time_embed)

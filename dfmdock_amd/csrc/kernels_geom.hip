@@ -161,8 +161,11 @@ __device__ inline int lanes_below(unsigned long long m)      // set bits of m be
 template <int NPL>
 __global__ __launch_bounds__(256) void k_knn_sample(const float4 *__restrict__ ca4, int B, int N, int knn, int nsamp,
                                                     uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
-                                                    int32_t *__restrict__ edges)
+                                                    int32_t *__restrict__ edges, const uint32_t *__restrict__ ctl)
 {
+    // ctl (replayed step graph, api.hip: StepCtl): the evaluation index and the call's seed come from device memory, so that the
+    // captured launch is the same node in every step and every call
+    if (ctl) { stream_id = ctl[0]; seed_lo = ctl[1]; seed_hi = ctl[2]; }
     __shared__ uint32_t sh_key[4][64], sh_j[4][64];
     __shared__ int32_t sh_out[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -248,12 +251,12 @@ __global__ __launch_bounds__(256) void k_knn_sample(const float4 *__restrict__ c
 }
 
 hipError_t launch_knn_sample(const float4 *ca4, int B, int N, int knn, int nsamp, uint64_t seed, uint32_t stream_id,
-                             int32_t *edges, hipStream_t s)
+                             int32_t *edges, const uint32_t *ctl, hipStream_t s)
 {
     const long long nodes = (long long)B * N;
     const dim3 grid((unsigned)((nodes + 3) / 4)), block(256);
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-#define LAUNCH(NPL) hipLaunchKernelGGL(k_knn_sample<NPL>, grid, block, 0, s, ca4, B, N, knn, nsamp, lo, hi, stream_id, edges)
+#define LAUNCH(NPL) hipLaunchKernelGGL(k_knn_sample<NPL>, grid, block, 0, s, ca4, B, N, knn, nsamp, lo, hi, stream_id, edges, ctl)
     if (N <= 256) LAUNCH(4);
     else if (N <= 512) LAUNCH(8);
     else if (N <= 768) LAUNCH(12);
@@ -351,9 +354,13 @@ template <int CLS>      // CLS 1: with the table classification, 1024 threads pe
 __global__ __launch_bounds__(CLS ? 1024 : 256) void k_edge_feat(const float *__restrict__ pos, const float4 *__restrict__ ca4,
                                                    const float4 *__restrict__ cb4, const int32_t *__restrict__ edges,
                                                    long long total, int N, int R, int K, float mask_dist,
-                                                   uint32_t *__restrict__ codes, float *__restrict__ radial, L0Classify cls)
+                                                   uint32_t *__restrict__ codes, float *__restrict__ radial, L0Classify cls,
+                                                   uint32_t *__restrict__ eval_ctr)
 {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // replayed step graph: the evaluation counter moves on here - after its reader of this evaluation's first half (k_knn_sample, an
+    // earlier launch) and before k_heads, which reads counter - 1
+    if (eval_ctr && e == 0) *eval_ctr += 1u;
     const bool live = e < total;
     if (!CLS && !live) return;
     int i = 0, j = 0;
@@ -395,15 +402,16 @@ __global__ __launch_bounds__(CLS ? 1024 : 256) void k_edge_feat(const float *__r
 }
 
 hipError_t launch_edge_feat(const float *pos, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B, int N,
-                            int R, int K, float mask_dist, uint32_t *codes, float *radial, const L0Classify &cls, hipStream_t s)
+                            int R, int K, float mask_dist, uint32_t *codes, float *radial, const L0Classify &cls, uint32_t *eval_ctr,
+                            hipStream_t s)
 {
     const long long total = (long long)B * N * K;
     if (cls.code0)
         hipLaunchKernelGGL(k_edge_feat<1>, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, pos, ca4, cb4, edges, total,
-                           N, R, K, mask_dist, codes, radial, cls);
+                           N, R, K, mask_dist, codes, radial, cls, eval_ctr);
     else
         hipLaunchKernelGGL(k_edge_feat<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pos, ca4, cb4, edges, total,
-                           N, R, K, mask_dist, codes, radial, cls);
+                           N, R, K, mask_dist, codes, radial, cls, eval_ctr);
     return hipGetLastError();
 }
 

@@ -136,6 +136,8 @@ struct HeadKArgs {
     long long trace_bstride;
     float *trace_scores;
     long long trace_s_bstride;
+    const StepParams *step_params;      // replayed step graph (HeadArgs::ctl): this step's scalars, seed and time embedding from device memory
+    const uint32_t *ctl;
 };
 
 // sum over the 128 threads of a group (two waves); scratch[4]
@@ -172,6 +174,15 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
     __shared__ float s_red[4], s_pred[8], s_score[8], s_upd[16];
     const int b = blockIdx.x, tid = threadIdx.x, R = p.R, L = p.L, N = R + L;
     float *lig = p.lig_cur + (size_t)b * L * 9;
+    const float *hid_base = p.hid_base + (size_t)b * p.hid_bstride;
+    if (p.ctl) {      // the captured launch is the same in every step: what differs between steps is read here
+        const uint32_t idx = p.ctl[0] - 1u;
+        const StepParams q = p.step_params[idx];
+        p.g2_r = q.g2_r; p.g_r = q.g_r; p.hg2_r = q.hg2_r; p.g2_t = q.g2_t; p.g_t = q.g_t; p.hg2_t = q.hg2_t;
+        p.dt = q.dt; p.sqrt_dt = q.sqrt_dt; p.rot_noise = q.rot_noise; p.tr_noise = q.tr_noise; p.step = q.step;
+        p.seed_lo = p.ctl[1]; p.seed_hi = p.ctl[2];
+        hid_base = p.hid_base + (size_t)idx * (2 * HI);
+    }
 
     // every reduction over the trajectory's residues in one pass and one exchange (r01-r03: fifteen block sums in sequence):
     //  [0..5]  :396-404  f = pos_out[lig] - r ;  tr_pred = mean f ; rot_pred = mean (r x f)
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
         const float *lw = g ? p.hw.rots_ln_w : p.hw.trs_ln_w, *lb = g ? p.hw.rots_ln_b : p.hw.trs_ln_b;
         const float *w4 = g ? p.hw.rots4 : p.hw.trs4;
         const float nrm = sqrtf((pred[0] * pred[0] + pred[1] * pred[1]) + pred[2] * pred[2]);
-        const float hid = fmaf(w0[c * (HI + 1)], nrm, p.hid_base[(size_t)b * p.hid_bstride + tid]);
+        const float hid = fmaf(w0[c * (HI + 1)], nrm, hid_base[tid]);
         const float mean = group_sum(hid, s_red, tid) * (1.0f / HI);
         const float d = hid - mean;
         const float var = group_sum(d * d, s_red, tid) * (1.0f / HI);
@@ -316,6 +327,7 @@ hipError_t launch_heads(const HeadArgs &a, hipStream_t s)
     k.lig_cur = a.lig_cur; k.tr_update = a.tr_update; k.rot_update = a.rot_update;
     k.trace_pose = a.trace_pose; k.trace_bstride = a.trace_bstride;
     k.trace_scores = a.trace_scores; k.trace_s_bstride = a.trace_s_bstride;
+    k.step_params = a.step_params; k.ctl = a.ctl;
     hipLaunchKernelGGL(k_heads, dim3(a.B), dim3(256), 0, s, k);
     return hipGetLastError();
 }

@@ -207,9 +207,10 @@ class Complex:
 
     def sample(self, B=1, num_steps=40, eps=1e-3, tr_noise_scale=0.5, rot_noise_scale=0.5, noise_annealing=False,
                use_clash_force=False, ode=False, seed=0, mfma16=False, inject=None, trace=False, profile=False, f16=False, bf16_ops=False,
-               bf16=False, l0_table=True):
+               bf16=False, l0_table=True, graph=False):
         """B independent Euler-Maruyama trajectories (inference_base.py:390-468 batched).  l0_table=False: DFM_F_NO_L0_TABLE
-        (layer 0 evaluated edge by edge even where the per-complex message table applies)."""
+        (layer 0 evaluated edge by edge even where the per-complex message table applies).  graph=True: DFM_F_GRAPH (one captured
+        step replayed as a hipGraph instead of every launch enqueued by the host; bitwise the same results, no faster on MI355X)."""
         mfma16 = mfma16 or bf16
         Lg, N, K, S = self.L, self.N, self.K, int(num_steps)
         o = dict(lig_pos=np.zeros((B, Lg, 3, 3), np.float32), rot_update=np.zeros((B, 3), np.float32),
@@ -239,7 +240,8 @@ class Complex:
         flags = (L.DFM_F_MFMA16 if mfma16 else 0) | (L.DFM_F_NOISE_ANNEALING if noise_annealing else 0) | \
                 (L.DFM_F_CLASH_FORCE if use_clash_force else 0) | (L.DFM_F_ODE if ode else 0) | \
                 (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if trace else 0) | (L.DFM_F_F16 if f16 else 0) | \
-                (L.DFM_F_BF16_OPS if bf16_ops else 0) | (0 if l0_table else L.DFM_F_NO_L0_TABLE)
+                (L.DFM_F_BF16_OPS if bf16_ops else 0) | (0 if l0_table else L.DFM_F_NO_L0_TABLE) | \
+                (L.DFM_F_GRAPH if graph else 0)
         rc = L.lib().dfm_sample(self._h, int(B), S, float(eps), float(tr_noise_scale), float(rot_noise_scale), flags,
                                 int(seed), C.byref(inj) if inj is not None else None, C.byref(out))
         L.check(rc, "dfm_sample")

@@ -105,7 +105,15 @@ enum {
        model as before.  Against the direct evaluation the only difference is the fp16 rounding of each stored message before the
        K-row sum (measured: tests/test_gpu_l0_table.py).                                                                  */
     DFM_F_L0_TABLE = 1u << 11,       /* dfm_score: use (and if necessary build) the table                                */
-    DFM_F_NO_L0_TABLE = 1u << 12     /* dfm_sample: evaluate layer 0 directly                                            */
+    DFM_F_NO_L0_TABLE = 1u << 12,    /* dfm_sample: evaluate layer 0 directly                                            */
+    DFM_F_GRAPH = 1u << 13           /* dfm_sample: capture ONE step (score evaluation + heads + update) as a hipGraph and replay it
+                                        num_steps times instead of enqueueing every launch (ignored when anything is injected,
+                                        traced or profiled).  Same kernels and arguments - the per-step / per-call scalars are
+                                        read from device memory - so the trajectories are bitwise those of the plain path
+                                        (tests/test_gpu_graph.py).  Opt-in: on MI355X the stream is paced by the device-side
+                                        dispatch of ~30 dependent launches per evaluation, not by the host, and the replay
+                                        measures 0.2 - 1.9 % SLOWER at B = 1 ... 120 (profiles/r04_graph_ab.txt); it is there
+                                        for hosts that cannot keep a stream fed (DFM_GRAPH=1 in the environment: default on) */
 };
 
 /* Output of dfm_score.  Required: tr_score, rot_score.  Any other pointer may be NULL. */

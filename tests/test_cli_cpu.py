@@ -87,8 +87,8 @@ def test_success_table():
     per, table = cli.success_table(rows)
     assert per["A"]["top1_DockQ"] == 0.1 and per["A"]["best_DockQ"] == 0.9      # minimum energy wins, not the best DockQ
     assert per["B"]["top1_DockQ"] == 0.3                                        # energy tie: the first minimum (inference_base.py:652)
-    assert table["acceptable"]["top1"] == pytest.approx(1 / 3) and table["acceptable"]["oracle"] == pytest.approx(2 / 3)
-    assert table["medium"]["oracle"] == pytest.approx(2 / 3) and table["high"]["oracle"] == pytest.approx(1 / 3) and table["high"]["top1"] == 0
+    assert table["acceptable"]["top1"] == pytest.approx(1 / 3) and table["acceptable"]["best_of_n"] == pytest.approx(2 / 3)
+    assert table["medium"]["best_of_n"] == pytest.approx(2 / 3) and table["high"]["best_of_n"] == pytest.approx(1 / 3) and table["high"]["top1"] == 0
     txt = cli.format_table(per, table)
     assert "DockQ >= 0.23" in txt and "A " in txt
 

@@ -81,4 +81,4 @@ def test_sweep_db5_directory(tmp_path):
     assert len(rows) == 12 and list(rows[0]) == ["id", "index", "c_rmsd", "i_rmsd", "l_rmsd", "fnat", "DockQ", "energy", "num_clashes"]
     s = json.load(open(tmp_path / "s.json"))
     assert set(s["complexes"]) == {"7CEI", "SYN1"} and len(s["selfcheck"]) == 2 and all(c["selfcheck"]["ok"] for c in s["selfcheck"])
-    assert 0 <= s["success"]["acceptable"]["top1"] <= s["success"]["acceptable"]["oracle"] <= 1
+    assert 0 <= s["success"]["acceptable"]["top1"] <= s["success"]["acceptable"]["best_of_n"] <= 1
