@@ -84,18 +84,23 @@ def cpu_baseline(blob, cx, num_steps, repeats=3):
 
 
 def replayed_counters(args):
-    """HBM bytes per launch and pipe-busy fractions of the dominant kernel.  PMC counters cannot be read from inside this
-    process: the numbers are REPLAYED from the committed rocprofv3 --pmc run of this exact configuration (profiles/*_traffic.json,
-    collected as MI355X_MICROARCH.md prescribes: separate passes, FETCH_SIZE x 2 + WRITE_SIZE) and absent otherwise."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-        try:
-            t = json.load(open(os.path.join(ROOT, "profiles", name)))
-        except OSError:
-            continue
-        c = t["config"]
-        if (c["R"], c["L"], c["batch"], {"bf16": "mfma16"}.get(c["precision"], c["precision"])) == (args.R, args.L, args.batch, args.precision):
-            return t, "replayed profiles/" + name
+    """Counters of the committed rocprofv3 --pmc run of this exact configuration (profiles/r04_traffic.json, tools/make_traffic_json.py;
+    collected as MI355X_MICROARCH.md prescribes: separate passes, FETCH_SIZE x 2 + WRITE_SIZE).  PMC counters cannot be read from inside
+    this process: they are REPLAYED, per launch TYPE of the message kernel (full / ligand-only), and weighted here by the launch mix this
+    run measures itself; absent for any other configuration."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+    except OSError:
+        return None, None
+    c = t["config"]
+    if (c["R"], c["L"], c["batch"], c["precision"], bool(c.get("layer0_table"))) == (args.R, args.L, args.batch, args.precision, not args.no_l0_table) \
+            and "full" in t.get("edge", {}):
+        return t, "replayed profiles/r04_traffic.json"
     return None, None
+
+
+# reference-equivalent work of one score evaluation per residue (SURVEY.md 8d: the reference's dense formulation, all six layers in full)
+FLOP_PER_NODE_EVAL = 59.2e6
 
 
 def workload_label(a):
@@ -162,6 +167,7 @@ def main():
                          "in the JSON line says what that is); f16: the same with fp32 A_i; fp32: exact; bf16: deprecated alias of mfma16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-l0-table", action="store_true", help="A/B: layer 0 evaluated edge by edge (DFM_F_NO_L0_TABLE)")
+    ap.add_argument("--no-fp32-line", action="store_true", help="skip the secondary measurement of the fp32 engine (one more batched call)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -211,7 +217,7 @@ def main():
         one_step(it)
     barrier()
     t0 = time.perf_counter()
-    edge_ms, edge_launches, edge_rows = 0.0, 0, 0
+    edge_ms, edge_launches, edge_rows, lig_launches, lig_ms = 0.0, 0, 0, 0, 0.0
     l0 = dict(l0_evals=0, l0_edges=0, l0_miss_rows=0, l0_rows_ms=0.0, l0_gather_ms=0.0)
     allrec = None
     for it in range(args.steps):
@@ -220,12 +226,31 @@ def main():
         edge_ms += p["edge_kernel_ms"]
         edge_launches += p["edge_kernel_launches"]
         edge_rows += p["edge_rows"]
+        lig_launches += p["edge_lig_launches"]
+        lig_ms += p["edge_lig_ms"]
         for k in l0:
             l0[k] += p[k]
     barrier()
     elapsed = time.perf_counter() - t0
     per_rank = D.allgather_scalars([elapsed, float(dev)])      # max over ranks of the time; which device every rank ran on
     elapsed = float(per_rank[:, 0].max())
+    fp32_line = None
+    if rank == 0 and world == 1 and mfma16 and not args.no_fp32_line:
+        # secondary record: the fp32 engine - the reference's own arithmetic - on the same workload, one batched call
+        gx.sample(B=B, num_steps=2, seed=7, l0_table=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        gx.sample(B=B, num_steps=args.num_steps, seed=8, profile=True)
+        dt32 = time.perf_counter() - t1
+        p32 = gx.profile()
+        fl32 = p32["edge_rows"] / K_DEG * FLOP_PER_NODE_LAYER
+        fp32_line = {"value": B / dt32, "unit": "trajectories/s", "ms_per_step": dt32 * 1e3, "dtype": "f32", "steps": 1,
+                     "kernel": "k_edge_f32m (exact fp32 on v_mfma_f32_32x32x2_f32, edge model + coordinate MLP fused)",
+                     "avg_launch_ms": p32["edge_kernel_ms"] / max(p32["edge_kernel_launches"], 1),
+                     "achieved_tflops": fl32 / (p32["edge_kernel_ms"] * 1e-3) / 1e12 if p32["edge_kernel_ms"] > 0 else None,
+                     "peak_tflops": PEAK_F32_TFLOPS,
+                     "frac": (fl32 / (p32["edge_kernel_ms"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS) if p32["edge_kernel_ms"] > 0 else None,
+                     "note": "message FLOPs only in `achieved` (the last layer's launches also run the coordinate MLP of the ligand nodes); 1e-4 parity gates"}
 
     if rank == 0:
         total_traj = world * B * args.steps
@@ -239,7 +264,14 @@ def main():
         achieved = flop_total / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
         peak = PEAK_MFMA16_TFLOPS if mfma16 else PEAK_F32_TFLOPS
         ctr, ctr_src = replayed_counters(args)
-        traffic = ctr["traffic_bytes_per_launch"] if ctr else None
+        n_full, n_lig = edge_launches - lig_launches, lig_launches
+        traffic = mfma_busy = valu_busy = None
+        if ctr:      # weight the two launch types by THIS run's mix (bytes: per launch; busy fractions: by active cycles)
+            ef, el = ctr["edge"]["full"], ctr["edge"].get("lig_only", ctr["edge"]["full"])
+            traffic = (n_full * ef["hbm_bytes"] + n_lig * el["hbm_bytes"]) / max(edge_launches, 1)
+            wf, wl = n_full * ef["active_cycles"], n_lig * el["active_cycles"]
+            mfma_busy = (wf * ef["mfma_busy"] + wl * el["mfma_busy"]) / max(wf + wl, 1)
+            valu_busy = (wf * ef["valu_busy"] + wl * el["valu_busy"]) / max(wf + wl, 1)
         out = {
             "metric": "docking trajectories/sec (N_res~300+300, 40 steps)",
             "value": total_traj / elapsed,
@@ -278,7 +310,11 @@ def main():
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
                          "flop_per_launch": flop_per_launch, "traffic": traffic, "traffic_source": ctr_src,
                          "traffic_gbps": (traffic / avg_launch_s / 1e9) if traffic else None,
-                         "mfma_busy": ctr.get("mfma_busy") if ctr else None, "valu_busy": ctr.get("valu_busy") if ctr else None,
+                         "mfma_busy": mfma_busy, "valu_busy": valu_busy,
+                         "launch_mix": {"full": int(n_full), "ligand_only": int(n_lig),
+                                        "avg_full_ms": (edge_ms - lig_ms) / max(n_full, 1), "avg_ligand_only_ms": lig_ms / max(n_lig, 1),
+                                        "traffic_full": ctr["edge"]["full"]["hbm_bytes"] if ctr else None,
+                                        "traffic_ligand_only": ctr["edge"].get("lig_only", {}).get("hbm_bytes") if ctr else None},
                          "rows_per_launch": edge_rows / max(edge_launches, 1),
                          "algorithmic_bytes_per_launch": 8 * H * edge_rows / K_DEG / max(edge_launches, 1),
                          "note": "achieved = B*N*(2*K*H*H + 2*K*H) FLOP / launch time from HIP events on the engine's stream, live; "
@@ -287,6 +323,22 @@ def main():
                                  "run, see traffic_source; algorithmic bytes per launch = 8*N*H per trajectory (SURVEY 8d)"},
             "best_energy": float(allrec[:, 2].min()),
         }
+        # whole path against the matrix peak in the reference's own currency: the dense formulation's FLOPs for the evaluations done
+        ref_flops = FLOP_PER_NODE_EVAL * (args.R + args.L) * (args.num_steps + 1) * total_traj
+        out["whole_path"] = {"reference_equivalent_tflops": ref_flops / elapsed / 1e12, "peak_tflops": peak,
+                             "frac": ref_flops / elapsed / 1e12 / peak,
+                             "note": "59.2 MFLOP per residue and score evaluation (SURVEY 8d: the reference's dense formulation, six full layers) x "
+                                     "residues x evaluations x trajectories / wall time; the engine executes less than that (layer-0 message "
+                                     "table, ligand-only last layer, one-hot -> gather) and three split-bf16 terms in the node GEMMs"}
+        if ctr:      # replayed per-kernel table (same PMC run as `roofline.traffic`): what bounds each kernel and how close it gets
+            out["kernels"] = {"source": ctr_src, "table": [
+                {"kernel": k, "avg_us": d.get("avg_us"), "percent_of_gpu_time": d.get("percent"), "bound": d.get("bound"), "frac": d.get("frac"),
+                 "hbm_tbps": d.get("hbm_tbps"), "hbm_MB": None if d.get("hbm_bytes") is None else d["hbm_bytes"] / 1e6,
+                 "mfma_busy": d.get("mfma_busy"), "valu_busy": d.get("valu_busy"), "issue_stalled": d.get("wait_frac")}
+                for k, d in sorted(ctr["kernels"].items(), key=lambda kv: -(kv[1].get("percent") or 0))],
+                "note": "bound hbm: frac = HBM TB/s / 8; valu: VALU-pipe busy (issue-bound kernel); l2 / mfma rows: see DESIGN section 5"}
+        if fp32_line:
+            out["fp32_engine"] = fp32_line
         if l0["l0_evals"]:      # layer 0 behind the message table: its launches are not part of `roofline` (HIP events, live)
             n = l0["l0_evals"]
             out["layer0_table"] = {"evaluations": int(n), "edge_model_fraction": l0["l0_miss_rows"] / max(l0["l0_edges"], 1),

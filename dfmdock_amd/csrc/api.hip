@@ -120,6 +120,7 @@ struct dfm_complex {
     Workspace ws;
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;      // profiling events (pairs)
+    std::vector<char> ev_lig;        // per pair: the launch covered the ligand nodes only
     size_t ev_used = 0;
     hipEvent_t ev_total[2] = {nullptr, nullptr};
     dfm_profile prof = {};
@@ -868,12 +869,15 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
                     cx->ev.push_back(a); cx->ev.push_back(b2);
                 }
                 e0 = cx->ev[cx->ev_used++]; e1 = cx->ev[cx->ev_used++];
+                if (cx->ev_lig.size() < cx->ev_used / 2) cx->ev_lig.resize(cx->ev_used / 2);
+                cx->ev_lig[cx->ev_used / 2 - 1] = ea.lig_only ? 1 : 0;
                 HIPCHK(hipEventRecord(e0, s));
             }
             if (o.bf16) HIPCHK(launch_edge_bf16(ea, s)); else HIPCHK(launch_edge_f32(ea, s));
             if (o.profile) {
                 HIPCHK(hipEventRecord(e1, s));
                 cx->prof.edge_kernel_launches += 1;
+                cx->prof.edge_lig_launches += ea.lig_only ? 1 : 0;
                 cx->prof.edge_rows += (int64_t)ea.B * (ea.lig_only ? N - R : N) * K;
             }
             return DFM_OK;
@@ -1005,6 +1009,7 @@ static int finish_profile(dfm_complex *cx)
     for (size_t i = 0; i + 1 < cx->ev_used; i += 2) {
         HIPCHK(hipEventElapsedTime(&ms, cx->ev[i], cx->ev[i + 1]));
         cx->prof.edge_kernel_ms += ms;
+        if (i / 2 < cx->ev_lig.size() && cx->ev_lig[i / 2]) cx->prof.edge_lig_ms += ms;
     }
     for (size_t i = 0; i + 2 < cx->ev_l0_used; i += 3) {
         HIPCHK(hipEventElapsedTime(&ms, cx->ev_l0[i], cx->ev_l0[i + 1]));

@@ -175,6 +175,8 @@ typedef struct {
     double l0_rows_ms;        /* summed HIP-event time of the row-list message launches                           */
     double l0_gather_ms;      /* ... of the gather-sum launches                                                  */
     double l0_build_ms;       /* table build of this call (0 when the table already existed)                      */
+    int64_t edge_lig_launches;/* of edge_kernel_launches: last-layer launches over the ligand nodes only          */
+    double edge_lig_ms;       /* their share of edge_kernel_ms                                                    */
 } dfm_profile;
 
 /* Output of dfm_complex_selfcheck: how far the 16-bit MFMA engine is from the fp32 engine (the reference's own arithmetic) on THIS

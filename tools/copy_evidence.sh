@@ -1,8 +1,7 @@
 #!/bin/bash
 # After tools/final_profile.sh (gpurun merges its outputs into gpurun_out/final): copy the summaries the docs cite into profiles/
-# under a round tag.   bash tools/copy_evidence.sh r03_e
+# under a round tag.   bash tools/copy_evidence.sh r04_e
 T=${1:?tag}; F=gpurun_out/final; cd "$(dirname "$0")/.."
-python3 tools/make_traffic_json.py $F > $F/traffic_summary.txt 2>&1
 tail -1 $F/bench.log > profiles/${T}_bench.json
 grep -h '^{"metric"' $F/bench_prof.log | tail -1 > profiles/${T}_bench_under_rocprof.json
 grep -h '^{"metric"' $F/c5.log | tail -1 > profiles/${T}_c5_bench_under_rocprof.json
@@ -10,9 +9,10 @@ cp $F/bench_prof_kernel_stats.csv profiles/${T}_kernel_stats.csv
 cp $F/c5_kernel_stats.csv profiles/${T}_c5_kernel_stats.csv
 cp $F/pair_kernel_stats.csv profiles/${T}_pair_kernel_stats.csv
 grep -v "rocprofv3\|^E20\|^W20" $F/pair.log | tail -6 > profiles/${T}_pair_family.txt
-for k in pmc_edge pmc_knn_c3 pmc_knn_c5; do cp $F/$k.txt profiles/${T}_$k.txt; done
+for k in pmc_all pmc_knn_c5; do cp $F/$k.txt profiles/${T}_$k.txt; done
 tail -4 $F/pytest_gpu.log > profiles/${T}_pytest_gpu.txt
 cp $F/size_sweep.txt profiles/${T}_size_sweep.txt
+cp $F/small_batches.txt profiles/${T}_small_batches.txt
 cp $F/traffic_summary.txt profiles/${T}_traffic_summary.txt
 cp $F/tol_report.txt profiles/${T%_*}_tol_report.txt
-cp $F/traffic.json profiles/${T%_*}_traffic.json      # the file bench.py replays into roofline.traffic / mfma_busy / valu_busy
+cp $F/traffic.json profiles/${T%_*}_traffic.json      # the file bench.py replays into roofline.traffic / mfma_busy / valu_busy / kernels

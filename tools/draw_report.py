@@ -18,7 +18,16 @@ from conftest import DRAWS, DRAW_CASES, complex_for, draw_blob, draw_golden, dra
 
 
 # engine selections: "mfma16" = the 16-bit MFMA engine as shipped (DFM_F_MFMA16: fp16 operands), "bf16ops" = + DFM_F_BF16_OPS
-KW = {"fp32": {}, "mfma16": dict(mfma16=True), "f16": dict(f16=True), "bf16ops": dict(mfma16=True, bf16_ops=True)}
+# "mfma16+tab" = ... with layer 0 through the per-complex message table (DFM_F_L0_TABLE; what dfm_sample runs by default)
+KW = {"fp32": {}, "mfma16": dict(mfma16=True), "f16": dict(f16=True), "bf16ops": dict(mfma16=True, bf16_ops=True),
+      "mfma16+tab": dict(mfma16=True, l0_table=True)}
+
+
+def sample_kw(prec):      # Complex.sample takes the table by default: the plain "mfma16" row switches it off
+    kw = dict(KW[prec])
+    if prec == "mfma16":
+        kw["l0_table"] = False
+    return kw
 
 
 def rel(a, b):
@@ -26,7 +35,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def main(fams=(0, 1), draws=("s0",) + tuple(DRAWS), precs=("fp32", "mfma16", "f16"), per_case=False):
+def main(fams=(0, 1), draws=("s0",) + tuple(DRAWS), precs=("fp32", "mfma16", "mfma16+tab", "f16"), per_case=False):
     from dfmdock_amd import engine
     from dfmdock_amd.weights import make_random_weights, pack_blob
     engine.set_device(0)
@@ -70,12 +79,12 @@ def main(fams=(0, 1), draws=("s0",) + tuple(DRAWS), precs=("fp32", "mfma16", "f1
             gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
             inj = dict(R0=g["R0"].astype(np.float32), tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"])
             for prec in worst:
-                r = gx.sample(B=1, num_steps=40, inject=inj, trace=True, **KW[prec])
+                r = gx.sample(B=1, num_steps=40, inject=inj, trace=True, **sample_kw(prec))
                 roll[prec] = float(np.sqrt(((r["trace_pose"][0][:, :, 1, :] - g["poses"][:, :, 1, :]) ** 2).sum(-1).mean(-1)).max())
             gx.close()
             for prec in worst:
                 w = worst[prec]
-                print(f"draw fam{fam} {draw} {prec:5s} f {w[0]:.2e} tr {w[1]:.2e} rot {w[2]:.2e} E {w[3]:.2e} rollout40 {roll[prec]:.2e} A"
+                print(f"draw fam{fam} {draw} {prec:10s} f {w[0]:.2e} tr {w[1]:.2e} rot {w[2]:.2e} E {w[3]:.2e} rollout40 {roll[prec]:.2e} A"
                       f"   worst cases: {wcase[prec][0]} / {wcase[prec][1]} / {wcase[prec][2]} / {wcase[prec][3]}")
             m.close()
     print()
@@ -85,7 +94,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--fam", default="0,1")
     ap.add_argument("--draws", default="s0," + ",".join(DRAWS))
-    ap.add_argument("--prec", default="fp32,bf16,f16")
+    ap.add_argument("--prec", default="fp32,mfma16,mfma16+tab,f16")
     ap.add_argument("--cases", action="store_true")
     a = ap.parse_args()
     main([int(x) for x in a.fam.split(",")], a.draws.split(","), a.prec.split(","), a.cases)

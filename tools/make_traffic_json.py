@@ -1,65 +1,117 @@
-"""From the counter passes of tools/final_profile.sh: the JSON bench.py replays into `roofline` (HBM bytes per launch of the dominant
-kernel, pipe-busy fractions) and the roofline lines of k_knn_sample at C3 / C5.  Counter conventions (MI355X_MICROARCH.md): FETCH_SIZE /
-WRITE_SIZE in KiB, FETCH_SIZE x 2 on gfx950 for wide coalesced reads; SQ_* are summed over the chip (1024 SIMDs, 256 CUs);
-GRBM_GUI_ACTIVE counts per shader engine: / 8 = active cycles of the launch."""
+"""From the counter passes of tools/final_profile.sh: the JSON bench.py replays into `roofline` and `kernels` (profiles/r04_traffic.json).
+
+  edge.full / edge.lig_only   HBM bytes and pipe-busy fractions of ONE launch of the message kernel k_edge_msg<1,1,0>, separately for a
+                              full launch (all nodes) and a last-layer launch over the ligand nodes only - bench.py weights them by the
+                              launch mix it measures itself (one replayed number divided by two different mixes)
+  kernels.<name>              per kernel: launches seen, active cycles, HBM bytes, busy fractions, its bound and the fraction reached
+
+Counter conventions (MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE x 2 on gfx950 for wide coalesced reads; SQ_* summed
+over the chip (1024 SIMDs, 256 CUs); GRBM_GUI_ACTIVE counts per shader engine: / 8 = active cycles of the launch.  Dispatches of the
+message kernel are classified by position: the passes run bench.py --num-steps 3 with the layer-0 table, i.e. three step evaluations of
+[layers 1-4 full, layer 5 ligand-only] and a final evaluation of five full launches.
+
+    python tools/make_traffic_json.py <dir with pmc_all/ and bench_prof_kernel_stats.csv>
+"""
 import collections, csv, glob, json, os, sys
 
 out = sys.argv[1]
+STEPS = int(os.environ.get("PMC_NUM_STEPS", "3"))
+HBM_PEAK, HBM_ACH, MFMA_PEAK = 8.0e12, 6.3e12, 2.5e15
+N, H, B, K, L = 600, 256, 256, 60, 300
 
 
-def means(d):
-    acc = collections.defaultdict(list)
+def per_pass_means(d, keep):
+    """{kernel: {counter: mean over the kept dispatches}}; dispatch ids differ between passes, so dispatches are ranked per pass"""
+    res = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in sorted(glob.glob(os.path.join(out, d, "*counter_collection.csv"))):
+        rows = collections.defaultdict(lambda: collections.defaultdict(dict))
         for row in csv.DictReader(open(f)):
-            acc[(row.get("Kernel_Name", ""), row["Counter_Name"])].append(float(row["Counter_Value"]))
-    by_kernel = collections.defaultdict(dict)
-    for (k, c), v in acc.items():
-        by_kernel[k][c] = (sum(v) / len(v), len(v))
-    return by_kernel
+            rows[row.get("Kernel_Name", "")][int(row.get("Dispatch_Id", 0))][row["Counter_Name"]] = float(row["Counter_Value"])
+        for k, disp in rows.items():
+            ids = sorted(disp)
+            for rank, i in enumerate(ids):
+                if keep(k, rank, len(ids)):
+                    for c, v in disp[i].items():
+                        res[k][c].append(v)
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in cs.items()} for k, cs in res.items()}
 
 
 def derived(c):
     g = lambda n: c.get(n, (float("nan"), 0))[0]
     cyc = g("GRBM_GUI_ACTIVE") / 8.0
-    return {"launches": c.get("GRBM_GUI_ACTIVE", (0, 0))[1], "active_cycles": cyc,
-            "hbm_bytes": (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0, "fetch_KiB": g("FETCH_SIZE"), "write_KiB": g("WRITE_SIZE"),
-            "mfma_busy": g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0 / cyc, "valu_busy": g("SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / cyc,
-            "lds_busy": g("SQ_LDS_IDX_ACTIVE") / 256.0 / cyc, "wait_frac": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
-            "insts_valu": g("SQ_INSTS_VALU"), "insts_vmem_rd": g("SQ_INSTS_VMEM_RD"),
-            "l2_hit": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))}
+    d = {"launches": c.get("GRBM_GUI_ACTIVE", (0, 0))[1], "active_cycles": cyc,
+         "hbm_bytes": (2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0, "fetch_KiB": g("FETCH_SIZE"), "write_KiB": g("WRITE_SIZE"),
+         "mfma_busy": g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0 / cyc, "valu_busy": g("SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / cyc,
+         "lds_busy": g("SQ_LDS_IDX_ACTIVE") / 256.0 / cyc, "wait_frac": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
+         "parked_frac": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"),
+         "insts_valu": g("SQ_INSTS_VALU"), "l2_hit": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))}
+    return {k: (None if isinstance(v, float) and v != v else v) for k, v in d.items()}
 
 
-edge = means("pmc_edge")
-res = {}
-for k, c in edge.items():
-    res[k] = derived(c)
-    d = res[k]
-    print(f"{k[:60]:60s} launches {d['launches']:3d}: HBM {d['hbm_bytes'] / 1e9:.3f} GB/launch (FETCH {d['fetch_KiB']:.0f} KiB x2 + WRITE {d['write_KiB']:.0f} KiB), "
-          f"{d['active_cycles'] / 1e6:.2f} M cycles, MFMA busy {d['mfma_busy']:.3f}, VALU busy {d['valu_busy']:.3f}, LDS {d['lds_busy']:.3f}, "
-          f"waiting {d['wait_frac']:.3f}, VALU insts {d['insts_valu'] / 1e6:.0f} M, L2 hit {d['l2_hit']:.3f}")
-if res:
-    N, H, B = 600, 256, 256
-    # the counter passes run bench.py --num-steps 3: E = 4 evaluations of six launches; in the E - 1 step evaluations the last layer's
-    # launch covers the ligand nodes only (half the rows at 300+300), so the launch-weighted algorithmic bytes are below 8 N H B
-    E = 4
-    alg = 8 * N * H * B * (6 * E - 0.5 * (E - 1)) / (6 * E)
-    tot = sum(d["hbm_bytes"] * d["launches"] for d in res.values()) / sum(d["launches"] for d in res.values())
-    w = lambda key: sum(d[key] * d["launches"] for d in res.values()) / sum(d["launches"] for d in res.values())
-    js = {"kernel": " / ".join(sorted(res)), "config": {"R": 300, "L": 300, "batch": 256, "precision": "mfma16"},
-          "source": "tools/final_profile.sh on MI355X: rocprofv3 --pmc, one counter set per run, kernel-filtered, no trace domains; "
-                    "FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE; busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs and "
-                    "SQ_ACTIVE_INST_VALU x 4 / 1024 over GRBM_GUI_ACTIVE / 8",
-          "per_kernel": res, "traffic_bytes_per_launch": tot, "algorithmic_bytes_per_launch": alg,
-          "mfma_busy": w("mfma_busy"), "valu_busy": w("valu_busy"), "wait_frac": w("wait_frac")}
-    json.dump(js, open(os.path.join(out, "traffic.json"), "w"), indent=1)
-    print(f"-> traffic.json: {tot / 1e9:.3f} GB per launch (launch-weighted over the six layers) = {tot / alg:.2f} x algorithmic ({alg / 1e6:.1f} MB: 8 N H B per full launch, half of it for a ligand-only last layer); "
-          f"MFMA busy {js['mfma_busy']:.3f}, VALU busy {js['valu_busy']:.3f}")
-# k_knn_sample: a VALU-issue-bound kernel.  Roofline line = VALU-pipe busy fraction (instructions x measured issue cost over the
-# launch's SIMD cycles) next to its HBM figure, which is tiny (16 N + 4 N K bytes per trajectory)
-for tag, (N, B) in (("pmc_knn_c3", (600, 256)), ("pmc_knn_c5", (2000, 32))):
-    for k, c in means(tag).items():
+def is_msg(k):
+    return "k_edge_msg<1, 1, 0>" in k
+
+
+def lig_rank(rank, n):
+    per = 5      # message launches of k_edge_msg<1,1,0> per evaluation behind the layer-0 table
+    return rank < per * STEPS and rank % per == per - 1
+
+
+full = per_pass_means("pmc_all", lambda k, r, n: is_msg(k) and not lig_rank(r, n))
+lig = per_pass_means("pmc_all", lambda k, r, n: is_msg(k) and lig_rank(r, n))
+others = per_pass_means("pmc_all", lambda k, r, n: not is_msg(k))
+
+stats = {}
+sf = os.path.join(out, "bench_prof_kernel_stats.csv")
+if os.path.exists(sf):
+    for r in csv.DictReader(open(sf)):
+        stats[r["Name"]] = {"avg_us": float(r["AverageNs"]) / 1e3, "calls": int(r["Calls"]), "percent": float(r["Percentage"])}
+
+
+def stat_of(k):
+    for name, v in stats.items():
+        if name[:60] == k[:60] or name.startswith(k[:50]):
+            return v
+    return None
+
+
+js = {"config": {"R": 300, "L": 300, "batch": B, "precision": "mfma16", "layer0_table": True, "num_steps_of_the_passes": STEPS},
+      "source": "tools/final_profile.sh on MI355X: rocprofv3 --pmc, one counter set per run, kernel-filtered, no trace domains; FETCH_SIZE x 2 "
+                "(gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE; busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs and SQ_ACTIVE_INST_VALU x 4 / 1024 "
+                "over GRBM_GUI_ACTIVE / 8; durations / shares from rocprofv3 --kernel-trace --stats of the default bench command",
+      "edge": {}, "kernels": {}}
+for tag, m, nodes in (("full", full, N), ("lig_only", lig, L)):
+    for k, c in m.items():
         d = derived(c)
-        alg = (16 * N + 4 * N * 60) * B
-        print(f"{tag} {k[:40]:40s} launches {d['launches']}: {d['active_cycles'] / 1e3:.0f} k cycles per launch, VALU insts {d['insts_valu'] / 1e6:.1f} M "
-              f"({d['insts_valu'] / (B * N):.0f} per node), VALU busy {d['valu_busy']:.3f} (= roofline fraction of the VALU issue bound), waiting {d['wait_frac']:.3f}, "
-              f"HBM {d['hbm_bytes'] / 1e6:.1f} MB per launch vs {alg / 1e6:.1f} MB algorithmic, pairwise distances {B * N * N / 1e6:.0f} M per launch")
+        d["algorithmic_bytes"] = 8 * nodes * H * B      # 8 N H per trajectory and launch
+        d["flop"] = B * nodes * (2 * K * H * H + 2 * K * H)
+        js["edge"][tag] = d
+        print(f"k_edge_msg<1,1,0> {tag:8s}: {d['launches']:3d} launches, HBM {d['hbm_bytes'] / 1e9:.3f} GB (FETCH {d['fetch_KiB']:.0f} KiB x 2 + WRITE {d['write_KiB']:.0f} KiB) = "
+              f"{d['hbm_bytes'] / d['algorithmic_bytes']:.2f} x algorithmic {d['algorithmic_bytes'] / 1e6:.0f} MB; {d['active_cycles'] / 1e6:.2f} M cycles; MFMA busy {d['mfma_busy']:.3f} "
+              f"VALU busy {d['valu_busy']:.3f} LDS {d['lds_busy']:.3f} issue-stalled {d['wait_frac']:.3f} parked {d['parked_frac']:.3f} L2 hit {d['l2_hit']:.3f}")
+
+BOUNDS = {      # kernel -> (bound, how the fraction is formed)
+    "k_gemm_split": "hbm", "k_edge_coord": "hbm", "k_l0_gather": "l2", "k_knn_sample": "valu", "k_edge_msg<1, 1, 1>": "mfma", "k_edge_feat": "hbm"}
+for k, c in sorted(others.items()):
+    d = derived(c)
+    st = stat_of(k)
+    if st:
+        d.update(st)
+    bound = next((b for key, b in BOUNDS.items() if key in k), None)
+    d["bound"] = bound
+    if st and d["hbm_bytes"] is not None:
+        d["hbm_tbps"] = d["hbm_bytes"] / (st["avg_us"] * 1e-6) / 1e12
+        if bound == "hbm":
+            d["frac"] = d["hbm_tbps"] * 1e12 / HBM_PEAK
+    if bound == "valu":
+        d["frac"] = d["valu_busy"]
+    js["kernels"][k[:70]] = d
+    print(f"{k[:58]:58s} {d['launches']:4d} launches" + (f" avg {st['avg_us']:8.1f} us {st['percent']:5.2f} %" if st else "") +
+          f": HBM {0 if d['hbm_bytes'] is None else d['hbm_bytes'] / 1e6:8.1f} MB" + (f" = {d['hbm_tbps']:.2f} TB/s" if "hbm_tbps" in d else "") +
+          f", MFMA {d['mfma_busy'] or 0:.3f} VALU {d['valu_busy'] or 0:.3f} LDS {d['lds_busy'] or 0:.3f} issue-stalled {d['wait_frac'] or 0:.3f}" +
+          (f" -> {bound} fraction {d['frac']:.3f}" if "frac" in d else ""))
+for k, st in stats.items():
+    if is_msg(k):
+        js["edge"]["stats"] = st
+json.dump(js, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+print("-> traffic.json")
