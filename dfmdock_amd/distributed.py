@@ -12,6 +12,11 @@ group (TCP on the loopback) is the control plane, the RCCL group is probed with 
 gather only if EVERY rank's probe succeeded; otherwise the gather runs over gloo, and with no torch.distributed rendezvous at
 all (independent replicas started with RANK / WORLD_SIZE / DFM_GATHER_DIR) over files - SURVEY.md 8(e)'s last row.  What was
 actually used is returned and ends up in bench.py's JSON line.
+
+DFM_DIST_BACKEND=rccl selects the torch-free path instead: librccl through ctypes (dfmdock_amd/rccl.py) for the gather AND the few
+control-plane exchanges, the communicator's unique id handed over through DFM_GATHER_DIR or a TCP socket at MASTER_PORT + 1
+(DFM_RCCL_PORT).  It is an opt-in: it cannot probe-and-fall-back the way the default chain does, and it has only ever run with one
+rank on the one-GPU boxes this was built on (tests/test_gpu_multiproc.py).
 """
 from __future__ import annotations
 
@@ -29,8 +34,8 @@ def dist_env():
 
 
 class Group:
-    """What init() settled on: `backend` in {"single", "nccl", "gloo", "file"}, the group handle the record gather uses, the
-    reason a preferred backend was not used (or None)."""
+    """What init() settled on: `backend` in {"single", "nccl", "gloo", "file", "rccl"}, the group handle the record gather uses
+    (a torch process group, or the dfmdock_amd.rccl.Rccl communicator), the reason a preferred backend was not used (or None)."""
 
     def __init__(self, backend, rank=0, world=1, data_group=None, fallback_reason=None, gather_dir=None):
         self.backend, self.rank, self.world = backend, rank, world
@@ -80,6 +85,21 @@ def _init(device_index, prefer, timeout_s) -> Group:
         _group = Group("single")
         return _group
     gather_dir = os.environ.get("DFM_GATHER_DIR")
+    if prefer == "rccl":      # librccl directly, no torch.distributed (opt-in; failures are raised, not papered over)
+        from . import rccl
+        if gather_dir:
+            os.makedirs(gather_dir, exist_ok=True)
+            token = "j" + "".join(ch if ch.isalnum() else "-" for ch in os.environ.get("DFM_JOB_ID", os.environ.get("MASTER_PORT", "0")))
+            exch = lambda uid: rccl.exchange_uid_file(uid, rank, world, gather_dir, token, timeout_s)
+        elif "MASTER_PORT" in os.environ:
+            port = int(os.environ.get("DFM_RCCL_PORT", int(os.environ["MASTER_PORT"]) + 1))
+            exch = lambda uid: rccl.exchange_uid_tcp(uid, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port, timeout_s)
+        else:
+            raise RuntimeError("DFM_DIST_BACKEND=rccl needs DFM_GATHER_DIR or MASTER_ADDR / MASTER_PORT to hand the unique id over")
+        comm = rccl.Rccl(rank, world, device_index if device_index is not None else int(os.environ.get("LOCAL_RANK", 0)), exch)
+        comm.barrier()
+        _group = Group("rccl", rank, world, data_group=comm)
+        return _group
     if prefer == "file" or "MASTER_PORT" not in os.environ:
         if not gather_dir:
             raise RuntimeError("WORLD_SIZE > 1 without a torch.distributed rendezvous needs DFM_GATHER_DIR for the file gather")
@@ -130,6 +150,13 @@ def _init(device_index, prefer, timeout_s) -> Group:
 
 def shutdown():
     global _group
+    if _group.backend == "rccl":
+        try:
+            _group.data_group.barrier()
+            _group.data_group.close()
+        finally:
+            _group = Group("single")
+        return
     if _group.backend == "file" and _group._token:
         # a closing round (nobody may still be reading this rank's last block when it goes); the closing round's own small file
         # stays behind under the job's token and is swept by the next job's rank of the same number
@@ -288,6 +315,9 @@ def gather_records(records: np.ndarray, device=None, force_collective: bool = Fa
     g = _group
     if g.backend == "file":
         return _file_gather(records, g)
+    if g.backend == "rccl":
+        blocks = g.data_group.all_gather_var(np.ascontiguousarray(records, np.float32).tobytes())
+        return np.concatenate([np.frombuffer(b, np.float32).reshape(-1, RECORD_WIDTH) for b in blocks], 0)
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
@@ -314,6 +344,8 @@ def allgather_scalars(values) -> np.ndarray:
     g = _group
     if g.backend == "single":
         return v[None]
+    if g.backend == "rccl":
+        return np.stack([np.frombuffer(b, np.float64) for b in g.data_group.all_gather_bytes(v.tobytes())])
     if g.backend == "file":
         assert v.size <= RECORD_WIDTH // 2
         rec = np.zeros((1, RECORD_WIDTH), np.float32)
@@ -336,6 +368,9 @@ def allreduce_max(value: float) -> float:
 def gather_objects(obj):
     """[obj of rank 0, obj of rank 1, ...] on every rank (small host objects: the CSV rows of driver.run_set)."""
     g = _group
+    if g.backend == "rccl":
+        import json
+        return [json.loads(b.decode()) for b in g.data_group.all_gather_var(json.dumps(obj, default=float).encode())]
     if g.backend == "file":
         import json
 
@@ -361,6 +396,9 @@ def barrier():
         return
     if g.backend == "file":
         _file_gather(np.zeros((0, RECORD_WIDTH), np.float32), g)
+        return
+    if g.backend == "rccl":
+        g.data_group.barrier()
         return
     import torch.distributed as dist
     dist.barrier()

@@ -161,3 +161,31 @@ def test_rccl_one_rank_record_gather():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port() + 301), HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0 and "RCCL_OK" in p.stdout.decode(), p.stderr.decode()[-3000:]
+
+
+def test_rccl_direct_one_rank_without_torch():
+    """The torch-free collective path (dfmdock_amd/rccl.py, DFM_DIST_BACKEND=rccl): librccl through ctypes builds a communicator on
+    the MI355X and runs the record gather, the timing exchange, the object gather and a barrier as byte all_gathers - in a process
+    that never imports torch."""
+    code = textwrap.dedent("""
+        import sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        from dfmdock_amd import distributed as D, rccl
+        comm = rccl.Rccl(0, 1, 0, lambda uid: uid)
+        D._group = D.Group("rccl", 0, 1, data_group=comm)
+        rec = np.arange(7 * D.RECORD_WIDTH, dtype=np.float32).reshape(7, D.RECORD_WIDTH)
+        out = D.gather_records(rec)
+        assert out.shape == rec.shape and (out == rec).all()
+        assert D.gather_records(rec[:0]).shape == (0, D.RECORD_WIDTH)
+        t = D.allgather_scalars([1.25, 3.0])
+        assert t.shape == (1, 2) and t[0, 0] == 1.25 and D.allreduce_max(2.5) == 2.5
+        assert D.gather_objects({"rows": [["1AVX", "0", -0.5]]}) == [{"rows": [["1AVX", "0", -0.5]]}]
+        D.barrier()
+        D.shutdown()
+        assert "torch" not in sys.modules, "the rccl path must not need torch"
+        print("RCCL_DIRECT_OK")
+    """ % ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and "RCCL_DIRECT_OK" in p.stdout.decode(), p.stderr.decode()[-3000:]

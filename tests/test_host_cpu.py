@@ -308,3 +308,36 @@ def test_dfmdock_wrapper_helpers_match_reference():
     DFMDock.move_to_lig_center(b)
     assert np.abs(b["rec_pos"] - g["centred_rec"]).max() < 1e-5 and np.abs(b["lig_pos"] - g["centred_lig"]).max() < 1e-5
 
+
+
+def test_rccl_unique_id_handover_tcp_and_file(tmp_path):
+    """dfmdock_amd/rccl.py: the 128-byte communicator id travels from rank 0 to the other ranks over a TCP socket (torchrun-style
+    launches: MASTER_ADDR / MASTER_PORT + 1) or a file in DFM_GATHER_DIR; late joiners retry until rank 0 is up."""
+    import socket, threading, time
+    from dfmdock_amd import rccl
+    uid = bytes(range(128))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    got = {}
+
+    def client(r, delay):
+        time.sleep(delay)
+        got[r] = rccl.exchange_uid_tcp(None, r, 3, "127.0.0.1", port, timeout_s=30)
+
+    th = [threading.Thread(target=client, args=(1, 0.0)), threading.Thread(target=client, args=(2, 0.3))]
+    for t in th:
+        t.start()
+    time.sleep(0.2)                                    # rank 1 is already knocking when rank 0 starts to listen
+    assert rccl.exchange_uid_tcp(uid, 0, 3, "127.0.0.1", port, timeout_s=30) == uid
+    for t in th:
+        t.join(30)
+    assert got == {1: uid, 2: uid}
+    d = str(tmp_path / "g"); os.makedirs(d)
+    res = {}
+    t = threading.Thread(target=lambda: res.update(r1=rccl.exchange_uid_file(None, 1, 2, d, "jx", timeout_s=30)))
+    t.start()
+    time.sleep(0.1)
+    assert rccl.exchange_uid_file(uid, 0, 2, d, "jx") == uid
+    t.join(30)
+    assert res["r1"] == uid
+    with pytest.raises(TimeoutError):
+        rccl.exchange_uid_file(None, 1, 2, d, "other-job", timeout_s=0.2)

@@ -91,7 +91,7 @@ for tag, m, nodes in (("full", full, N), ("lig_only", lig, L)):
               f"VALU busy {d['valu_busy']:.3f} LDS {d['lds_busy']:.3f} issue-stalled {d['wait_frac']:.3f} parked {d['parked_frac']:.3f} L2 hit {d['l2_hit']:.3f}")
 
 BOUNDS = {      # kernel -> (bound, how the fraction is formed)
-    "k_gemm_split": "hbm", "k_edge_coord": "hbm", "k_l0_gather": "l2", "k_knn_sample": "valu", "k_edge_msg<1, 1, 1>": "mfma", "k_edge_feat": "hbm"}
+    "k_gemm_split": "hbm", "k_edge_coord": "hbm", "k_l0_gather": "l2", "k_knn_sample": "valu", "k_edge_msg<1, 1, 1>": "mfma", "k_edge_feat": "valu", "k_heads": "latency"}
 for k, c in sorted(others.items()):
     d = derived(c)
     st = stat_of(k)
