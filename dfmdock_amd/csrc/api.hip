@@ -1354,8 +1354,11 @@ extern "C" int dfm_complex_selfcheck(dfm_complex *cx, int n_eval, const float *t
     if (n_eval < 1 || n_eval > 16) return fail(DFM_E_INVALID, "n_eval must be in 1..16");
     DEVICE_SCOPE(cx->device);
     const int B = n_eval;
-    int rc = ensure_workspace(cx, B, true);
+    // the 16-bit pass runs the engine as dfm_sample runs it: layer 0 through the message table where the complex is eligible
+    const bool l0 = !(flags & (DFM_F_F16 | DFM_F_BF16_OPS | DFM_F_NO_L0_TABLE)) && l0_eligible(cx, B);
+    int rc = ensure_workspace(cx, B, true, l0);
     if (rc) return rc;
+    if (l0 && !cx->l0_valid && (rc = build_l0_table(cx, nullptr)) != DFM_OK) return rc;
     Workspace &W = cx->ws;
     hipStream_t s = cx->stream;
     const dfm_model *m = cx->m;
@@ -1385,8 +1388,11 @@ extern "C" int dfm_complex_selfcheck(dfm_complex *cx, int n_eval, const float *t
         FwdOpts o;
         o.bf16 = mfma; o.f16 = mfma && (flags & DFM_F_F16); o.bf16_ops = mfma && !o.f16 && (flags & DFM_F_BF16_OPS);
         o.want_energy = true; o.need_node_out = true; o.seed = seed;
-        if (mfma) { o.edges_dev = edges_d; o.edges_pitch = (int64_t)N * K; o.sat = sat_d; }
-        else o.range = range_d;
+        if (mfma) {
+            o.edges_dev = edges_d; o.edges_pitch = (int64_t)N * K; o.sat = sat_d; o.l0_table = l0;
+            if (l0)      // the table's own entries (S * gate * m as fp16) are clamped like every other 16-bit store: count them too
+                HIPCHK(launch_sat_count(cx->l0_table, (long long)((size_t)cx->R * cx->R + (size_t)cx->L * cx->L) * H, sat_d, s));
+        } else o.range = range_d;
         int rc2 = enqueue_forward(cx, B, o);
         if (rc2) return rc2;
         HeadArgs ha;

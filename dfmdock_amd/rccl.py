@@ -109,7 +109,7 @@ class Rccl:
         uid = _UniqueId()
         if rank == 0:
             self._nccl(self.nccl.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        raw = exchange(bytes(uid.internal) if rank == 0 else None)
+        raw = exchange(C.string_at(C.byref(uid), NCCL_UNIQUE_ID_BYTES) if rank == 0 else None)      # (c_char arrays stop at a NUL)
         if len(raw) != NCCL_UNIQUE_ID_BYTES:
             raise RuntimeError(f"rccl unique id has {len(raw)} bytes")
         C.memmove(C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)

@@ -47,7 +47,8 @@ def test_selfcheck_reports_the_engines_own_numbers(family):
         # the same three graphs: evaluation 0 of a call with this seed draws them again
         poses = np.repeat(cx["lig_pos"][None], 3, 0)
         a = gx.score(poses, ts, seed=11, energy=True, debug=True)
-        b = gx.score(poses, ts, edges=a["edges"], energy=True, **engine.precision_kwargs(prec))
+        # (the 16-bit pass of the check is the engine as dfm_sample runs it: layer 0 through the message table for "mfma16")
+        b = gx.score(poses, ts, edges=a["edges"], energy=True, l0_table=prec == "mfma16", **engine.precision_kwargs(prec))
         assert r["dev_f"] == pytest.approx(max(rel_inf(b["f"][k], a["f"][k]) for k in range(3)), rel=1e-5)
         assert r["dev_tr_score"] == pytest.approx(max(rel_inf(b["tr_score"][k], a["tr_score"][k]) for k in range(3)), rel=1e-5)
         assert r["dev_rot_score"] == pytest.approx(max(rel_inf(b["rot_score"][k], a["rot_score"][k]) for k in range(3)), rel=1e-5)
