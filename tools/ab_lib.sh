@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 for lib in ${LIBS:-libdfmdock_amd libdfm_r01 libdfmdock_amd libdfm_r01}; do
 export DFM_LIB=$GRAFT_REPO_ROOT/dfmdock_amd/$lib.so
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$lib -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline ${BENCH_ARGS} > /tmp/b_$lib.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$lib -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fp32-line ${BENCH_ARGS} > /tmp/b_$lib.log 2>&1
 f=$(find /tmp/prof_$lib -name "*kernel_stats.csv" | head -1)
 echo "== $lib: $(grep -o '"value": [0-9.]*' /tmp/b_$lib.log)"
 python - "$f" <<'PY'
