@@ -754,6 +754,7 @@ extern "C" const char *dfm_config_string(void)
 struct FwdOpts {
     bool bf16 = false, f16 = false, want_energy = false, profile = false;   // bf16: 16-bit MFMA engine; f16: ... with fp32 A_i
     bool bf16_ops = false;                // bf16 MFMA operands in every layer but the last (DFM_F_BF16_OPS)
+    bool pose_prepared = false;           // ws.pos / ca4 / cb4 already hold this evaluation's pose (written by the previous step's k_heads)
     uint32_t *ctl = nullptr;              // replayed step graph: device {evaluation index, seed} block (ws.step_ctl) instead of by-value seed / stream id
     bool l0_table = false;                // layer 0 through the complex's message table (cx->l0_valid, workspace l0 buffers allocated)
     bool need_node_out = true;            // false: nobody reads the final node features (no energy / ires / debug tap) - the last layer then
@@ -809,7 +810,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
     const uint32_t stream_id = cx->fwd_counter++;
 
     const bool pair_family = m->hp.family == 1;
-    HIPCHK(launch_prep_pose(cx->rec_pos, W.lig_cur, B, R, L, pair_family ? 1 : 0, W.pos, W.ca4, W.cb4, s));
+    if (!o.pose_prepared) HIPCHK(launch_prep_pose(cx->rec_pos, W.lig_cur, B, R, L, pair_family ? 1 : 0, W.pos, W.ca4, W.cb4, s));
     if (o.edges_dev) {
         HIPCHK(hipMemcpy2DAsync(W.edges, (size_t)N * K * 4, o.edges_dev, (size_t)o.edges_pitch * 4, (size_t)N * K * 4, B,
                                 hipMemcpyDeviceToDevice, s));
@@ -1261,6 +1262,9 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     // kernels with the same arguments as the plain path - bitwise the same trajectories (tests/test_gpu_graph.py).
     static const bool graph_env_on = [] { const char *e = getenv("DFM_GRAPH"); return e && atoi(e) != 0; }();
     const bool use_graph = (graph_env_on || (flags & DFM_F_GRAPH)) && !(flags & (DFM_F_PROFILE | DFM_F_STEP_ENERGY)) && !inj && !tp_d && !tsc_d;
+    // the pose a step produces is prepared for the next evaluation by that step's k_heads (one dependent launch less per step) unless
+    // something still moves it afterwards (clash force) or the step is a captured graph (whose first launch is the preparation)
+    const bool fuse_prep = !use_graph && !(flags & DFM_F_CLASH_FORCE);
     if (use_graph) {
         std::vector<StepParams> sp(S);
         for (int i = 0; i < num_steps; ++i) {
@@ -1304,10 +1308,12 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     for (int i = 0; i < num_steps; ++i) {
         o.edges_dev = ed_d ? ed_d + (size_t)i * N * K : nullptr;
         o.want_energy = step_energy; o.need_node_out = step_energy;
+        o.pose_prepared = fuse_prep && i > 0;
         rc = enqueue_forward(cx, B, o);
         if (rc) return rc;
         HeadArgs ha;
         step_head_args(i, ha);
+        if (fuse_prep) { ha.prep_next = 1; ha.rec_pos = cx->rec_pos; ha.prep_pos = W.pos; ha.prep_ca4 = W.ca4; ha.prep_cb4 = W.cb4; }
         HIPCHK(launch_heads(ha, s));
         if (flags & DFM_F_CLASH_FORCE) {   // inference_base.py:458-461
             HIPCHK(launch_clash_force(cx->rec_pos, B, cx->R, cx->L, W.lig_cur, W.tr_update, s));
@@ -1317,7 +1323,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     }
     // final evaluation of the last pose, with the energy head (inference_base.py:463-466); same t as the last step
     o.edges_dev = ed_d ? ed_d + (size_t)num_steps * N * K : nullptr;
-    o.want_energy = true; o.need_node_out = true;
+    o.want_energy = true; o.need_node_out = true; o.pose_prepared = fuse_prep;
     rc = enqueue_forward(cx, B, o);
     if (rc) return rc;
     {

@@ -137,6 +137,53 @@ __device__ inline double block_sum_d(double v, double *scratch)
     return t;
 }
 
+// ---- pose preparation of ONE trajectory by one 256-thread workgroup: centre receptor + ligand on the ligand centroid
+// (score_net_mlsb.py:353-359; all backbone atoms for the second family, DFMDock.py:254-257), build the CA and virtual-CB arrays
+// (coords6d.py:71-75).  Used by k_prep_pose and - for the pose a step has just produced - by k_heads.  scratch: double[8], center: float[3]
+__device__ inline void prep_pose_block(const float *__restrict__ rec_pos, const float *__restrict__ lig, int R, int L, int all_atoms,
+                                       float *__restrict__ P, float4 *__restrict__ ca4, float4 *__restrict__ cb4, double *scratch, float *center)
+{
+    const int N = R + L;
+    double s0 = 0, s1 = 0, s2 = 0;
+    if (all_atoms) {
+        for (int q = threadIdx.x; q < L * 3; q += blockDim.x) { s0 += lig[q * 3]; s1 += lig[q * 3 + 1]; s2 += lig[q * 3 + 2]; }
+    } else {
+        for (int q = threadIdx.x; q < L; q += blockDim.x) { s0 += lig[q * 9 + 3]; s1 += lig[q * 9 + 4]; s2 += lig[q * 9 + 5]; }
+    }
+    s0 = block_sum_d(s0, scratch);
+    s1 = block_sum_d(s1, scratch);
+    s2 = block_sum_d(s2, scratch);
+    if (threadIdx.x == 0) {
+        const int cnt = all_atoms ? L * 3 : L;
+        center[0] = (float)(s0 / cnt); center[1] = (float)(s1 / cnt); center[2] = (float)(s2 / cnt);
+    }
+    __syncthreads();
+    const float cx = center[0], cy = center[1], cz = center[2];
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const float *src = i < R ? rec_pos + (size_t)i * 9 : lig + (size_t)(i - R) * 9;
+        float v[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            v[a * 3 + 0] = src[a * 3 + 0] - cx;
+            v[a * 3 + 1] = src[a * 3 + 1] - cy;
+            v[a * 3 + 2] = src[a * 3 + 2] - cz;
+        }
+#pragma unroll
+        for (int a = 0; a < 9; ++a) P[(size_t)i * 9 + a] = v[a];
+        // Cb = -0.58273431*a + 0.56802827*b - 0.54067466*c + Ca ;  b = Ca - N, c = C - Ca, a = b x c
+        const float bx = v[3] - v[0], by = v[4] - v[1], bz = v[5] - v[2];
+        const float cx_ = v[6] - v[3], cy_ = v[7] - v[4], cz_ = v[8] - v[5];
+        const float ax = by * cz_ - bz * cy_, ay = bz * cx_ - bx * cz_, az = bx * cy_ - by * cx_;
+        float4 cb;
+        cb.x = ((-0.58273431f * ax + 0.56802827f * bx) - 0.54067466f * cx_) + v[3];
+        cb.y = ((-0.58273431f * ay + 0.56802827f * by) - 0.54067466f * cy_) + v[4];
+        cb.z = ((-0.58273431f * az + 0.56802827f * bz) - 0.54067466f * cz_) + v[5];
+        cb.w = 0.f;
+        ca4[i] = make_float4(v[3], v[4], v[5], 0.f);
+        cb4[i] = cb;
+    }
+}
+
 // ---- SO(3) maps, float32, same operation order as the reference (src/utils/geometry.py) --------------
 __device__ inline void aa_to_quat(const float aa[3], float q[4])
 {   // geometry.py:154-183

@@ -282,6 +282,12 @@ struct HeadArgs {
     // its time embedding hid_base + (ctl[0] - 1) * 256 (the by-value fields above are then ignored)
     const StepParams *step_params;
     const uint32_t *ctl;
+    // prep_next: k_heads also prepares the pose it has just produced for the next evaluation (pos / ca4 / cb4 of its trajectory,
+    // exactly what launch_prep_pose would write as that evaluation's first launch)
+    int prep_next;
+    const float *rec_pos;
+    float *prep_pos;
+    float4 *prep_ca4, *prep_cb4;
 };
 hipError_t launch_heads(const HeadArgs &a, hipStream_t s);
 // base[n][2][128] for the n times t_dev[n] (kernels_heads.hip: k_time_embed)

@@ -799,8 +799,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         if (blockIdx.x >= n_row_tiles) return;      // tasks go wave-major (wave w of workgroup g starts at tile w * grid + g): nothing for this
                                                     // workgroup - leave before the 128 KiB weight fill (the launch is sized for the capacity)
     }
-    for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
-    __syncthreads();
+    // (the 128 KiB weight fill of the workgroup happens below, AFTER the wave has requested its first tile's operands)
 
     // XCD-aware task order (speed only): workgroup g runs on XCD g % 8; give every XCD whole trajectories so that the gathered
     // rows of Bm stay in that XCD's L2; few trajectories (B < 8): each is split over several XCDs
@@ -850,7 +849,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
                        : (unsigned)wave * (unsigned)wg_per_xcd + (unsigned)slot;      // wave-major: a launch with fewer tasks than waves spreads over ALL workgroups
                                                                                // (a few waves each, a SIMD to themselves) instead of filling the first ones
     int b = 0, i = 0, mt = 0;
-    if (!next_task(tt, b, i, mt)) return;
+    const bool has_task = next_task(tt, b, i, mt);      // (a wave without a task still helps to fill the weights and meets the barrier)
 
     // raw edge data of the tile in lookahead (rows past K read the node's last edge and are masked in set_tile)
     int jqn[2]; uint32_t codeqn[2]; float radqn[2];
@@ -1021,11 +1020,19 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
 
     // ---- the only prologue of the wave: first tile's chunk 0 built, its chunk 1 requested
     RawP r0, r1;
-    load_idx(b, i, mt);
-    set_tile(b, i, mt);
-    radq[0] = radq_nx[0]; radq[1] = radq_nx[1];
-    gather_chunk(0);
-    gather(0, 0, r0); gather(0, 1, r1);
+    if (has_task) {
+        load_idx(b, i, mt);
+        set_tile(b, i, mt);
+        radq[0] = radq_nx[0]; radq[1] = radq_nx[1];
+        gather_chunk(0);
+        gather(0, 0, r0); gather(0, 1, r1);
+    }
+    // The workgroup's weight fragments, global -> LDS, with the first tile's index loads and gathers already in flight: a launch with
+    // one round of tiles (small batches, the row-list launches) otherwise pays the two dependent round trips of its prologue AFTER
+    // the 128 KiB fill instead of under it.
+    for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
+    __syncthreads();
+    if (!has_task) return;
     compute_store(0, r0, stage); gather(1, 0, r0);
     compute_store(1, r1, stage); gather(1, 1, r1);
     gather_chunk(1);

@@ -19,46 +19,8 @@ __global__ __launch_bounds__(256) void k_prep_pose(const float *__restrict__ rec
     __shared__ double scratch[8];
     __shared__ float center[3];
     const int b = blockIdx.x, N = R + L;
-    const float *lig = lig_cur + (size_t)b * L * 9;
-    double s0 = 0, s1 = 0, s2 = 0;
-    if (all_atoms) {   // DFMDock.move_to_lig_center (DFMDock.py:254-257): mean over all L x 3 backbone atoms
-        for (int q = threadIdx.x; q < L * 3; q += blockDim.x) { s0 += lig[q * 3]; s1 += lig[q * 3 + 1]; s2 += lig[q * 3 + 2]; }
-    } else {           // score_net_mlsb.py:353: ligand CA centroid
-        for (int q = threadIdx.x; q < L; q += blockDim.x) { s0 += lig[q * 9 + 3]; s1 += lig[q * 9 + 4]; s2 += lig[q * 9 + 5]; }
-    }
-    s0 = block_sum_d(s0, scratch);
-    s1 = block_sum_d(s1, scratch);
-    s2 = block_sum_d(s2, scratch);
-    if (threadIdx.x == 0) {
-        const int cnt = all_atoms ? L * 3 : L;
-        center[0] = (float)(s0 / cnt); center[1] = (float)(s1 / cnt); center[2] = (float)(s2 / cnt);
-    }
-    __syncthreads();
-    const float cx = center[0], cy = center[1], cz = center[2];
-    float *P = pos + (size_t)b * N * 9;
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-        const float *src = i < R ? rec_pos + (size_t)i * 9 : lig + (size_t)(i - R) * 9;
-        float v[9];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            v[a * 3 + 0] = src[a * 3 + 0] - cx;
-            v[a * 3 + 1] = src[a * 3 + 1] - cy;
-            v[a * 3 + 2] = src[a * 3 + 2] - cz;
-        }
-#pragma unroll
-        for (int a = 0; a < 9; ++a) P[(size_t)i * 9 + a] = v[a];
-        // Cb = -0.58273431*a + 0.56802827*b - 0.54067466*c + Ca ;  b = Ca - N, c = C - Ca, a = b x c
-        const float bx = v[3] - v[0], by = v[4] - v[1], bz = v[5] - v[2];
-        const float cx_ = v[6] - v[3], cy_ = v[7] - v[4], cz_ = v[8] - v[5];
-        const float ax = by * cz_ - bz * cy_, ay = bz * cx_ - bx * cz_, az = bx * cy_ - by * cx_;
-        float4 cb;
-        cb.x = ((-0.58273431f * ax + 0.56802827f * bx) - 0.54067466f * cx_) + v[3];
-        cb.y = ((-0.58273431f * ay + 0.56802827f * by) - 0.54067466f * cy_) + v[4];
-        cb.z = ((-0.58273431f * az + 0.56802827f * bz) - 0.54067466f * cz_) + v[5];
-        cb.w = 0.f;
-        ca4[(size_t)b * N + i] = make_float4(v[3], v[4], v[5], 0.f);
-        cb4[(size_t)b * N + i] = cb;
-    }
+    prep_pose_block(rec_pos, lig_cur + (size_t)b * L * 9, R, L, all_atoms, pos + (size_t)b * N * 9, ca4 + (size_t)b * N, cb4 + (size_t)b * N,
+                    scratch, center);
 }
 
 hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, int all_atoms, float *pos, float4 *ca4,

@@ -138,6 +138,12 @@ struct HeadKArgs {
     long long trace_s_bstride;
     const StepParams *step_params;      // replayed step graph (HeadArgs::ctl): this step's scalars, seed and time embedding from device memory
     const uint32_t *ctl;
+    // prep_next: after the update, prepare the NEW pose for the next evaluation right here (what k_prep_pose would do as that
+    // evaluation's first launch: same workgroup shape, same code) - one dependent launch less per step
+    int prep_next;
+    const float *rec_pos;
+    float *prep_pos;
+    float4 *prep_ca4, *prep_cb4;
 };
 
 // sum over the 128 threads of a group (two waves); scratch[4]
@@ -171,7 +177,7 @@ template <int NV> __device__ inline void block_sum_dn(double (&v)[NV], double *s
 __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
 {
     __shared__ double dscr[4 * 12];
-    __shared__ float s_red[4], s_pred[8], s_score[8], s_upd[16];
+    __shared__ float s_red[4], s_pred[8], s_score[8], s_upd[16], s_center[3];
     const int b = blockIdx.x, tid = threadIdx.x, R = p.R, L = p.L, N = R + L;
     float *lig = p.lig_cur + (size_t)b * L * 9;
     const float *hid_base = p.hid_base + (size_t)b * p.hid_bstride;
@@ -312,6 +318,11 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
             if (tp) tp[at * 3 + r] = o;
         }
     }
+    if (p.prep_next) {
+        __syncthreads();      // the workgroup's new pose is complete (and its reads of this evaluation's centred CA are long done)
+        prep_pose_block(p.rec_pos, lig, R, L, p.all_atoms, p.prep_pos + (size_t)b * N * 9, p.prep_ca4 + (size_t)b * N, p.prep_cb4 + (size_t)b * N,
+                        dscr, s_center);
+    }
 }
 
 hipError_t launch_heads(const HeadArgs &a, hipStream_t s)
@@ -328,6 +339,7 @@ hipError_t launch_heads(const HeadArgs &a, hipStream_t s)
     k.trace_pose = a.trace_pose; k.trace_bstride = a.trace_bstride;
     k.trace_scores = a.trace_scores; k.trace_s_bstride = a.trace_s_bstride;
     k.step_params = a.step_params; k.ctl = a.ctl;
+    k.prep_next = a.prep_next; k.rec_pos = a.rec_pos; k.prep_pos = a.prep_pos; k.prep_ca4 = a.prep_ca4; k.prep_cb4 = a.prep_cb4;
     hipLaunchKernelGGL(k_heads, dim3(a.B), dim3(256), 0, s, k);
     return hipGetLastError();
 }
