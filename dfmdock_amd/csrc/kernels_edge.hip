@@ -54,6 +54,7 @@ struct EdgeKArgs {
     unsigned long long *stamp;   // DFM_EDGE_STAMP builds only: per-phase cycle sums of workgroup 0 (tools/edge_phases.py)
     const uint16_t *Ah;          // k_edge_msg<0, 1>: A as fp16
     int split;                   // k_edge_msg: 1 = a wave task is one TILE (small launches), agg is pre-zeroed and added to atomically
+    int no_agg;                  // message kernels: nobody reads agg after this launch (ligand-only last layer): no segment-sum store, no atomics, no memset
     int node0, nodes;            // message kernels: the tasks cover nodes node0 .. node0 + nodes - 1 of every trajectory (all of them, or - last
                                  // layer when nobody reads the node outputs - the ligand nodes only: EdgeArgs::lig_only)
     uint32_t *range;             // k_edge_f32, dfm_complex_selfcheck only: [0] max |pre-activation of edge_mlp.0|, [1] of edge_mlp.2, as float bits
@@ -1257,7 +1258,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             float *out = p.agg + ((size_t)b * p.N + i) * H + l31;
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
-                if (h == 0) {
+                if (h == 0 && !p.no_agg) {
                     if (split) atomicAdd(out + nt * 32, colsum[nt]); else store_stream(out + nt * 32, colsum[nt]);
                 }
                 colsum[nt] = 0.f;
@@ -1465,6 +1466,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.Wc1t = w->Wc1t; k.bc1 = w->bc1; k.wc2 = w->wc2;
     k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.stamp = a.stamp; k.split = 0;
     k.node0 = a.lig_only ? a.R : 0; k.nodes = a.lig_only ? a.N - a.R : a.N;
+    k.no_agg = a.lig_only ? 1 : 0;      // the ligand-only last layer feeds the coordinate update alone (api.hip: no node model follows)
     k.Ah = a.Ah; k.range = a.range;
     return k;
 }
@@ -1553,7 +1555,7 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
     long long tasks = (long long)a.B * k.nodes;
     if (edge_msg_tile_tasks(a.B, k.nodes, a.K)) {
         k.split = 1; tasks *= (a.K + 31) / 32;
-        if (!a.agg_is_zero) {
+        if (!a.agg_is_zero && !k.no_agg) {
             hipError_t e = hipMemsetAsync(a.agg, 0, (size_t)a.B * a.N * H * sizeof(float), s);
             if (e != hipSuccess) return e;
         }

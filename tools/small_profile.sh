@@ -5,7 +5,7 @@ B=${1:-8}; R=${2:-300}; L=${3:-300}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_sb
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sb -- python $ROOT/bench.py --steps 5 --warmup 1 --batch $B --R $R --L $L --no-cpu-baseline > /tmp/sb.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sb -- python $ROOT/bench.py --steps 5 --warmup 1 --batch $B --R $R --L $L --no-cpu-baseline --no-fp32-line > /tmp/sb.log 2>&1
 f=$(find /tmp/prof_sb -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
