@@ -653,7 +653,7 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
         HIPCHK(W.pool.alloc(&W.Bmb, b * N * H)); HIPCHK(W.pool.alloc(&W.agg, b * N * H));
         HIPCHK(W.pool.alloc(&W.u, b * N * H));
         HIPCHK(W.pool.alloc(&W.gn_shift, b * H)); HIPCHK(W.pool.alloc(&W.gn_den, b * H));
-        HIPCHK(W.pool.alloc(&W.gn_part, b * ((N + 63) / 64) * H * 2));
+        HIPCHK(W.pool.alloc(&W.gn_part, b * ((N + 31) / 32) * H * 2));      // (mean, M2) per 32-row half of a GEMM tile, trajectory and channel
         const size_t RT = (R + 63) / 64, NP = R > 4 * RT ? R : 4 * RT;     // partial-sum slots per trajectory
         HIPCHK(W.pool.alloc(&W.fvec, b * L * 3)); HIPCHK(W.pool.alloc(&W.en_part, b * NP * 2));
         HIPCHK(W.pool.alloc(&W.clash_part, b * NP)); HIPCHK(W.pool.alloc(&W.scores, b * 8));
@@ -741,7 +741,7 @@ extern "C" const char *dfm_config_string(void)
         c += "; layer 0 through the per-complex message table in dfm_sample (DFM_F_NO_L0_TABLE: direct), on request in dfm_score (DFM_F_L0_TABLE)";
         c += "; build: TAB_MERGE=" + std::to_string((int)DFM_TAB_MERGE);
         std::string env;
-        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_GEMM_NARROW_MAXWG", "DFM_L0_TABLE", "DFM_GRAPH", "DFM_EDGE_F32_SCALAR", "DFM_LIB"}) {
+        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_GEMM_NARROW_MAXWG", "DFM_GEMM_QUARTER_MAXWG", "DFM_L0_TABLE", "DFM_GRAPH", "DFM_EDGE_F32_SCALAR", "DFM_LIB"}) {
             const char *e = getenv(k);
             if (e) env += std::string(env.empty() ? "" : " ") + k + "=" + e;
         }

@@ -152,19 +152,19 @@ hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s)
 // Same prologues / epilogues as k_gemm_f32, except that prologue 2 takes the folded GraphNorm affine
 // (gn_den := w/den, gn_shift := b - w*shift/den per graph and channel, see k_gn_stats fold=1).
 // Needs K % 32 == 0, Nout % 256 == 0.
-// One channel of GraphNorm from the per-tile column statistics of k_gemm_split (stat_part [B][tiles per trajectory][256][2] =
-// (mean, M2 = sum of squared deviations) over the tile's rows): tiles merged in a fixed order with Chan's update in float64, then
+// One channel of GraphNorm from the column statistics of k_gemm_split (stat_part [B][ceil(N / 32)][256][2] = (mean, M2 = sum of squared
+// deviations) over each 32-row half of a tile - the unit every tile shape of the kernel shares, r04): halves merged in a fixed order with Chan's update in float64, then
 // var = E[(u - shift)^2] = M2 / N + (mean - shift)^2 with shift = mean * mean_scale.  fold_w: returns the folded affine
 // (den := w / den, shift := b - w * shift / den).  Runs in the prologue of the GEMM that consumes the normalised activations
 // (r01-r03: a separate k_gn_finish launch per layer, 5 us each that small batches could not hide).
 __device__ inline void gn_finish_col(const float *__restrict__ part, int b, int N, int c, const float *__restrict__ mean_scale,
                                      const float *__restrict__ fold_w, const float *__restrict__ fold_b, float &o_den, float &o_shift)
 {
-    const int tpt = (N + 63) / 64;
+    const int tpt = (N + 31) / 32;
     double n = 0, mean = 0, M2 = 0;
     for (int t = 0; t < tpt; ++t) {
         const float *pp = part + ((size_t)b * tpt + t) * (H * 2) + c * 2;
-        const double nt = (double)(N - t * 64 < 64 ? N - t * 64 : 64), d = (double)pp[0] - mean, tot = n + nt;
+        const double nt = (double)(N - t * 32 < 32 ? N - t * 32 : 32), d = (double)pp[0] - mean, tot = n + nt;
         mean += d * nt / tot;
         M2 += (double)pp[1] + d * d * n * nt / tot;
         n = tot;
@@ -212,9 +212,15 @@ __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
 // can pull from L2 / HBM (~55 GB/s: 40 KiB per K-stage = 0.75 us; deeper prefetch or a pipelined loop buy nothing,
 // profiles/r02_exp_gemm_deep.txt, r03_d notes) - twice the workgroups, each with half the weight bytes per stage.  Same MFMA sequence per
 // output element and the same row order in the column statistics: bitwise the same results as NJ = 2.
-template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmSplitArgs sa)
+// QT = 1 (with NJ = 1): 64 x 64 tiles, waves 2 x 2 of 32 x 32, for launches that do not even give every second CU a 64 x 128 workgroup
+// (B <= 6 at 300+300): a lone workgroup is a serial chain of K-stages whose length follows the bytes and MFMAs of ONE stage (r03 stamps:
+// 970 cycles of MFMA phase + 830 of fetch per stage at 64 x 128), so four times the workgroups with a third of each: node GEMMs
+// 17.9 / 8.7 -> XX / XX us at B = 1 (profiles/r04_small_batch.txt).  Bitwise the same results again.
+template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmSplitArgs sa)
 {
-    constexpr int SM = 64, SN = NJ * 128;      // rows; output columns per workgroup (four waves along N, NJ 32-column tiles each)
+    static_assert(!QT || NJ == 1, "quarter tiles: one 32-column tile per wave");
+    constexpr int MI = QT ? 1 : 2;                       // 32-row tiles per wave
+    constexpr int SM = 64, SN = QT ? 64 : NJ * 128;      // rows; output columns per workgroup (QT 0: four waves along N, NJ 32-column tiles each)
     const GemmArgs &a = sa.g;
     // operand tiles; the epilogue reuses the space as 4 x 9216 B of transposition buffers
     constexpr int LDS_OPER = (2 * SM + 2 * SN) * SLD, LDS_EPI = 4 * 32 * 72 * 2;      // operand tiles | epilogue staging (4 waves x 32 x ELD floats)
@@ -222,8 +228,7 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
     __shared__ __attribute__((aligned(16))) uint16_t lds[LDS_U16];
     uint16_t *Ah = lds, *Al = lds + SM * SLD, *Wh = lds + 2 * SM * SLD, *Wl = lds + (2 * SM + SN) * SLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int wm = 0;
-    const int wn = wave, l31 = lane & 31;
+    const int wm = QT ? wave >> 1 : 0, wn = QT ? wave & 1 : wave, l31 = lane & 31;      // wave's 32-row tile(s) start at wm * MI * 32
     // row tile: plain 64/128-row blocks of the [M] rows, or - when the GraphNorm column sums are wanted - blocks aligned to
     // the trajectory (rows_per_graph rows each, last block partial): every block then belongs to one trajectory and the
     // summation order is the same for every trajectory, whatever its position in the batch (batched == single, bitwise)
@@ -268,9 +273,9 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
             for (int q = 0; q < SN / 16; ++q) z[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    f32x16 acc[2][NJ];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -285,9 +290,11 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
 
     // registers of the stage being fetched: activations (rows x 8 k) and 4 x 16 B of hi / lo weights
     float4 xa0, xa1;
-    uint4 wh0, wh1, wh2, wh3, wl0, wl1, wl2, wl3;      // NJ = 1: thread = (column tid & 127, hi / lo tid >> 7), wh0..3 only
-    const int wcol = NJ == 2 ? tid : (tid & 127);
-    const uint16_t *wsrc = (NJ == 2 || tid < 128) ? sa.Whi : sa.Wlo;
+    uint4 wh0, wh1, wh2, wh3, wl0, wl1, wl2, wl3;      // NJ = 1: thread = (column tid & 127, hi / lo tid >> 7), wh0..3 only;
+                                                       // QT: thread = (column tid & 63, hi / lo (tid >> 6) & 1, k-groups 2 (tid >> 7) + {0, 1}), wh0..1 only
+    const int wcol = QT ? (tid & 63) : (NJ == 2 ? tid : (tid & 127));
+    const int wkq = QT ? (tid >> 7) * 2 : 0;
+    const uint16_t *wsrc = QT ? (((tid >> 6) & 1) ? sa.Wlo : sa.Whi) : ((NJ == 2 || tid < 128) ? sa.Whi : sa.Wlo);
 #define GEMM_SPLIT_FETCH(K0)                                                                                          \
     {                                                                                                                 \
         const int k_ = (K0) + kg;                                                                                     \
@@ -296,9 +303,11 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
         xa0 = *reinterpret_cast<const float4 *>(s0_); xa1 = *reinterpret_cast<const float4 *>(s0_ + 4);              \
         const size_t wbase_ = ((size_t)((K0) / SK) * 4 * a.Nout + col0 + wcol) * 8;                                   \
         const size_t wq_ = (size_t)a.Nout * 8;                                                                        \
-        const uint16_t *ph_ = wsrc + wbase_, *pl_ = sa.Wlo + wbase_;                                                  \
+        const uint16_t *ph_ = wsrc + wbase_ + wkq * wq_, *pl_ = sa.Wlo + wbase_;                                      \
         wh0 = *reinterpret_cast<const uint4 *>(ph_); wh1 = *reinterpret_cast<const uint4 *>(ph_ + wq_);               \
-        wh2 = *reinterpret_cast<const uint4 *>(ph_ + 2 * wq_); wh3 = *reinterpret_cast<const uint4 *>(ph_ + 3 * wq_); \
+        if constexpr (!QT) {                                                                                          \
+            wh2 = *reinterpret_cast<const uint4 *>(ph_ + 2 * wq_); wh3 = *reinterpret_cast<const uint4 *>(ph_ + 3 * wq_); \
+        }                                                                                                             \
         if constexpr (NJ == 2) {                                                                                      \
             wl0 = *reinterpret_cast<const uint4 *>(pl_); wl1 = *reinterpret_cast<const uint4 *>(pl_ + wq_);               \
             wl2 = *reinterpret_cast<const uint4 *>(pl_ + 2 * wq_); wl3 = *reinterpret_cast<const uint4 *>(pl_ + 3 * wq_); \
@@ -330,8 +339,8 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
         *reinterpret_cast<uint4 *>(&Al[row * SLD + kg]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     };
 
-    const int wu = wcol * SLD;   // weights: thread = output column, q = 8-k group (consecutive lanes -> consecutive LDS rows: conflict-free)
-    uint16_t *wdst = (NJ == 2 || tid < 128) ? Wh : Wl;
+    const int wu = wcol * SLD + wkq * 8;   // weights: thread = output column, q = 8-k group (consecutive lanes -> consecutive LDS rows: conflict-free)
+    uint16_t *wdst = QT ? (((tid >> 6) & 1) ? Wl : Wh) : ((NJ == 2 || tid < 128) ? Wh : Wl);
 #ifdef DFM_GEMM_STAMP
     unsigned long long gs[4] = {0, 0, 0, 0}, gprev = __builtin_amdgcn_s_memtime();
 #define GSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _n = __builtin_amdgcn_s_memtime(); gs[k] += _n - gprev; gprev = _n; __builtin_amdgcn_sched_barrier(0); }
@@ -349,7 +358,7 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
         GSTAMP(0)                  // [0] MFMA phase + barrier wait
         stage_row(xa0, xa1, rv0, k0 + kg, ar);
         *reinterpret_cast<uint4 *>(&wdst[wu]) = wh0; *reinterpret_cast<uint4 *>(&wdst[wu + 8]) = wh1;
-        *reinterpret_cast<uint4 *>(&wdst[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&wdst[wu + 24]) = wh3;
+        if constexpr (!QT) { *reinterpret_cast<uint4 *>(&wdst[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&wdst[wu + 24]) = wh3; }
         if constexpr (NJ == 2) {
             *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
             *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
@@ -361,10 +370,10 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
 #pragma unroll
         for (int ks = 0; ks < SK; ks += 16) {
             const int ko = ks + (lane >> 5) * 8;
-            FragB ah[2], al[2];
+            FragB ah[MI], al[MI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wm * 64 + i * 32 + l31;
+            for (int i = 0; i < MI; ++i) {
+                const int r = (wm * MI + i) * 32 + l31;
                 ah[i].u = *reinterpret_cast<const uint4 *>(&Ah[r * SLD + ko]);
                 al[i].u = *reinterpret_cast<const uint4 *>(&Al[r * SLD + ko]);
             }
@@ -375,7 +384,7 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
                 wh.u = *reinterpret_cast<const uint4 *>(&Wh[c * SLD + ko]);
                 wl.u = *reinterpret_cast<const uint4 *>(&Wl[c * SLD + ko]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < MI; ++i) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].b, wh.b, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wl.b, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wh.b, acc[i][j], 0, 0, 0);
@@ -390,12 +399,14 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
     __syncthreads();
     // GraphNorm statistics of this lane's rows (4 columns): shifted sums about the lane's first value - no E[u^2] - E[u]^2
     // cancellation when |mean| >> std - turned into (count, mean, M2) and merged Chan-style across lanes, tiles (gn_finish_col)
-    float st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0}, st_p[4] = {0, 0, 0, 0}, st_n = 0.f;
+    // One set per 32-row half of the tile (r01-r03: per 64-row tile): the unit that every tile shape shares, so that the choice of shape -
+    // a function of the launch size - never shows in a bit.
     constexpr int ELD = 72;                               // floats per staged row (64 + 8: the half-waves, 4 rows apart, hit disjoint banks)
     float *est = reinterpret_cast<float *>(lds) + wave * (32 * ELD);   // 9216 B per wave
     const int er = lane >> 4, ec = (lane & 15) * 4;       // read-back: 4 rows x 16 float4 per instruction
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i) {
+    float st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0}, st_p[4] = {0, 0, 0, 0}, st_n = 0.f;
 #pragma unroll
         for (int jp = 0; jp < (NJ + 1) / 2; ++jp) {
             // residual rows of this pass, requested before the transposition below instead of one dependent load per store
@@ -403,7 +414,7 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
             if (a.epi == 1) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const size_t row = (size_t)row0 + wm * 64 + i * 32 + q * 4 + er;
+                    const size_t row = (size_t)row0 + (wm * MI + i) * 32 + q * 4 + er;
                     const size_t rrow = a.r_period ? row % (size_t)a.r_period : row;
                     const int col = col0 + (wn * NJ + jp * 2) * 32 + ec;
                     res[q] = (row < (size_t)row_end && ec < NJ * 32) ? *reinterpret_cast<const float4 *>(a.R + rrow * a.ldc + col) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -429,7 +440,7 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
                     const int lr = q * 8 + er8;
                     const float4 v0 = *reinterpret_cast<const float4 *>(est + lr * ELD + ec8);
                     const float4 v1 = *reinterpret_cast<const float4 *>(est + lr * ELD + ec8 + 4);
-                    const size_t row = (size_t)row0 + wm * 64 + i * 32 + lr;
+                    const size_t row = (size_t)row0 + (wm * MI + i) * 32 + lr;
                     const int col = (col0 < H ? col0 : col0 - H) + (wn * NJ + jp * 2) * 32 + ec8;
                     if (row >= (size_t)row_end || ec8 >= NJ * 32) continue;
                     uint4 o;
@@ -442,7 +453,7 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
             for (int q = 0; q < 8; ++q) {
                 const int lr = q * 4 + er;
                 const float4 v = *reinterpret_cast<const float4 *>(est + lr * ELD + ec);
-                const size_t row = (size_t)row0 + wm * 64 + i * 32 + lr;
+                const size_t row = (size_t)row0 + (wm * MI + i) * 32 + lr;
                 const int col = col0 + (wn * NJ + jp * 2) * 32 + ec;
                 if (row >= (size_t)row_end || ec >= NJ * 32) continue;
                 {
@@ -481,16 +492,13 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
             }   // full-width outputs
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-#ifdef DFM_GEMM_STAMP
-    GSTAMP(3)                      // [3] epilogue
-    if (vb == (gridDim.x > 2048 ? 7 * 8 + 1536 : 3) && blockIdx.y == 0 && tid == 0 && a.C) {       // one mid-grid workgroup reports (debug buffer = first floats of ... stderr-free: printf)
-        printf("gemm stamp K=%d Nout=%d pro=%d epi=%d: mfma+barrier %llu  fetch-wait+stage %llu  barrier2 %llu  epilogue %llu cycles\n",
-               a.K, a.Nout, a.pro, a.epi, gs[0], gs[1], gs[2], gs[3]);
-    }
-#endif
     {
+        // this 32-row half's statistics -> partial (tile's first half index + wm * MI + i) of the trajectory's ceil(N / 32); a half past the
+        // trajectory's last row has no slot
         if (a.stat_part) {
-            float *sp = a.stat_part + (size_t)vb * (H * 2);
+            const int tpt64 = (a.rows_per_graph + 63) / 64, tpt32 = (a.rows_per_graph + 31) / 32;
+            const int sub = (vb % tpt64) * 2 + wm * MI + i;
+            float *sp = a.stat_part + ((size_t)(vb / tpt64) * tpt32 + sub) * (H * 2);
             const float inv_n = st_n > 0.f ? 1.0f / st_n : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -506,7 +514,7 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
                     }
                     ne = nt;
                 }
-                if (er == 0 && ec < NJ * 32) {       // only this lane's merge order is ever read: deterministic, the same for every trajectory
+                if (er == 0 && ec < NJ * 32 && sub < tpt32) {       // only this lane's merge order is ever read: deterministic, the same for every trajectory
                     const int c = col0 + wn * (NJ * 32) + ec + e;
                     sp[c * 2] = mean;
                     sp[c * 2 + 1] = M2;
@@ -514,6 +522,14 @@ template <int HALF, int NJ> __global__ __launch_bounds__(256, 3) void k_gemm_spl
             }
         }
     }
+    }      // i: 32-row halves
+#ifdef DFM_GEMM_STAMP
+    GSTAMP(3)                      // [3] epilogue
+    if (vb == (gridDim.x > 2048 ? 7 * 8 + 1536 : 3) && blockIdx.y == 0 && tid == 0 && a.C) {       // one mid-grid workgroup reports (debug buffer = first floats of ... stderr-free: printf)
+        printf("gemm stamp K=%d Nout=%d pro=%d epi=%d: mfma+barrier %llu  fetch-wait+stage %llu  barrier2 %llu  epilogue %llu cycles\n",
+               a.K, a.Nout, a.pro, a.epi, gs[0], gs[1], gs[2], gs[3]);
+    }
+#endif
 }
 #undef GEMM_SPLIT_FETCH
 
@@ -541,6 +557,18 @@ hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint1
     const bool narrow = (long long)row_tiles * (a.Nout / SN) < narrow_max;
     const bool half = a.epi == 2 && a.Cb && a.C2b && !a.C2;
     if (narrow) {
+        // ... and 64 x 64 tiles (QT) while even those leave more than half of the CUs without a workgroup (B <= 6 at 300+300)
+        static const int quarter_env = [] {
+            const char *e = getenv("DFM_GEMM_QUARTER_MAXWG");      // diagnostics: 64 x 128 workgroup count below which QT is used (0 = never)
+            return e ? atoi(e) : -1;
+        }();
+        const int quarter_max = quarter_env >= 0 ? quarter_env : device_cus() / 2;
+        if ((long long)row_tiles * (a.Nout / 128) < quarter_max) {
+            const dim3 grid(row_tiles, a.Nout / 64);
+            if (half) hipLaunchKernelGGL((k_gemm_split<1, 1, 1>), grid, dim3(256), 0, s, sa);
+            else hipLaunchKernelGGL((k_gemm_split<0, 1, 1>), grid, dim3(256), 0, s, sa);
+            return hipGetLastError();
+        }
         const dim3 grid(row_tiles, a.Nout / 128);
         if (half) hipLaunchKernelGGL((k_gemm_split<1, 1>), grid, dim3(256), 0, s, sa);
         else hipLaunchKernelGGL((k_gemm_split<0, 1>), grid, dim3(256), 0, s, sa);

@@ -415,7 +415,7 @@ def test_other_depths_both_families_lean_equals_full(depth, family):
 
 
 def test_narrow_gemm_tiles_equal_wide_tiles_bitwise(tmp_path):
-    """k_gemm_split runs 64 x 128 tiles for launches below two workgroups per CU and 64 x 256 tiles above: the same MFMA sequence per
+    """k_gemm_split runs 64 x 64 / 64 x 128 tiles for small launches and 64 x 256 tiles above two workgroups per CU: the same MFMA sequence per
     output element and the same row order in the GraphNorm column statistics, so the choice (a function of the batch size) must not
     show in a single bit - of a score evaluation (node features of the first and last layer included) or of a sampled pose.
     DFM_GEMM_NARROW_MAXWG forces the form (read once per process: subprocesses); B = 1 and B = 7 also cross the tile-task threshold."""
@@ -439,11 +439,15 @@ def test_narrow_gemm_tiles_equal_wide_tiles_bitwise(tmp_path):
         np.savez(sys.argv[1], **out)
     """))
     outs = {}
-    for tag, env, B in (("wide1", "0", 1), ("narrow1", "1000000", 1), ("wide7", "0", 7), ("narrow7", "1000000", 7)):
+    # quarter1 / quarter7: 64 x 64 tiles (waves 2 x 2; what launches with fewer 64 x 128 workgroups than half the CUs run), forced at
+    # B = 7 too.  The column statistics go out per 32-row half of a tile in every shape.
+    for tag, env, B in (("wide1", "0", 1), ("narrow1", "1000000", 1), ("wide7", "0", 7), ("narrow7", "1000000", 7), ("quarter1", "1000000", 1),
+                        ("quarter7", "1000000", 7)):
         p = subprocess.run([sys.executable, str(script), str(tmp_path / f"{tag}.npz"), str(B)],
-                           env=dict(os.environ, DFM_GEMM_NARROW_MAXWG=env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+                           env=dict(os.environ, DFM_GEMM_NARROW_MAXWG=env, DFM_GEMM_QUARTER_MAXWG="1000000" if tag.startswith("quarter") else "0"),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         assert p.returncode == 0, p.stdout.decode()[-2000:]
         outs[tag] = np.load(tmp_path / f"{tag}.npz")
-    for tag in ("narrow1", "wide7", "narrow7"):
+    for tag in ("narrow1", "wide7", "narrow7", "quarter1", "quarter7"):
         for k in outs["wide1"].files:
             assert (outs[tag][k] == outs["wide1"][k]).all(), (tag, k)
