@@ -157,18 +157,35 @@ hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s)
 // var = E[(u - shift)^2] = M2 / N + (mean - shift)^2 with shift = mean * mean_scale.  fold_w: returns the folded affine
 // (den := w / den, shift := b - w * shift / den).  Runs in the prologue of the GEMM that consumes the normalised activations
 // (r01-r03: a separate k_gn_finish launch per layer, 5 us each that small batches could not hide).
+constexpr int GN_CH = 20;      // partials in flight per round trip (300+300: 19 partials = one round)
 __device__ inline void gn_finish_col(const float *__restrict__ part, int b, int N, int c, const float *__restrict__ mean_scale,
                                      const float *__restrict__ fold_w, const float *__restrict__ fold_b, float &o_den, float &o_shift)
 {
     const int tpt = (N + 31) / 32;
-    double n = 0, mean = 0, M2 = 0;
-    for (int t = 0; t < tpt; ++t) {
-        const float *pp = part + ((size_t)b * tpt + t) * (H * 2) + c * 2;
-        const double nt = (double)(N - t * 32 < 32 ? N - t * 32 : 32), d = (double)pp[0] - mean, tot = n + nt;
-        mean += d * nt / tot;
-        M2 += (double)pp[1] + d * d * n * nt / tot;
-        n = tot;
+    // This loop is the exposed prologue of every workgroup of the consuming GEMM: the partials come GN_CH loads at a time (one L2 round
+    // trip per GN_CH, not per partial: 164 -> 153 us per launch at C3), and the merge is the division-free pooled form in float64 - S1 = sum n_t mean_t,
+    // S2 = sum n_t mean_t^2: mean = S1 / N, M2 = sum M2_t + (S2 - mean S1) - whose cancellation float64 absorbs (the partial means are
+    // fp32 values).  Fixed order: the same bits for every trajectory and batch size.
+    const float *base = part + (size_t)b * tpt * (H * 2) + c * 2;
+    double S1 = 0, S2 = 0, SM = 0;
+    for (int t0 = 0; t0 < tpt; t0 += GN_CH) {
+        float2 v[GN_CH];
+#pragma unroll
+        for (int u = 0; u < GN_CH; ++u) {
+            const int t = t0 + u < tpt ? t0 + u : tpt - 1;
+            v[u] = *reinterpret_cast<const float2 *>(base + (size_t)t * (H * 2));
+        }
+#pragma unroll
+        for (int u = 0; u < GN_CH; ++u) {
+            const int t = t0 + u;
+            if (t < tpt) {
+                const double nt = (double)(N - t * 32 < 32 ? N - t * 32 : 32), m = (double)v[u].x, w = nt * m;
+                S1 += w; S2 += w * m; SM += (double)v[u].y;
+            }
+        }
     }
+    const double mean = S1 / N;
+    const double M2 = SM + (S2 - mean * S1);
     const float sft = (float)mean * mean_scale[c];
     const double dm = mean - (double)sft;
     double var = M2 / N + dm * dm;
@@ -245,7 +262,7 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
         bx = g16 * 8 + (j & 7); by = j >> 3;
         if (bx * SM >= a.M) return;          // tail of the last group of 8 tiles
     }
-    int row0 = bx * SM, row_end = a.M;
+    int row0 = bx * SM, row_end = a.M, gn_tb = 0;
     const int col0 = by * SN;
     // GraphNorm prologue: the folded scale / shift of the tile's trajectory, 2 KiB in LDS for the whole K loop (a load
     // per K-stage inside the staging code would expose an L2 round trip per stage)
@@ -253,17 +270,7 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
         const int tpt = (a.rows_per_graph + SM - 1) / SM, tb = bx / tpt;
         row0 = tb * a.rows_per_graph + (bx - tb * tpt) * SM;
         row_end = (tb + 1) * a.rows_per_graph;
-        if (a.pro == 2) {
-            if (a.gn_part) {      // finish the statistics here (thread = channel): no separate launch between the two GEMMs
-                float sc, sh;
-                gn_finish_col(a.gn_part, tb, a.rows_per_graph, tid, a.gn_ms, a.gn_w, a.gn_b, sc, sh);
-                gn_s[tid] = sc; gn_s[H + tid] = sh;
-            } else if (tid < 128) {
-                const float *src = (tid < 64 ? a.gn_den : a.gn_shift) + (size_t)tb * H + (tid & 63) * 4;
-                *reinterpret_cast<float4 *>(&gn_s[(tid < 64 ? 0 : H) + (tid & 63) * 4]) = *reinterpret_cast<const float4 *>(src);
-            }
-            __syncthreads();
-        }
+        gn_tb = tb;
     }
     if (a.zbuf) {      // zero this tile's block of a [M][256] buffer nobody reads any more (agg: see GemmArgs::zbuf)
         const int zr = tid >> 2;
@@ -353,6 +360,18 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bias_r[j] = a.bias ? a.bias[col0 + (wn * NJ + j) * 32 + l31] : 0.f;
     GEMM_SPLIT_FETCH(0)
+    // GraphNorm prologue, behind the first stage's loads (its L2 round trip rides under theirs instead of preceding it)
+    if (a.pro == 2) {
+        if (a.gn_part) {      // finish the statistics here (thread = channel): no separate launch between the two GEMMs
+            float sc, sh;
+            gn_finish_col(a.gn_part, gn_tb, a.rows_per_graph, tid, a.gn_ms, a.gn_w, a.gn_b, sc, sh);
+            gn_s[tid] = sc; gn_s[H + tid] = sh;
+        } else if (tid < 128) {
+            const float *src = (tid < 64 ? a.gn_den : a.gn_shift) + (size_t)gn_tb * H + (tid & 63) * 4;
+            *reinterpret_cast<float4 *>(&gn_s[(tid < 64 ? 0 : H) + (tid & 63) * 4]) = *reinterpret_cast<const float4 *>(src);
+        }
+        __syncthreads();
+    }
     for (int k0 = 0; k0 < a.K; k0 += SK) {
         if (k0) __syncthreads();   // previous stage fully consumed
         GSTAMP(0)                  // [0] MFMA phase + barrier wait
@@ -404,9 +423,15 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
     constexpr int ELD = 72;                               // floats per staged row (64 + 8: the half-waves, 4 rows apart, hit disjoint banks)
     float *est = reinterpret_cast<float *>(lds) + wave * (32 * ELD);   // 9216 B per wave
     const int er = lane >> 4, ec = (lane & 15) * 4;       // read-back: 4 rows x 16 float4 per instruction
+    float st_s[MI][4], st_q[MI][4], st_p[MI][4], st_n[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-    float st_s[4] = {0, 0, 0, 0}, st_q[4] = {0, 0, 0, 0}, st_p[4] = {0, 0, 0, 0}, st_n = 0.f;
+        st_n[i] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { st_s[i][e] = 0.f; st_q[i][e] = 0.f; st_p[i][e] = 0.f; }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int jp = 0; jp < (NJ + 1) / 2; ++jp) {
             // residual rows of this pass, requested before the transposition below instead of one dependent load per store
@@ -458,11 +483,12 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
                 if (row >= (size_t)row_end || ec >= NJ * 32) continue;
                 {
                     if (a.stat_part) {
-                        if (st_n == 0.f) { st_p[0] = v.x; st_p[1] = v.y; st_p[2] = v.z; st_p[3] = v.w; }
-                        const float d0 = v.x - st_p[0], d1 = v.y - st_p[1], d2 = v.z - st_p[2], d3 = v.w - st_p[3];
-                        st_s[0] += d0; st_s[1] += d1; st_s[2] += d2; st_s[3] += d3;
-                        st_q[0] += d0 * d0; st_q[1] += d1 * d1; st_q[2] += d2 * d2; st_q[3] += d3 * d3;
-                        st_n += 1.f;
+#pragma clang fp contract(off)      // every tile shape must round these sums alike: no instantiation-dependent fma formation
+                        if (st_n[i] == 0.f) { st_p[i][0] = v.x; st_p[i][1] = v.y; st_p[i][2] = v.z; st_p[i][3] = v.w; }
+                        const float d0 = v.x - st_p[i][0], d1 = v.y - st_p[i][1], d2 = v.z - st_p[i][2], d3 = v.w - st_p[i][3];
+                        st_s[i][0] += d0; st_s[i][1] += d1; st_s[i][2] += d2; st_s[i][3] += d3;
+                        st_q[i][0] += d0 * d0; st_q[i][1] += d1 * d1; st_q[i][2] += d2 * d2; st_q[i][3] += d3 * d3;
+                        st_n[i] += 1.f;
                     }
                 }
                 if (a.epi == 1) {
@@ -492,17 +518,19 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
             }   // full-width outputs
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-    {
-        // this 32-row half's statistics -> partial (tile's first half index + wm * MI + i) of the trajectory's ceil(N / 32); a half past the
-        // trajectory's last row has no slot
-        if (a.stat_part) {
-            const int tpt64 = (a.rows_per_graph + 63) / 64, tpt32 = (a.rows_per_graph + 31) / 32;
+    if (a.stat_part) {
+#pragma clang fp contract(off)
+        // each 32-row half's statistics -> partial (tile's first half index + wm * MI + i) of the trajectory's ceil(N / 32); a half past the
+        // trajectory's last row has no slot.  (After BOTH row passes: emitted between them the block costs the large launches 8 %.)
+        const int tpt64 = (a.rows_per_graph + 63) / 64, tpt32 = (a.rows_per_graph + 31) / 32;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
             const int sub = (vb % tpt64) * 2 + wm * MI + i;
             float *sp = a.stat_part + ((size_t)(vb / tpt64) * tpt32 + sub) * (H * 2);
-            const float inv_n = st_n > 0.f ? 1.0f / st_n : 0.f;
+            const float inv_n = st_n[i] > 0.f ? 1.0f / st_n[i] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float mean = st_p[e] + st_s[e] * inv_n, M2 = st_q[e] - st_s[e] * st_s[e] * inv_n, ne = st_n;
+                float mean = st_p[i][e] + st_s[i][e] * inv_n, M2 = st_q[i][e] - st_s[i][e] * st_s[i][e] * inv_n, ne = st_n[i];
 #pragma unroll
                 for (int m = 16; m <= 32; m <<= 1) {      // the four row groups (er) of a column, merged in a fixed order (Chan)
                     const float n2 = __shfl_xor(ne, m, 64), mean2 = __shfl_xor(mean, m, 64), M22 = __shfl_xor(M2, m, 64);
@@ -522,7 +550,6 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
             }
         }
     }
-    }      // i: 32-row halves
 #ifdef DFM_GEMM_STAMP
     GSTAMP(3)                      // [3] epilogue
     if (vb == (gridDim.x > 2048 ? 7 * 8 + 1536 : 3) && blockIdx.y == 0 && tid == 0 && a.C) {       // one mid-grid workgroup reports (debug buffer = first floats of ... stderr-free: printf)
