@@ -95,6 +95,7 @@ struct Workspace {
     float *gn_shift = nullptr, *gn_den = nullptr, *gn_part = nullptr;
     float *fvec = nullptr, *en_part = nullptr; int32_t *clash_part = nullptr;
     float *fpart = nullptr, *cpart = nullptr, *conf = nullptr;    // family 1: force partials per receptor tile, confidence
+    float *pair_s = nullptr;                                      // family 1, 16-bit engines: s(r, l) of one pair head, [B][L][32 ceil(R / 32)]
     float *scores = nullptr, *lig_cur = nullptr, *tr_update = nullptr, *rot_update = nullptr, *t_dev = nullptr;
     float *hid_base = nullptr;       // [max(Bcap, 1024)][2][128]: time-dependent half of the score-scale MLPs (k_time_embed), per trajectory
                                      // (dfm_score) or per step of the time grid (dfm_sample)
@@ -660,6 +661,7 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
         if (cx->m->hp.family == 1) {
             HIPCHK(W.pool.alloc(&W.fpart, b * RT * L * 3)); HIPCHK(W.pool.alloc(&W.cpart, b * RT * 4 * 2));
             HIPCHK(W.pool.alloc(&W.conf, b));
+            HIPCHK(W.pool.alloc(&W.pair_s, b * L * (((R + 31) / 32) * 32)));
         }
         HIPCHK(W.pool.alloc(&W.lig_cur, b * L * 9)); HIPCHK(W.pool.alloc(&W.tr_update, b * 3));
         HIPCHK(W.pool.alloc(&W.rot_update, b * 3)); HIPCHK(W.pool.alloc(&W.t_dev, b > MAX_TIME_GRID ? b : (size_t)MAX_TIME_GRID));
@@ -951,6 +953,8 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
     if (pair_family) {
         // egnn_net.py:430-470: pair heads on cat[h_r, h_l, D].  Per head: one GEMM projects every node through the stacked
         // halves of Linear(513 -> 256) (reusing the A / Bm buffers), then the elementwise pair kernel.
+        static const bool pair_valu = [] { const char *e = getenv("DFM_PAIR_HEAD_VALU"); return e && atoi(e) != 0; }();      // A/B: r02-r03 kernel
+        const bool pair_m = o.bf16 && !pair_valu;
         auto run_head = [&](int q, int mode) -> int {
             const PairHeadDev &Ph = m->pair[q];
             GemmArgs g;
@@ -963,6 +967,12 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             a.P = W.A; a.Q = W.Bm; a.ca4 = W.ca4; a.B = B; a.R = R; a.L = L; a.w_d = Ph.w_d; a.ln_w = Ph.ln_w; a.ln_b = Ph.ln_b;
             a.w3 = Ph.w3; a.mode = mode; a.exact = o.bf16 ? 0 : 1; a.cut_off = m->hp.cut_off; a.fpart = W.fpart;
             a.spart = mode == 1 ? W.en_part : W.cpart; a.clash_part = W.clash_part;
+            if (pair_m) {      // 16-bit engines: s(r, l) with the rank-4 part on the matrix pipe, then this head's reductions
+                a.S = W.pair_s; a.Rp = (R + 31) / 32 * 32;
+                HIPCHK(launch_pair_head_m(a, s));
+                HIPCHK(launch_pair_finish_s(a, 4 * ((R + 63) / 64), m->hp.agg_mean ? 1.0f / (float)R : 1.0f, W.fvec, W.conf, s));
+                return DFM_OK;
+            }
             HIPCHK(launch_pair_head(a, s));
             return DFM_OK;
         };
@@ -972,8 +982,9 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
             if ((rc = run_head(1, 1)) != DFM_OK) return rc;
             if ((rc = run_head(2, 2)) != DFM_OK) return rc;
         }
-        HIPCHK(launch_pair_finish(W.fpart, B, R, L, m->hp.agg_mean ? 1.0f / (float)R : 1.0f, W.fvec, W.cpart,
-                                  o.want_energy ? W.conf : nullptr, s));
+        if (!pair_m)
+            HIPCHK(launch_pair_finish(W.fpart, B, R, L, m->hp.agg_mean ? 1.0f / (float)R : 1.0f, W.fvec, W.cpart,
+                                      o.want_energy ? W.conf : nullptr, s));
     } else if (o.want_energy) {
         // to_energy.0 on cat[h_r, h_l] = Wa h_r + Wb h_l: project every node once (reuses A / Bm buffers)
         GemmArgs g;

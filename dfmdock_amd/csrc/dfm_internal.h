@@ -234,8 +234,12 @@ struct PairArgs {
     float *fpart;            // [B][ceil(R/64)][L][3]
     float *spart;            // [B][ceil(R/64)*4][2]
     int32_t *clash_part;     // [B][ceil(R/64)*4]
+    float *S; int Rp;        // 16-bit engines (k_pair_head_m): the pair scalars s(r, l) as [B][L][Rp], Rp = 32 ceil(R / 32)
 };
 hipError_t launch_pair_head(const PairArgs &a, hipStream_t s);
+// 16-bit engines: the rank-4 part of the pre-activation on the fp32 matrix pipe -> S; then the reductions of one head (mode of a) from S
+hipError_t launch_pair_head_m(const PairArgs &a, hipStream_t s);
+hipError_t launch_pair_finish_s(const PairArgs &a, int n_part, float inv_pool, float *fvec, float *conf, hipStream_t s);
 // dist_logits [B][R][L][64] = Linear(256 -> 64)(SiLU(LayerNorm(P_r + Q_l + w_d D)))  (egnn_net.py:347-352,:447); exact fp32
 hipError_t launch_pair_dist(const float *P, const float *Q, const float4 *ca4, int B, int R, int L, const float *w_d, const float *ln_w,
                             const float *ln_b, const float *w3t /*[256][64]*/, float *out, hipStream_t s);
