@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void k_pair_head(PairKArgs p)
 // VALU operations per pair and channel, and the channel-major C layout (lane = receptor residue, 16 channels per lane and block) keeps
 // the w3 dot product inside the lane.  The pair's LayerNorm statistics come from row moments and the dot product P_r . Q_l as before
 // (k_pair_head<0>), the dot products of a workgroup's 32 x 64 pairs from one fp32 MFMA pass over the raw tile before it is scaled in place.
-// Per pair and channel the VALU is left with fma, exp2, add, rcp, mul, fma + a quarter of two LDS reads: 2.71 -> XX ms per launch at
-// 300+300, B = 256 (profiles/r04_pair_head.txt).
+// Per pair and channel the VALU is left with fma, exp2, add, rcp, mul, fma + a quarter of two LDS reads: 4.82 -> 2.26 ms per launch at
+// 300+300, B = 256, second family 310 -> 358 traj/s (profiles/r04_pair_head.txt; VALU busy 0.77, 79 % of the issue floor of its mix).
 //   workgroup = (32 receptor residues, 64 ligand residues, trajectory), four waves striding over the ligand residues; P'' sits in LDS as
 //   [channel quad][r][4] (conflict-free 16-byte reads in the C layout, 32 KiB), three workgroups per CU.
 //   Output: the scalar s(r, l) as S[b][l][Rp] - the reductions over r (force, clashes, masked energy sum, confidence) are

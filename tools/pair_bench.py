@@ -17,7 +17,8 @@ engine.set_device(0)
 model = engine.Model(pack_blob(make_random_weights(0, hp), hp), hp)
 cases = ["fwd2_syn_24_16", "fwd2_syn_64_48_p0", "fwd2_syn_64_48_p1", "fwd2_syn_64_48_p2", "fwd2_7CEI_p0", "fwd2_7CEI_p1", "fwd2_7CEI_p2"]
 cache = {}
-for prec in ("fp32", "mfma16", "f16"):
+STEPS = int(os.environ.get("PAIR_STEPS", "40"))      # PAIR_ONLY_BENCH=1 PAIR_STEPS=3: the C3-shaped launches alone (counter passes)
+for prec in (() if os.environ.get("PAIR_ONLY_BENCH") else ("fp32", "mfma16", "f16")):
     worst = np.zeros(6)
     for c in cases:
         g = load_golden(c + ".npz")
@@ -38,6 +39,6 @@ if len(sys.argv) > 1:
     for prec in ("mfma16",):
         gx.sample(B=B, num_steps=4, seed=1, mfma16=True)
         t0 = time.perf_counter()
-        gx.sample(B=B, num_steps=40, seed=2, mfma16=True)
+        gx.sample(B=B, num_steps=STEPS, seed=2, mfma16=True)
         dt = time.perf_counter() - t0
-        print(f"C3-shaped 300+300, B={B}, 40 steps, {prec}: {dt*1e3:.0f} ms -> {B/dt:.1f} trajectories/s")
+        print(f"C3-shaped 300+300, B={B}, {STEPS} steps, {prec}: {dt*1e3:.0f} ms -> {B/dt:.1f} trajectories/s")
