@@ -161,3 +161,32 @@ def test_pair_family_dist_logits_vs_reference(blob_pair):
     with pytest.raises(ValueError):
         gx0.score(cx["lig_pos"], 0.5, dist=True)
     gx0.close()
+
+
+@pytest.mark.parametrize("R,L", [(31, 3), (33, 65), (95, 131), (64, 64), (130, 40)])
+def test_pair_head_on_the_matrix_pipe_at_ragged_sizes(R, L, blob_pair):
+    """k_pair_head_m tiles the receptor by 32 and the ligand by 64 (16 per wave): sizes on, just past and far from those edges.
+    The 16-bit engine's heads against the fp32 engine's (three-pass LayerNorm kernel) on the same graph, the clash count exactly,
+    and a batch of poses against the same poses one at a time, bitwise."""
+    from dfmdock_amd import engine
+    from dfmdock_amd.synthetic import make_complex
+    engine.set_device(0)
+    if True not in _models:
+        _models[True] = engine.Model(blob_pair, pair_hparams(True))
+    cx = make_complex(R, L, seed=R * 1000 + L)
+    gx = engine.Complex(_models[True], cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    rng = np.random.default_rng(L)
+    poses = np.stack([cx["lig_pos"] + rng.normal(0, 1.5, 3).astype(np.float32) for _ in range(3)])
+    ts = np.array([0.9, 0.5, 0.1], np.float32)
+    ref = gx.score(poses, ts, seed=5, energy=True, debug=True)
+    r = gx.score(poses, ts, edges=ref["edges"], energy=True, mfma16=True)
+    for i in range(3):
+        assert rel_inf(r["f"][i], ref["f"][i]) < 1e-2
+        assert rel_inf(r["tr_score"][i], ref["tr_score"][i]) < 1e-2
+        assert rel_inf(r["rot_score"][i], ref["rot_score"][i]) < 1e-2
+        assert abs(float(r["energy"][i]) - float(ref["energy"][i])) < 3e-2 * max(abs(float(ref["energy"][i])), 0.1)
+        assert abs(float(r["confidence"][i]) - float(ref["confidence"][i])) < 3e-2 * max(abs(float(ref["confidence"][i])), 0.1)
+        assert int(r["num_clashes"][i]) == int(ref["num_clashes"][i])
+        one = gx.score(poses[i], ts[i], edges=ref["edges"][i], energy=True, mfma16=True)
+        for k in ("tr_score", "rot_score", "energy", "f", "confidence"):
+            np.testing.assert_array_equal(r[k][i], one[k][0])
