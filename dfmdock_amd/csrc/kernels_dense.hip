@@ -239,8 +239,12 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
     constexpr int MI = QT ? 1 : 2;                       // 32-row tiles per wave
     constexpr int SM = 64, SN = QT ? 64 : NJ * 128;      // rows; output columns per workgroup (QT 0: four waves along N, NJ 32-column tiles each)
     const GemmArgs &a = sa.g;
+#ifdef DFM_GEMM_STAMP
+    const unsigned long long g_entry = __builtin_amdgcn_s_memtime();
+#endif
     // operand tiles; the epilogue reuses the space as 4 x 9216 B of transposition buffers
-    constexpr int LDS_OPER = (2 * SM + 2 * SN) * SLD, LDS_EPI = 4 * 32 * 72 * 2;      // operand tiles | epilogue staging (4 waves x 32 x ELD floats)
+    constexpr int LDS_BUF = (2 * SM + 2 * SN) * SLD;      // one set of operand tiles (hi / lo activations, hi / lo weights)
+    constexpr int LDS_OPER = (QT ? 2 : 1) * LDS_BUF, LDS_EPI = 4 * 32 * 72 * 2;      // operand tiles | epilogue staging (4 waves x 32 x ELD floats)
     constexpr int LDS_U16 = LDS_OPER > LDS_EPI ? LDS_OPER : LDS_EPI;
     __shared__ __attribute__((aligned(16))) uint16_t lds[LDS_U16];
     uint16_t *Ah = lds, *Al = lds + SM * SLD, *Wh = lds + 2 * SM * SLD, *Wl = lds + (2 * SM + SN) * SLD;
@@ -320,7 +324,7 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
             wl2 = *reinterpret_cast<const uint4 *>(pl_ + 2 * wq_); wl3 = *reinterpret_cast<const uint4 *>(pl_ + 3 * wq_); \
         }                                                                                                             \
     }
-    auto stage_row = [&](const float4 &v0, const float4 &v1, bool valid, int k, int row) {
+    auto stage_row = [&](const float4 &v0, const float4 &v1, bool /*valid*/, int k, int row, int boff = 0) {
         float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         if (a.pro == 2) {   // GraphNorm + SiLU (egnn.py:72-76) as y = x * sc + sh with per-(graph, channel) sc, sh
             // the tile's trajectory: scale / shift sit in LDS since the start of the kernel
@@ -337,19 +341,22 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
         uint32_t hi[4], lo[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float x0 = valid ? x[2 * e] : 0.f, x1 = valid ? x[2 * e + 1] : 0.f;
+            // (rows past the tile's last valid row hold a re-read of its first row: rows of a product are independent and the epilogue
+            // neither stores nor counts them, so they are not zeroed - eight selects per thread and stage less)
+            const float x0 = x[2 * e], x1 = x[2 * e + 1];
             const __bf16 b0 = (__bf16)x0, b1 = (__bf16)x1;
             hi[e] = pack2(b0, b1);
             lo[e] = pack2((__bf16)(x0 - (float)b0), (__bf16)(x1 - (float)b1));
         }
-        *reinterpret_cast<uint4 *>(&Ah[row * SLD + kg]) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        *reinterpret_cast<uint4 *>(&Al[row * SLD + kg]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *reinterpret_cast<uint4 *>(&Ah[boff + row * SLD + kg]) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        *reinterpret_cast<uint4 *>(&Al[boff + row * SLD + kg]) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     };
 
     const int wu = wcol * SLD + wkq * 8;   // weights: thread = output column, q = 8-k group (consecutive lanes -> consecutive LDS rows: conflict-free)
     uint16_t *wdst = QT ? (((tid >> 6) & 1) ? Wl : Wh) : ((NJ == 2 || tid < 128) ? Wh : Wl);
 #ifdef DFM_GEMM_STAMP
     unsigned long long gs[4] = {0, 0, 0, 0}, gprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long g_first = gprev;
 #define GSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _n = __builtin_amdgcn_s_memtime(); gs[k] += _n - gprev; gprev = _n; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define GSTAMP(k)
@@ -359,7 +366,21 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
     float bias_r[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bias_r[j] = a.bias ? a.bias[col0 + (wn * NJ + j) * 32 + l31] : 0.f;
+    // Quarter tiles run alone on their CU (launches of fewer workgroups than half the CUs): a K-stage there is ONE round trip to L2 / HBM
+    // (~2 000 cycles, s_memtime stamps at B = 1: profiles/r04_small_gemm_ring.txt) however little it carries, so QD stages are kept in
+    // flight in a static register ring (16 registers per stage) instead of one
+    constexpr int QD = QT ? 4 : 1;
+    float4 rxa0[QD], rxa1[QD];
+    uint4 rw0[QD], rw1[QD];
     GEMM_SPLIT_FETCH(0)
+    if constexpr (QT) {
+        rxa0[0] = xa0; rxa1[0] = xa1; rw0[0] = wh0; rw1[0] = wh1;
+#pragma unroll
+        for (int d = 1; d < QD; ++d) {
+            GEMM_SPLIT_FETCH((d * SK < a.K ? d : 0) * SK)
+            rxa0[d] = xa0; rxa1[d] = xa1; rw0[d] = wh0; rw1[d] = wh1;
+        }
+    }
     // GraphNorm prologue, behind the first stage's loads (its L2 round trip rides under theirs instead of preceding it)
     if (a.pro == 2) {
         if (a.gn_part) {      // finish the statistics here (thread = channel): no separate launch between the two GEMMs
@@ -372,20 +393,7 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
         }
         __syncthreads();
     }
-    for (int k0 = 0; k0 < a.K; k0 += SK) {
-        if (k0) __syncthreads();   // previous stage fully consumed
-        GSTAMP(0)                  // [0] MFMA phase + barrier wait
-        stage_row(xa0, xa1, rv0, k0 + kg, ar);
-        *reinterpret_cast<uint4 *>(&wdst[wu]) = wh0; *reinterpret_cast<uint4 *>(&wdst[wu + 8]) = wh1;
-        if constexpr (!QT) { *reinterpret_cast<uint4 *>(&wdst[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&wdst[wu + 24]) = wh3; }
-        if constexpr (NJ == 2) {
-            *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
-            *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
-        }
-        GSTAMP(1)                  // [1] waiting for the fetched registers + conversion + LDS stores
-        __syncthreads();
-        GSTAMP(2)                  // [2] barrier after staging
-        if (k0 + SK < a.K) GEMM_SPLIT_FETCH(k0 + SK)         // flies under the MFMAs below
+    auto mfma_stage = [&](int boff = 0) {
 #pragma unroll
         for (int ks = 0; ks < SK; ks += 16) {
             const int ko = ks + (lane >> 5) * 8;
@@ -393,15 +401,15 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int r = (wm * MI + i) * 32 + l31;
-                ah[i].u = *reinterpret_cast<const uint4 *>(&Ah[r * SLD + ko]);
-                al[i].u = *reinterpret_cast<const uint4 *>(&Al[r * SLD + ko]);
+                ah[i].u = *reinterpret_cast<const uint4 *>(&Ah[boff + r * SLD + ko]);
+                al[i].u = *reinterpret_cast<const uint4 *>(&Al[boff + r * SLD + ko]);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int c = (wn * NJ + j) * 32 + l31;
                 FragB wh, wl;
-                wh.u = *reinterpret_cast<const uint4 *>(&Wh[c * SLD + ko]);
-                wl.u = *reinterpret_cast<const uint4 *>(&Wl[c * SLD + ko]);
+                wh.u = *reinterpret_cast<const uint4 *>(&Wh[boff + c * SLD + ko]);
+                wl.u = *reinterpret_cast<const uint4 *>(&Wl[boff + c * SLD + ko]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i].b, wh.b, acc[i][j], 0, 0, 0);
@@ -409,6 +417,59 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i].b, wh.b, acc[i][j], 0, 0, 0);
                 }
             }
+        }
+    };
+    if constexpr (QT) {
+        // ... and the operand tiles are double-buffered: stage k + 1 is converted and written (VALU, LDS stores) behind the MFMAs of
+        // stage k in the same instruction stream, one barrier per stage - with a single wave per SIMD nothing else would fill the
+        // matrix pipe's latency (stamps: 800 cycles of staging + 700 of MFMA phase per stage in sequence before)
+        // The loop body is branch-free (the launcher takes this shape only when K / 32 is a multiple of QD; stages past the end are
+        // clamped re-reads of the last one, staged into the idle buffer and never consumed): with a branch around the refill the
+        // compiler's s_waitcnt insertion falls back to vmcnt(0) - it waits for the loads just issued and the ring is worth nothing.
+        const int S = a.K / SK;
+        stage_row(rxa0[0], rxa1[0], rv0, kg, ar, 0);
+        *reinterpret_cast<uint4 *>(&wdst[wu]) = rw0[0]; *reinterpret_cast<uint4 *>(&wdst[wu + 8]) = rw1[0];
+        {
+            GEMM_SPLIT_FETCH((QD < S ? QD : S - 1) * SK)
+            rxa0[0] = xa0; rxa1[0] = xa1; rw0[0] = wh0; rw1[0] = wh1;
+        }
+        __syncthreads();
+        GSTAMP(1)
+        for (int k0 = 0; k0 < S; k0 += QD) {
+#pragma unroll
+            for (int d = 0; d < QD; ++d) {
+                const int k = k0 + d;
+                const int dn = (d + 1) % QD, nb = ((d + 1) & 1) * LDS_BUF;
+                const int kn = k + 1 < S ? k + 1 : S - 1, kf = k + 1 + QD < S ? k + 1 + QD : S - 1;
+                mfma_stage((d & 1) * LDS_BUF);
+                GSTAMP(0)
+                stage_row(rxa0[dn], rxa1[dn], rv0, kn * SK + kg, ar, nb);
+                *reinterpret_cast<uint4 *>(&wdst[nb + wu]) = rw0[dn]; *reinterpret_cast<uint4 *>(&wdst[nb + wu + 8]) = rw1[dn];
+                {      // this slot's next stage: QD - 1 others are already on their way
+                    GEMM_SPLIT_FETCH(kf * SK)
+                    rxa0[dn] = xa0; rxa1[dn] = xa1; rw0[dn] = wh0; rw1[dn] = wh1;
+                }
+                GSTAMP(1)
+                __syncthreads();
+                GSTAMP(2)
+            }
+        }
+    } else {
+        for (int k0 = 0; k0 < a.K; k0 += SK) {
+            if (k0) __syncthreads();   // previous stage fully consumed
+            GSTAMP(0)                  // [0] MFMA phase + barrier wait
+            stage_row(xa0, xa1, rv0, k0 + kg, ar);
+            *reinterpret_cast<uint4 *>(&wdst[wu]) = wh0; *reinterpret_cast<uint4 *>(&wdst[wu + 8]) = wh1;
+            if constexpr (!QT) { *reinterpret_cast<uint4 *>(&wdst[wu + 16]) = wh2; *reinterpret_cast<uint4 *>(&wdst[wu + 24]) = wh3; }
+            if constexpr (NJ == 2) {
+                *reinterpret_cast<uint4 *>(&Wl[wu]) = wl0; *reinterpret_cast<uint4 *>(&Wl[wu + 8]) = wl1;
+                *reinterpret_cast<uint4 *>(&Wl[wu + 16]) = wl2; *reinterpret_cast<uint4 *>(&Wl[wu + 24]) = wl3;
+            }
+            GSTAMP(1)                  // [1] waiting for the fetched registers + conversion + LDS stores
+            __syncthreads();
+            GSTAMP(2)                  // [2] barrier after staging
+            if (k0 + SK < a.K) GEMM_SPLIT_FETCH(k0 + SK)         // flies under the MFMAs below
+            mfma_stage();
         }
     }
     GSTAMP(0)
@@ -553,8 +614,8 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
 #ifdef DFM_GEMM_STAMP
     GSTAMP(3)                      // [3] epilogue
     if (vb == (gridDim.x > 2048 ? 7 * 8 + 1536 : 3) && blockIdx.y == 0 && tid == 0 && a.C) {       // one mid-grid workgroup reports (debug buffer = first floats of ... stderr-free: printf)
-        printf("gemm stamp K=%d Nout=%d pro=%d epi=%d: mfma+barrier %llu  fetch-wait+stage %llu  barrier2 %llu  epilogue %llu cycles\n",
-               a.K, a.Nout, a.pro, a.epi, gs[0], gs[1], gs[2], gs[3]);
+        printf("gemm stamp K=%d Nout=%d pro=%d epi=%d stats=%d gn=%d: entry->loop %llu  mfma+barrier %llu  fetch-wait+stage %llu  barrier2 %llu  epilogue %llu  total %llu cycles (100 MHz ticks x 21 at 2.1 GHz)\n",
+               a.K, a.Nout, a.pro, a.epi, a.stat_part ? 1 : 0, a.gn_part ? 1 : 0, g_first - g_entry, gs[0], gs[1], gs[2], gs[3], gprev - g_entry);
     }
 #endif
 }
@@ -590,7 +651,7 @@ hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint1
             return e ? atoi(e) : -1;
         }();
         const int quarter_max = quarter_env >= 0 ? quarter_env : device_cus() / 2;
-        if ((long long)row_tiles * (a.Nout / 128) < quarter_max) {
+        if ((long long)row_tiles * (a.Nout / 128) < quarter_max && (a.K / 32) % 4 == 0) {      // (the quarter-tile K loop runs four stages per trip)
             const dim3 grid(row_tiles, a.Nout / 64);
             if (half) hipLaunchKernelGGL((k_gemm_split<1, 1, 1>), grid, dim3(256), 0, s, sa);
             else hipLaunchKernelGGL((k_gemm_split<0, 1, 1>), grid, dim3(256), 0, s, sa);
