@@ -233,9 +233,14 @@ __device__ inline uint32_t pack2(__bf16 a, __bf16 b)
 // (B <= 6 at 300+300): a lone workgroup is a serial chain of K-stages whose length follows the bytes and MFMAs of ONE stage (r03 stamps:
 // 970 cycles of MFMA phase + 830 of fetch per stage at 64 x 128), so four times the workgroups with a third of each: node GEMMs
 // 17.9 / 8.7 -> XX / XX us at B = 1 (profiles/r04_small_batch.txt).  Bitwise the same results again.
-template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) void k_gemm_split(GemmSplitArgs sa)
+// RING (= QT): the K loop keeps four stages of loads in flight and double-buffers the operand tiles (see below).  The same loop on the
+// 64 x 128 shape (RING = 1, QT = 0: 176 registers, 62 KiB of LDS) was measured at B = 8 and bought nothing - there the statistics epilogue
+// and the GraphNorm + SiLU staging chains of a lone wave are what a launch waits for (profiles/r04_small_gemm_ring.txt) - and is not instantiated.
+template <int HALF, int NJ, int QT = 0, int RING = QT> __global__ __launch_bounds__(256, RING ? 1 : 3) void k_gemm_split(GemmSplitArgs sa)
 {
     static_assert(!QT || NJ == 1, "quarter tiles: one 32-column tile per wave");
+    static_assert(!RING || NJ == 1, "the register ring is sized for the 64 x 128 and 64 x 64 shapes");
+    static_assert(!QT || RING, "quarter tiles always run the ring");
     constexpr int MI = QT ? 1 : 2;                       // 32-row tiles per wave
     constexpr int SM = 64, SN = QT ? 64 : NJ * 128;      // rows; output columns per workgroup (QT 0: four waves along N, NJ 32-column tiles each)
     const GemmArgs &a = sa.g;
@@ -244,7 +249,7 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
 #endif
     // operand tiles; the epilogue reuses the space as 4 x 9216 B of transposition buffers
     constexpr int LDS_BUF = (2 * SM + 2 * SN) * SLD;      // one set of operand tiles (hi / lo activations, hi / lo weights)
-    constexpr int LDS_OPER = (QT ? 2 : 1) * LDS_BUF, LDS_EPI = 4 * 32 * 72 * 2;      // operand tiles | epilogue staging (4 waves x 32 x ELD floats)
+    constexpr int LDS_OPER = (RING ? 2 : 1) * LDS_BUF, LDS_EPI = 4 * 32 * 72 * 2;      // operand tiles | epilogue staging (4 waves x 32 x ELD floats)
     constexpr int LDS_U16 = LDS_OPER > LDS_EPI ? LDS_OPER : LDS_EPI;
     __shared__ __attribute__((aligned(16))) uint16_t lds[LDS_U16];
     uint16_t *Ah = lds, *Al = lds + SM * SLD, *Wh = lds + 2 * SM * SLD, *Wl = lds + (2 * SM + SN) * SLD;
@@ -369,16 +374,18 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
     // Quarter tiles run alone on their CU (launches of fewer workgroups than half the CUs): a K-stage there is ONE round trip to L2 / HBM
     // (~2 000 cycles, s_memtime stamps at B = 1: profiles/r04_small_gemm_ring.txt) however little it carries, so QD stages are kept in
     // flight in a static register ring (16 registers per stage) instead of one
-    constexpr int QD = QT ? 4 : 1;
+    constexpr int QD = RING ? 4 : 1, RW = QT ? 2 : 4;      // stages in flight; 16-byte weight registers of a stage
     float4 rxa0[QD], rxa1[QD];
-    uint4 rw0[QD], rw1[QD];
+    uint4 rw[QD][RW];
     GEMM_SPLIT_FETCH(0)
-    if constexpr (QT) {
-        rxa0[0] = xa0; rxa1[0] = xa1; rw0[0] = wh0; rw1[0] = wh1;
+#define RING_TAKE(d) { rxa0[d] = xa0; rxa1[d] = xa1; rw[d][0] = wh0; rw[d][1] = wh1; if constexpr (!QT) { rw[d][2] = wh2; rw[d][3] = wh3; } }
+#define RING_WSTORE(d, nb) { _Pragma("unroll") for (int q_ = 0; q_ < RW; ++q_) *reinterpret_cast<uint4 *>(&wdst[(nb) + wu + 8 * q_]) = rw[d][q_]; }
+    if constexpr (RING) {
+        RING_TAKE(0)
 #pragma unroll
         for (int d = 1; d < QD; ++d) {
             GEMM_SPLIT_FETCH((d * SK < a.K ? d : 0) * SK)
-            rxa0[d] = xa0; rxa1[d] = xa1; rw0[d] = wh0; rw1[d] = wh1;
+            RING_TAKE(d)
         }
     }
     // GraphNorm prologue, behind the first stage's loads (its L2 round trip rides under theirs instead of preceding it)
@@ -419,7 +426,7 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
             }
         }
     };
-    if constexpr (QT) {
+    if constexpr (RING) {
         // ... and the operand tiles are double-buffered: stage k + 1 is converted and written (VALU, LDS stores) behind the MFMAs of
         // stage k in the same instruction stream, one barrier per stage - with a single wave per SIMD nothing else would fill the
         // matrix pipe's latency (stamps: 800 cycles of staging + 700 of MFMA phase per stage in sequence before)
@@ -428,10 +435,10 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
         // compiler's s_waitcnt insertion falls back to vmcnt(0) - it waits for the loads just issued and the ring is worth nothing.
         const int S = a.K / SK;
         stage_row(rxa0[0], rxa1[0], rv0, kg, ar, 0);
-        *reinterpret_cast<uint4 *>(&wdst[wu]) = rw0[0]; *reinterpret_cast<uint4 *>(&wdst[wu + 8]) = rw1[0];
+        RING_WSTORE(0, 0)
         {
             GEMM_SPLIT_FETCH((QD < S ? QD : S - 1) * SK)
-            rxa0[0] = xa0; rxa1[0] = xa1; rw0[0] = wh0; rw1[0] = wh1;
+            RING_TAKE(0)
         }
         __syncthreads();
         GSTAMP(1)
@@ -444,10 +451,10 @@ template <int HALF, int NJ, int QT = 0> __global__ __launch_bounds__(256, 3) voi
                 mfma_stage((d & 1) * LDS_BUF);
                 GSTAMP(0)
                 stage_row(rxa0[dn], rxa1[dn], rv0, kn * SK + kg, ar, nb);
-                *reinterpret_cast<uint4 *>(&wdst[nb + wu]) = rw0[dn]; *reinterpret_cast<uint4 *>(&wdst[nb + wu + 8]) = rw1[dn];
+                RING_WSTORE(dn, nb)
                 {      // this slot's next stage: QD - 1 others are already on their way
                     GEMM_SPLIT_FETCH(kf * SK)
-                    rxa0[dn] = xa0; rxa1[dn] = xa1; rw0[dn] = wh0; rw1[dn] = wh1;
+                    RING_TAKE(dn)
                 }
                 GSTAMP(1)
                 __syncthreads();

@@ -441,6 +441,7 @@ def test_narrow_gemm_tiles_equal_wide_tiles_bitwise(tmp_path):
     outs = {}
     # quarter1 / quarter7: 64 x 64 tiles (waves 2 x 2; what launches with fewer 64 x 128 workgroups than half the CUs run), forced at
     # B = 7 too.  The column statistics go out per 32-row half of a tile in every shape.
+    # (quarter tiles run a different K loop - four stages in flight, double-buffered operand tiles - with the same MFMA sequence)
     for tag, env, B in (("wide1", "0", 1), ("narrow1", "1000000", 1), ("wide7", "0", 7), ("narrow7", "1000000", 7), ("quarter1", "1000000", 1),
                         ("quarter7", "1000000", 7)):
         p = subprocess.run([sys.executable, str(script), str(tmp_path / f"{tag}.npz"), str(B)],
