@@ -20,6 +20,7 @@
 
 #include "dfm_device.h"
 #include "dfm_internal.h"
+#include "dfm_edge_knobs.h"
 
 namespace dfm {
 
@@ -227,40 +228,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 union Frag { uint4 u; bf16x8 b; f16x8 f; };
 union H8 { uint4 u; __half2 h[4]; };   // eight fp16 values of one gathered 16-byte chunk
 
-#ifndef DFM_EDGE_BD
-#define DFM_EDGE_BD 2
-#endif
-#ifndef DFM_EDGE_SB
-#define DFM_EDGE_SB 1      // a scheduling barrier after every DFM_EDGE_SB-th MFMA slot of a chunk
-#endif
-// Slots (MFMA index inside a chunk) after which the producer requests the next-but-one chunk's operands.  The vector-memory
-// counter completes in order, so a wait for the YOUNGEST load a slot needs also waits for everything issued before it:
-// the per-chunk constants (A_i, w_r: L1 hits, used from slot 0 of the next chunk) go out BEFORE the second pass's gathers (L2
-// hits, used from slot 8), and both gathers as early as their registers are dead (pass registers die after the pass's slice 0).
-#ifndef DFM_EDGE_G0
-#define DFM_EDGE_G0 7
-#endif
-#ifndef DFM_EDGE_G1
-#define DFM_EDGE_G1 15
-#endif
-#ifndef DFM_EDGE_GC
-#define DFM_EDGE_GC 14
-#endif
 constexpr int LDS_WF_BYTES = 16 * 8 * 64 * 16;     // 131072: bf16 B-fragments of one 256x256 matrix
 constexpr int LDS_STAGE_BYTES = 32 * 64 * 2;       // 4096 per wave: 32 rows x 64 channels bf16
-#ifndef DFM_EDGE_WAVES
-#define DFM_EDGE_WAVES 8
-#endif
 constexpr int EDGE_WAVES = DFM_EDGE_WAVES;         // waves per workgroup: 8 = two per SIMD (256 registers each), 4 = one per SIMD (512)
 constexpr int LDS_EDGE_BYTES = LDS_WF_BYTES + EDGE_WAVES * LDS_STAGE_BYTES;   // 163840 = the whole CU with 8 waves
 
-#ifdef DFM_EDGE_NOPK   // experiment: plain f32 instructions instead of packed pairs (build with -fno-slp-vectorize)
-struct f2 { float x, y; };
-__device__ inline f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
-__device__ inline f2 operator*(f2 a, f2 b) { return {a.x * b.x, a.y * b.y}; }
-#else
 typedef float f2 __attribute__((ext_vector_type(2)));   // packed fp32 pair -> v_pk_{mul,add,fma}_f32 (2 results / instr)
-#endif
 // a + (float)half of a packed fp16 pair in ONE plain-rate instruction (v_fma_mix_f32: f16 source 0 times 1.0 plus f32 source 2);
 // hipcc otherwise emits v_cvt_f32_f16 x2 + v_pk_add_f32, twice the issue time (tools/ubench/valu_rate.hip)
 __device__ inline float add_half_lo(float a, uint32_t h2)
@@ -403,9 +376,6 @@ __device__ inline float4 bload16f(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint
 }
 // Streams that pass through once (A_i rows, edge data, agg / message stores) carry the non-temporal hint, so that they do not
 // push the lookup tables and the re-gathered Bm rows out of the XCD's 4 MiB L2 (cache-policy bit 1 of the buffer instructions)
-#ifndef DFM_EDGE_NT
-#define DFM_EDGE_NT 1
-#endif
 constexpr int AUX_STREAM = DFM_EDGE_NT ? 2 : 0;
 __device__ inline float4 bload16f_stream(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
 {
@@ -768,12 +738,6 @@ __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
 // and requests that tile's chunk 1, which flies under this tile's epilogue; the next tile starts straight at its first MFMA.  The
 // wave walks its (node, tile) sequence with a one-tile lookahead; after the last tile the lookahead repeats that tile (valid
 // addresses, results never used) so that the loop body has no tail variant.
-#ifndef DFM_EDGE_MSTORE_LDS   // last layer: gated messages transposed through the wave's staging buffer (1) or stored as 2-byte scatters (0)
-#define DFM_EDGE_MSTORE_LDS 1
-#endif
-#ifndef DFM_EDGE_DEFER      // requests of the next tile's chunk 1 issued after the epilogue instead of under chunk 7: 0 none, 1 A_i / w_r, 2 + second pass
-#define DFM_EDGE_DEFER 2
-#endif
 // AW16: A_i comes as fp16 (one 16-byte load per chunk instead of two; bf16 operands only).  w_r stays fp32: its product with the
 // radial |x_i - x_j|^2 (thousands of A^2) is the one large term of the pre-activation, and an fp16 w_r moved the worst force
 // deviation of the bf16 engine from 7.2e-3 to 8.8e-3
@@ -924,12 +888,6 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
 #undef FAKE4
 #else
     auto gather_chunk = [&](int c) {
-#ifdef DFM_EDGE_DENSE_UB
-        if constexpr (AW16) a1 = bload16f_stream(rs_a, c4 * 16 + ((i + 1 < p.N) ? H * 2 : 0), c * 64);      // the next node's row
-#endif
-#ifndef DFM_EDGE_A_NT      // 1: the A_i row carries the non-temporal hint like the single-pass streams; 0 (shipped): cached - the node's second
-#define DFM_EDGE_A_NT 0     // tile and the other half of each 128-byte line re-read it: 2.187 vs 2.221 ms per launch, same box
-#endif
         if constexpr (ROWS) { a0 = bload16f(rs_a, oa[0], c * 64); a1 = bload16f(rs_a, oa[1], c * 64); }      // a row of A per pass
         else if constexpr (AW16) a0 = DFM_EDGE_A_NT ? bload16f_stream(rs_a, c4 * 16, c * 64) : bload16f(rs_a, c4 * 16, c * 64);
         else { a0 = bload16f_stream(rs_a, oc4, c * 128); a1 = bload16f_stream(rs_a, oc4, c * 128 + 16); }
@@ -971,11 +929,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         if ((k & 1) == 0) {
             const f2 wv = e == 0 ? (f2){w0.x, w0.y} : (e == 1 ? (f2){w0.z, w0.w} : (e == 2 ? (f2){w1.x, w1.y} : (f2){w1.z, w1.w}));
             if constexpr (AW16) {      // w * radial (fp32) + a (fp16), one v_fma_mix_f32 per channel
-#ifdef DFM_EDGE_DENSE_UB
-                const float4 &aq = q == 1 ? a1 : a0;
-#else
                 const float4 &aq = (ROWS && q == 1) ? a1 : a0;
-#endif
                 const uint32_t ah = __float_as_uint(e == 0 ? aq.x : (e == 1 ? aq.y : (e == 2 ? aq.z : aq.w)));
                 pv[e] = (f2){fma_half_lo(wv.x, radq[q], ah), fma_half_hi(wv.y, radq[q], ah)};
             } else {
@@ -1049,11 +1003,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         unsigned ntt = tt;
         int nb = b, ni = i, nmt = mt + 1;
         bool have_next = true;
-#if defined(DFM_EDGE_DENSE_UB) && DFM_EDGE_DENSE_UB == 1     // diagnostic (wrong results): 15 tiles per 8 nodes, the tile count of dense row packing (8 x 60 rows = 15 x 32); 2: only the extra A_i load of that scheme
-        if (split || nmt == (((((i >> 3) + (i >> 6) + i) & 7) == 7) ? 1 : ntile)) {
-#else
         if (split || nmt == ntile) {
-#endif
             ntt = tt + tstride;
             have_next = next_task(ntt, nb, ni, nmt);
         }
@@ -1250,11 +1200,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             asm volatile("" : "+v"(xt));
             colsum[nt] += xt;
         }
-#if defined(DFM_EDGE_DENSE_UB) && DFM_EDGE_DENSE_UB == 1
-        if (split || mt == (((((i >> 3) + (i >> 6) + i) & 7) == 7) ? 0 : ntile - 1)) {
-#else
         if (split || mt == ntile - 1) {
-#endif
             float *out = p.agg + ((size_t)b * p.N + i) * H + l31;
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
