@@ -13,6 +13,7 @@ for k in pmc_all pmc_knn_c5; do cp $F/$k.txt profiles/${T}_$k.txt; done
 tail -4 $F/pytest_gpu.log > profiles/${T}_pytest_gpu.txt
 cp $F/size_sweep.txt profiles/${T}_size_sweep.txt
 cp $F/small_batches.txt profiles/${T}_small_batches.txt
+cp $F/b1_profile.txt profiles/${T}_b1_profile.txt; cp $F/b8_profile.txt profiles/${T}_b8_profile.txt
 cp $F/traffic_summary.txt profiles/${T}_traffic_summary.txt
 cp $F/tol_report.txt profiles/${T%_*}_tol_report.txt
 cp $F/traffic.json profiles/${T%_*}_traffic.json      # the file bench.py replays into roofline.traffic / mfma_busy / valu_busy / kernels

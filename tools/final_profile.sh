@@ -2,7 +2,7 @@
 # Round-end evidence run on the GPU box (every step under its own timeout, outputs under gpurun_out/final/, copied into profiles/ by
 # tools/copy_evidence.sh):
 #   full GPU test suite | default bench line (with cpu_baseline and the fp32 secondary line) | rocprofv3 --kernel-trace --stats of the
-#   same bench command | counters of EVERY kernel of the step evaluation in one set of passes (FETCH_SIZE / WRITE_SIZE in separate
+#   same bench command | kernel profiles at B = 1 and B = 8 | counters of EVERY kernel of the step evaluation in one set of passes (FETCH_SIZE / WRITE_SIZE in separate
 #   --pmc passes, SQ busy counters; no trace domains) -> traffic JSON that bench.py replays (per launch type of the message kernel,
 #   per-kernel table) | counters of k_knn_sample at C5 | C5 kernel stats | second model family | tolerance report | size sweeps
 cd $GRAFT_REPO_ROOT; OUT=$GRAFT_REPO_ROOT/gpurun_out/final; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
@@ -34,3 +34,4 @@ prof pair python $GRAFT_REPO_ROOT/tools/pair_bench.py 256; tail -4 $OUT/pair.log
 timeout 900 python tools/tol_report.py > $OUT/tol_report.txt 2>&1; grep -E "^draw" $OUT/tol_report.txt | cut -c1-110
 timeout 600 python tools/size_sweep.py > $OUT/size_sweep.txt 2>&1; cat $OUT/size_sweep.txt
 timeout 300 python tools/graph_ab.py 1 8 40 120 > $OUT/small_batches.txt 2>&1; cat $OUT/small_batches.txt
+bash tools/b1_profile.sh > $OUT/b1_profile.txt 2>&1; BATCH=8 bash tools/b1_profile.sh > $OUT/b8_profile.txt 2>&1; tail -3 $OUT/b1_profile.txt
