@@ -289,6 +289,21 @@ template <int HALF, int NJ, int QT = 0, int RING = QT> __global__ __launch_bound
             for (int q = 0; q < SN / 16; ++q) z[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    // The residual tile, touched now (one dword per 128-byte line): the epilogue's loads of it then hit L2 instead of paying a round trip to
+    // HBM at the end of the workgroup, where nothing is left to hide it.  Ordinary loads (the compiler's vmcnt bookkeeping covers them),
+    // kept alive without arithmetic by an empty asm before the epilogue.
+    // Quarter tiles only: at the 64 x 128 shape (B = 8) the epilogue got slower with it, and the 64 x 256 launches lose 2.5 %.
+    constexpr int LPR = SN * 4 / 128, NTOUCH = QT ? (SM * LPR + 255) / 256 : 0;      // lines per tile row; lines per thread
+    float touch[NTOUCH + 1];
+#pragma unroll
+    for (int q = 0; q < NTOUCH; ++q) {
+        touch[q] = 0.f;
+        const int t = tid + q * 256, row = row0 + t / LPR;
+        if (a.epi == 1 && t < SM * LPR && row < row_end) {
+            const int rrow = a.r_period ? row % a.r_period : row;
+            touch[q] = a.R[(size_t)rrow * a.ldc + col0 + (t % LPR) * 32];
+        }
+    }
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -479,6 +494,8 @@ template <int HALF, int NJ, int QT = 0, int RING = QT> __global__ __launch_bound
             mfma_stage();
         }
     }
+#pragma unroll
+    for (int q = 0; q < NTOUCH; ++q) asm volatile("" :: "v"(touch[q]));
     GSTAMP(0)
     // epilogue: the C layout (lane = column, registers = rows) would need scalar stores, and the kernel is then bound
     // by store issue.  Each wave instead transposes its outputs through a private LDS region (the operand tiles are
@@ -596,19 +613,30 @@ template <int HALF, int NJ, int QT = 0, int RING = QT> __global__ __launch_bound
             const int sub = (vb % tpt64) * 2 + wm * MI + i;
             float *sp = a.stat_part + ((size_t)(vb / tpt64) * tpt32 + sub) * (H * 2);
             const float inv_n = st_n[i] > 0.f ? 1.0f / st_n[i] : 0.f;
+            // the four row groups (er) of a column, merged in a fixed order (Chan).  The counts are the same for the lane's four columns:
+            // their exchange and the weight n2 / (n + n2) of each level are computed once (values unchanged: the same expression), and
+            // the merge is branch-free (an empty partner enters with weight 0) so that the 16 exchanges of a half pipeline - at small
+            // launches this block is exposed at the end of every workgroup (14 k cycles of node_mlp.0 at B = 8 before)
+            float nl[2], fl[2];
+            {
+                float ne = st_n[i];
+#pragma unroll
+                for (int lv = 0; lv < 2; ++lv) {
+                    const float n2 = __shfl_xor(ne, 16 << lv, 64), nt = ne + n2;
+                    nl[lv] = ne;
+                    fl[lv] = nt > 0.f ? n2 / nt : 0.f;
+                    ne = nt;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float mean = st_p[i][e] + st_s[i][e] * inv_n, M2 = st_q[i][e] - st_s[i][e] * st_s[i][e] * inv_n, ne = st_n[i];
+                float mean = st_p[i][e] + st_s[i][e] * inv_n, M2 = st_q[i][e] - st_s[i][e] * st_s[i][e] * inv_n;
 #pragma unroll
-                for (int m = 16; m <= 32; m <<= 1) {      // the four row groups (er) of a column, merged in a fixed order (Chan)
-                    const float n2 = __shfl_xor(ne, m, 64), mean2 = __shfl_xor(mean, m, 64), M22 = __shfl_xor(M2, m, 64);
-                    const float nt = ne + n2;
-                    if (nt > 0.f) {
-                        const float d = mean2 - mean, f = n2 / nt;
-                        mean += d * f;
-                        M2 += M22 + d * d * ne * f;
-                    }
-                    ne = nt;
+                for (int lv = 0; lv < 2; ++lv) {
+                    const float mean2 = __shfl_xor(mean, 16 << lv, 64), M22 = __shfl_xor(M2, 16 << lv, 64);
+                    const float d = mean2 - mean, f = fl[lv];
+                    mean += d * f;
+                    M2 += M22 + d * d * nl[lv] * f;
                 }
                 if (er == 0 && ec < NJ * 32 && sub < tpt32) {       // only this lane's merge order is ever read: deterministic, the same for every trajectory
                     const int c = col0 + wn * (NJ * 32) + ec + e;
