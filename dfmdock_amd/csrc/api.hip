@@ -103,6 +103,7 @@ struct Workspace {
     // layer 0 behind the message table (allocated on first use): per edge the source of its gated message, the row list of the
     // edges the edge model still evaluates, their messages, the list's length and the running total for the profile
     uint32_t *l0_src = nullptr; uint4 *l0_rows = nullptr; uint16_t *l0_x = nullptr; uint32_t *l0_counter = nullptr;
+    float *l0_x32 = nullptr;      // fp32 engine: the row list's messages (1 KiB per row)
     unsigned long long *l0_miss_total = nullptr;
     // replayed step graph: {evaluations started, seed lo, seed hi, -} and the per-step scalars of the call's time grid
     uint32_t *step_ctl = nullptr; StepParams *step_params = nullptr;
@@ -129,9 +130,10 @@ struct dfm_complex {
     uint32_t fwd_counter = 0;
     // layer-0 message table of the 16-bit engine (kernels_edge.hip: k_l0_gather): gated messages of every intra-chain ordered pair
     // [R*R + L*L][256] fp16 and the feature code each entry was built with; rebuilt after set_pose / set_homomer
-    DevPool l0_pool;
+    DevPool l0_pool, l0_pool32;
     uint16_t *l0_table = nullptr; uint32_t *l0_code0 = nullptr;
     bool l0_valid = false;
+    float *l0_table32 = nullptr; uint32_t *l0_code0_32 = nullptr; bool l0_valid32 = false;      // the fp32 engine's table (1 KiB per pair)
     std::vector<hipEvent_t> ev_l0;   // profiling events of the table path (triples: before rows | between | after gather)
     size_t ev_l0_used = 0;
     // One step of dfm_sample (score evaluation + heads + Euler-Maruyama update [+ clash force]) captured as a hipGraph and replayed
@@ -586,7 +588,7 @@ extern "C" int dfm_complex_set_pose(dfm_complex *cx, const float *rec_pos, const
     HIPCHK(hipStreamSynchronize(cx->stream));
     if (rec_pos) HIPCHK(hipMemcpy(cx->rec_pos, rec_pos, (size_t)cx->R * 9 * sizeof(float), hipMemcpyHostToDevice));
     if (lig_pos) HIPCHK(hipMemcpy(cx->lig0, lig_pos, (size_t)cx->L * 9 * sizeof(float), hipMemcpyHostToDevice));
-    cx->l0_valid = false;      // the intra-chain geometry may have changed: the layer-0 message table is rebuilt on next use
+    cx->l0_valid = false; cx->l0_valid32 = false;      // the intra-chain geometry may have changed: the layer-0 message tables are rebuilt on next use
     return DFM_OK;
 }
 
@@ -602,7 +604,7 @@ extern "C" int dfm_complex_set_homomer(dfm_complex *cx, int flag)
     // usable and a retry with the same flag does the work again instead of returning DFM_OK on stale operands
     const int old = cx->homomer;
     cx->homomer = flag;
-    cx->l0_valid = false;      // A0 carries the flag's bias: the layer-0 message table is rebuilt on next use
+    cx->l0_valid = false; cx->l0_valid32 = false;      // A0 carries the flag's bias: the layer-0 message tables are rebuilt on next use
     hipError_t e = project_layer0(cx);
     if (e == hipSuccess) e = hipStreamSynchronize(cx->stream);
     if (e != hipSuccess) {
@@ -639,7 +641,8 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
         return fail(DFM_E_INVALID, "B * N * K * 4 must stay below 2^31: split the batch");
     const bool wants_mbuf = bf16 && cx->m->hp.family == 0;    // gated messages for the coordinate MLP (family 0 only)
     const bool need_mbuf = wants_mbuf && !W.mbuf;
-    if (B <= W.Bcap && !need_mbuf && !(l0 && !W.l0_src)) return DFM_OK;
+    const bool need_l0 = l0 && (!W.l0_src || (bf16 ? !W.l0_x : !W.l0_x32));
+    if (B <= W.Bcap && !need_mbuf && !need_l0) return DFM_OK;
     if (B > W.Bcap) {
         HIPCHK(hipStreamSynchronize(cx->stream));
         W.pool.release();
@@ -670,14 +673,17 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
         W.Bcap = B;
     }
     if (wants_mbuf && !W.mbuf) { HIPCHK(W.pool.alloc(&W.mbuf, (size_t)W.Bcap * cx->L * KPAD * H)); cx->buf_gen++; }
-    if (l0 && !W.l0_src) {
-        cx->buf_gen++;
+    if (l0) {
         const size_t cap = (size_t)W.Bcap * cx->N * cx->K;      // every edge of a batched evaluation may miss the table
-        HIPCHK(W.pool.alloc(&W.l0_src, cap)); HIPCHK(W.pool.alloc(&W.l0_rows, cap));
-        HIPCHK(W.pool.alloc(&W.l0_x, (cap + 32) * H));          // the last tile of the row list stores all of its 32 rows
-        HIPCHK(W.pool.alloc(&W.l0_counter, 1)); HIPCHK(W.pool.alloc(&W.l0_miss_total, 1));
-        HIPCHK(hipMemsetAsync(W.l0_counter, 0, sizeof(uint32_t), cx->stream));
-        HIPCHK(hipMemsetAsync(W.l0_miss_total, 0, sizeof(unsigned long long), cx->stream));
+        if (!W.l0_src) {
+            cx->buf_gen++;
+            HIPCHK(W.pool.alloc(&W.l0_src, cap)); HIPCHK(W.pool.alloc(&W.l0_rows, cap));
+            HIPCHK(W.pool.alloc(&W.l0_counter, 1)); HIPCHK(W.pool.alloc(&W.l0_miss_total, 1));
+            HIPCHK(hipMemsetAsync(W.l0_counter, 0, sizeof(uint32_t), cx->stream));
+            HIPCHK(hipMemsetAsync(W.l0_miss_total, 0, sizeof(unsigned long long), cx->stream));
+        }
+        if (bf16 && !W.l0_x) { cx->buf_gen++; HIPCHK(W.pool.alloc(&W.l0_x, (cap + 32) * H)); }      // the last tile of the row list stores all of its 32 rows
+        if (!bf16 && !W.l0_x32) { cx->buf_gen++; HIPCHK(W.pool.alloc(&W.l0_x32, cap * H)); }      // fp32 engine: only the list's own rows are stored
     }
     return DFM_OK;
 }
@@ -695,29 +701,47 @@ static EdgeArgs layer0_edge_args(const dfm_complex *cx)
 // Builds the layer-0 message table of the complex: every intra-chain ordered pair (i, j) through the edge model once, features from
 // the stored pose (any rigid placement of the ligand gives the same intra-chain geometry; k_edge_feat checks the bins per pose).
 // Uses trajectory slot 0 of the workspace (ensure_workspace first) and overwrites ws.lig_cur's first pose.  Synchronises.
-static int build_l0_table(dfm_complex *cx, float *build_ms)
+static EdgeArgs layer0_edge_args32(const dfm_complex *cx)      // fp32 engine: the complex's own fp32 A0 / Bm0
+{
+    EdgeArgs e;
+    std::memset(&e, 0, sizeof(e));
+    e.A = cx->A0; e.Bm = cx->Bm0; e.Bmb = cx->Bmb0; e.ab_bstride = 0;
+    e.B = 1; e.N = cx->N; e.R = cx->R; e.K = cx->K; e.lw = &cx->m->layers[0];
+    return e;
+}
+
+static int build_l0_table(dfm_complex *cx, float *build_ms, bool fp32 = false)
 {
     Workspace &W = cx->ws;
     hipStream_t s = cx->stream;
     const size_t R = cx->R, L = cx->L, P = R * R + L * L;
-    cx->l0_valid = false;
+    (fp32 ? cx->l0_valid32 : cx->l0_valid) = false;
     HIPCHK(hipStreamSynchronize(s));
-    cx->l0_pool.release();
+    (fp32 ? cx->l0_pool32 : cx->l0_pool).release();
     cx->buf_gen++;
-    HIPCHK(cx->l0_pool.alloc(&cx->l0_table, ((P + 31) / 32 * 32) * H));
-    HIPCHK(cx->l0_pool.alloc(&cx->l0_code0, P));
+    uint32_t *code0 = nullptr;
+    if (fp32) {
+        HIPCHK(cx->l0_pool32.alloc(&cx->l0_table32, P * H));
+        HIPCHK(cx->l0_pool32.alloc(&cx->l0_code0_32, P));
+        code0 = cx->l0_code0_32;
+    } else {
+        HIPCHK(cx->l0_pool.alloc(&cx->l0_table, ((P + 31) / 32 * 32) * H));
+        HIPCHK(cx->l0_pool.alloc(&cx->l0_code0, P));
+        code0 = cx->l0_code0;
+    }
     DevPool tmp;
     uint4 *rows = nullptr;
     HIPCHK(tmp.alloc(&rows, P));
     HIPCHK(hipEventRecord(cx->ev_total[0], s));
     HIPCHK(hipMemcpyAsync(W.lig_cur, cx->lig0, L * 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(launch_prep_pose(cx->rec_pos, W.lig_cur, 1, cx->R, cx->L, cx->m->hp.family == 1 ? 1 : 0, W.pos, W.ca4, W.cb4, s));
-    HIPCHK(launch_l0_pairs(W.pos, W.ca4, W.cb4, cx->R, cx->L, cx->m->hp.mask_dist, cx->l0_code0, rows, s));
-    HIPCHK(launch_edge_rows(layer0_edge_args(cx), rows, nullptr, (uint32_t)P, cx->l0_table, s));
+    HIPCHK(launch_l0_pairs(W.pos, W.ca4, W.cb4, cx->R, cx->L, cx->m->hp.mask_dist, code0, rows, s));
+    if (fp32) HIPCHK(launch_edge_rows32(layer0_edge_args32(cx), rows, nullptr, (uint32_t)P, cx->l0_table32, s));
+    else HIPCHK(launch_edge_rows(layer0_edge_args(cx), rows, nullptr, (uint32_t)P, cx->l0_table, s));
     HIPCHK(hipEventRecord(cx->ev_total[1], s));
     HIPCHK(hipStreamSynchronize(s));
     if (build_ms) HIPCHK(hipEventElapsedTime(build_ms, cx->ev_total[0], cx->ev_total[1]));
-    cx->l0_valid = true;
+    (fp32 ? cx->l0_valid32 : cx->l0_valid) = true;
     return DFM_OK;
 }
 
@@ -821,7 +845,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
     }
     L0Classify cls;
     std::memset(&cls, 0, sizeof(cls));
-    if (o.l0_table) { cls.code0 = cx->l0_code0; cls.src = W.l0_src; cls.rows = W.l0_rows; cls.counter = W.l0_counter; }
+    if (o.l0_table) { cls.code0 = o.bf16 ? cx->l0_code0 : cx->l0_code0_32; cls.src = W.l0_src; cls.rows = W.l0_rows; cls.counter = W.l0_counter; }
     HIPCHK(launch_edge_feat(W.pos, W.ca4, W.cb4, W.edges, B, N, R, K, m->hp.mask_dist, W.codes, W.radial, cls, o.ctl, s));
     // layer 0 reads the node embedding h0 [N][256] of the complex itself - identical for every trajectory - through a row period
     // (GemmArgs::a0_period / r_period) instead of a [B][N][256] copy made per evaluation (r01-r03: k_bcast_rows, 157 MB of writes at C3)
@@ -898,9 +922,11 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
                     t0 = cx->ev_l0[cx->ev_l0_used++]; t1 = cx->ev_l0[cx->ev_l0_used++]; t2 = cx->ev_l0[cx->ev_l0_used++];
                     HIPCHK(hipEventRecord(t0, s));
                 }
-                HIPCHK(launch_edge_rows(e, W.l0_rows, W.l0_counter, (uint32_t)((size_t)B * N * K), W.l0_x, s));
+                if (o.bf16) HIPCHK(launch_edge_rows(e, W.l0_rows, W.l0_counter, (uint32_t)((size_t)B * N * K), W.l0_x, s));
+                else HIPCHK(launch_edge_rows32(e, W.l0_rows, W.l0_counter, (uint32_t)((size_t)B * N * K), W.l0_x32, s));
                 if (o.profile) HIPCHK(hipEventRecord(t1, s));
-                HIPCHK(launch_l0_gather(cx->l0_table, W.l0_x, W.l0_src, W.agg, B, N, K, W.l0_counter, W.l0_miss_total, s));
+                if (o.bf16) HIPCHK(launch_l0_gather(cx->l0_table, W.l0_x, W.l0_src, W.agg, B, N, K, W.l0_counter, W.l0_miss_total, s));
+                else HIPCHK(launch_l0_gather32(cx->l0_table32, W.l0_x32, W.l0_src, W.agg, B, N, K, W.l0_counter, W.l0_miss_total, s));
                 if (o.profile) {
                     HIPCHK(hipEventRecord(t2, s));
                     cx->prof.l0_evals += 1; cx->prof.l0_edges += (int64_t)B * N * K;
@@ -1071,8 +1097,8 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     DEVICE_SCOPE(cx->device);
     // layer 0 through the message table: on request only (dfm_score stays a pure function of its arguments and flags)
     const bool l0 = (flags & DFM_F_L0_TABLE) != 0;
-    if (l0 && !(bf16 && !f16 && !(flags & DFM_F_BF16_OPS) && l0_eligible(cx, B)))
-        return fail(DFM_E_INVALID, "DFM_F_L0_TABLE needs the DFM_F_MFMA16 engine (no DFM_F_F16 / DFM_F_BF16_OPS), depth >= 2 and a complex / batch within the table budgets");
+    if (l0 && !(((bf16 && !f16 && !(flags & DFM_F_BF16_OPS)) || !bf16) && l0_eligible(cx, B)))
+        return fail(DFM_E_INVALID, "DFM_F_L0_TABLE needs the fp32 or the DFM_F_MFMA16 engine (no DFM_F_F16 / DFM_F_BF16_OPS), depth >= 2 and a complex / batch within the table budgets");
     int rc = ensure_workspace(cx, B, bf16, l0);
     if (rc) return rc;
     Workspace &W = cx->ws;
@@ -1082,9 +1108,9 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     cx->ev_used = 0; cx->ev_l0_used = 0;
     cx->fwd_counter = 0;   // RNG streams are a pure function of (seed, trajectory, evaluation index)
     if (l0) {
-        if (!cx->l0_valid) {
+        if (!(bf16 ? cx->l0_valid : cx->l0_valid32)) {
             float bms = 0.f;
-            if ((rc = build_l0_table(cx, &bms)) != DFM_OK) return rc;
+            if ((rc = build_l0_table(cx, &bms, !bf16)) != DFM_OK) return rc;
             cx->prof.l0_build_ms = bms;
         }
         HIPCHK(hipMemsetAsync(W.l0_miss_total, 0, sizeof(unsigned long long), s));
@@ -1190,7 +1216,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     DEVICE_SCOPE(cx->device);
     // layer 0 through the complex's message table whenever the shipped 16-bit plan runs and the complex is eligible - a property of
     // the complex, not of the batch (below the edge budget), so a trajectory's result does not depend on the batch it is sampled in
-    const bool l0 = bf16 && !f16 && !(flags & (DFM_F_BF16_OPS | DFM_F_NO_L0_TABLE)) && l0_eligible(cx, B);
+    const bool l0 = ((bf16 && !f16 && !(flags & DFM_F_BF16_OPS)) || !bf16) && !(flags & DFM_F_NO_L0_TABLE) && l0_eligible(cx, B);
     int rc = ensure_workspace(cx, B, bf16, l0);
     if (rc) return rc;
     Workspace &W = cx->ws;
@@ -1201,9 +1227,9 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     cx->ev_used = 0; cx->ev_l0_used = 0;
     cx->fwd_counter = 0;   // evaluation i of this call draws its graph from Philox stream i
     if (l0) {
-        if (!cx->l0_valid) {
+        if (!(bf16 ? cx->l0_valid : cx->l0_valid32)) {
             float bms = 0.f;
-            if ((rc = build_l0_table(cx, &bms)) != DFM_OK) return rc;
+            if ((rc = build_l0_table(cx, &bms, !bf16)) != DFM_OK) return rc;
             cx->prof.l0_build_ms = bms;
         }
         HIPCHK(hipMemsetAsync(W.l0_miss_total, 0, sizeof(unsigned long long), s));

@@ -215,6 +215,10 @@ bool edge_msg_tile_tasks(int B, int N, int K);   // does launch_edge_bf16 run ti
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s);
 // row-list form of the message kernel and the slot-order gather-sum of layer 0 behind the message table (kernels_edge.hip)
 hipError_t launch_edge_rows(const EdgeArgs &a, const uint4 *rows, const uint32_t *n_rows_dev, uint32_t n_rows_cap, uint16_t *out, hipStream_t s);
+// fp32 engine: the same over k_edge_f32m<1> (fp32 rows, 1 KiB each) and the gather-sum of fp32 rows
+hipError_t launch_edge_rows32(const EdgeArgs &a, const uint4 *rows, const uint32_t *n_rows_dev, uint32_t n_rows_cap, float *out, hipStream_t s);
+hipError_t launch_l0_gather32(const float *table, const float *X, const uint32_t *src, float *agg, int B, int N, int K,
+                              uint32_t *counter, unsigned long long *miss_total, hipStream_t s);
 hipError_t launch_l0_gather(const uint16_t *table, const uint16_t *X, const uint32_t *src, float *agg, int B, int N, int K,
                             uint32_t *counter, unsigned long long *miss_total, hipStream_t s);
 

@@ -65,6 +65,7 @@ struct EdgeKArgs {
     const uint32_t *n_rows_dev;  // row count on the device (filled by k_edge_feat's classification), or nullptr: n_rows
     uint32_t n_rows;
     uint16_t *rows_out;
+    float *rows_out32;           // k_edge_f32m<1>: gated messages of the row list, row-major fp32 [row][256]
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -422,13 +423,16 @@ __device__ inline f2 silu2s(f2 x)
 constexpr int FM_LD = 129;                       // floats per k-row of the m1 staging ([k][128 rows] + 1)
 constexpr int FM_W_FLOATS = 32 * 256;            // one weight chunk
 constexpr int FM_M_FLOATS = 32 * FM_LD;          // one staging chunk
-constexpr int LDS_F32M_BYTES = (2 * FM_W_FLOATS + 2 * FM_M_FLOATS + 4 * 256 + 16 + 3 * 128) * 4;
+constexpr int LDS_F32M_BYTES = (2 * FM_W_FLOATS + 2 * FM_M_FLOATS + 4 * 256 + 16 + 4 * 128) * 4;
 
 // SiLU on the hardware's 1-ulp exp2 / rcp: x / (1 + exp2(-x log2 e)), ~3 ulp; saturates correctly (exp2 -> inf: x * 0; -> 0: x * 1).
 // silu_exact (expf + IEEE division, ~35 instructions) cost the kernel more VALU time than its MFMAs take
 __device__ inline float silu_f32m(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x)); }
 
-__global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
+// ROWS = 1 (layer 0 of the fp32 engine behind the per-complex message table, like k_edge_msg<1,1,1> for the 16-bit engine): a workgroup takes
+// 128 consecutive rows of a flat edge list (i, j, code, radial per row; A_i gathered per row), and the gated messages go out row-major in
+// fp32 instead of being summed per node.  No coordinate MLP (layer 0 is never the last layer on this path).
+template <int ROWS> __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *Ws = reinterpret_cast<float *>(smem);              // [2][32][256]
@@ -438,6 +442,7 @@ __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
     int *s_j = reinterpret_cast<int *>(s_cp + 16);            // [128]
     uint32_t *s_code = reinterpret_cast<uint32_t *>(s_j + 128);
     float *s_rad = reinterpret_cast<float *>(s_code + 128);
+    int *s_i = reinterpret_cast<int *>(s_rad + 128);          // [128] row-list form: the row's own node
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
     const int K = p.K;
@@ -458,7 +463,17 @@ __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
         b = (int)(tt / p.nodes); i = p.node0 + (int)(tt % p.nodes);
         return valid;
     };
-    if (tid < 128) {
+    uint32_t n_rows = 0;
+    const uint32_t row_base = 128u * blockIdx.x;
+    if constexpr (ROWS) {
+        n_rows = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p.n_rows_dev ? *p.n_rows_dev : p.n_rows));
+        if (row_base >= n_rows) return;      // the launch is sized for the list's capacity
+        if (tid < 128) {      // rows past the end repeat the last row (valid addresses, finite values; gated off and never stored)
+            const uint32_t r = row_base + (uint32_t)tid;
+            const uint4 rec = p.rows[r < n_rows ? r : n_rows - 1u];
+            s_i[tid] = (int)rec.x; s_j[tid] = (int)rec.y; s_code[tid] = rec.z; s_rad[tid] = __uint_as_float(rec.w);
+        }
+    } else if (tid < 128) {
         int b, i;
         const bool valid = node_of(tid >> 6, b, i);
         const int s = tid & 63;
@@ -474,15 +489,17 @@ __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
     // cycles per chunk as the MFMAs).  LDS stores [k][row] with stride 129: bank (4 x + e + y) % 32 over lanes (x = tid & 7, y = tid / 8)
     // is conflict-free within each 32-lane pass.
     const int pr8 = tid >> 3, pch = (tid & 7) * 4;
-    uint32_t oA[2], oBm[4], oT[5][4];
+    constexpr int NA = ROWS ? 4 : 2;      // A_i rows a thread reads per chunk: one per row (list) or one per node (two nodes per workgroup)
+    uint32_t oA[NA], oBm[4], oT[5][4];
     float prad[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = it * 32 + pr8;
-        int nb, ni;
-        node_of(row >> 6, nb, ni);
-        const uint32_t ab = (uint32_t)((size_t)nb * p.ab_bstride);
-        if ((it & 1) == 0) oA[it >> 1] = ab + (uint32_t)ni * H + pch;
+        int nb = 0, ni = 0;
+        if constexpr (ROWS) ni = s_i[row]; else node_of(row >> 6, nb, ni);
+        const uint32_t ab = ROWS ? 0u : (uint32_t)((size_t)nb * p.ab_bstride);      // (the list's operands are the complex's own: no batch stride)
+        if constexpr (ROWS) oA[it] = (uint32_t)ni * H + pch;
+        else if ((it & 1) == 0) oA[it >> 1] = ab + (uint32_t)ni * H + pch;
         oBm[it] = ab + (uint32_t)s_j[row] * H + pch;
         const uint32_t code = s_code[row];
         oT[0][it] = (code & 63u) * H + pch; oT[1][it] = (40u + ((code >> 6) & 31u)) * H + pch;
@@ -492,7 +509,7 @@ __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
     }
     float pre_max = 0.f, acc_max = 0.f;      // range telemetry (p.range)
 
-    float4 oa[2], ob[4], ot[5][4], ow;      // operands of the m1 chunk in flight (4 rows x 4 channels)
+    float4 oa[NA], ob[4], ot[5][4], ow;      // operands of the m1 chunk in flight (4 rows x 4 channels)
     // weight chunk c of Wt ([256 k][256 n] fp32) straight from global memory into LDS buffer `buf` (global_load_lds_dwordx4: no
     // registers in between - 32 of them spilled otherwise; a wave's 64 lanes fill 1 KiB of contiguous LDS per instruction).  The
     // caller waits for vmcnt(0) before the barrier that publishes the buffer.
@@ -507,26 +524,27 @@ __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
     };
     auto wait_w = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     // the 29 operand loads of a chunk, one per call (j = 0 .. 28): w_r, A_i of the two nodes, then per row Bm_j and five table rows
+    constexpr int NOPS = 1 + NA + 24;      // operand loads of a chunk
     auto fetch_op1 = [&](int c, int j) {
         const int k0 = c * 32;
         if (j == 0) ow = *reinterpret_cast<const float4 *>(p.w_r + k0 + pch);
-        else if (j <= 2) oa[j - 1] = *reinterpret_cast<const float4 *>(p.A + oA[j - 1] + k0);
+        else if (j <= NA) oa[j - 1] = *reinterpret_cast<const float4 *>(p.A + oA[j - 1] + k0);
         else {
-            const int it = (j - 3) / 6, q = (j - 3) % 6;
+            const int it = (j - 1 - NA) / 6, q = (j - 1 - NA) % 6;
             if (q == 0) ob[it] = *reinterpret_cast<const float4 *>(p.Bm + oBm[it] + k0);
             else ot[q - 1][it] = *reinterpret_cast<const float4 *>(p.T + oT[q - 1][it] + k0);
         }
     };
     auto fetch_ops = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < 27; ++j) fetch_op1(c, j);
+        for (int j = 0; j < NOPS; ++j) fetch_op1(c, j);
     };
     // edge_mlp.0 + SiLU (egnn.py:95-101) of element e of this thread's row `it`, same association as k_edge_f32; in two slices so that
     // it can be laid between MFMAs (a slice must stay below the 64 cycles an MFMA occupies the pipe)
     float pre_e = 0.f;
     auto build_slice = [&](int buf, int it, int e, int part) {
         if (part == 0) {
-            const float4 a4 = oa[it >> 1], b4 = ob[it];
+            const float4 a4 = oa[ROWS ? it : it >> 1], b4 = ob[it];
             const float a = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w)), bm = e == 0 ? b4.x : (e == 1 ? b4.y : (e == 2 ? b4.z : b4.w));
             const float w = e == 0 ? ow.x : (e == 1 ? ow.y : (e == 2 ? ow.z : ow.w));
             float pre = a + bm;
@@ -599,7 +617,7 @@ __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
         // elements in two slices each, one slice after every second MFMA
         mfma_chunk(c & 1, acc, [&](int m) {
             if (m >= 1 && m <= 8) fetch_w1(p.W2t, c + 1, nb, m - 1);
-            else if (m >= 9 && m <= 35) fetch_op1(c + 1, m - 9);
+            else if (m >= 9 && m < 9 + NOPS) fetch_op1(c + 1, m - 9);
             else if (m >= 64 && (m & 1)) { const int j = (m - 64) >> 1; build_slice(nb, j >> 3, (j >> 1) & 3, j & 1); }
         });
         wait_w();
@@ -610,10 +628,10 @@ __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
     FSTAMP()
 
     // ---- epilogue of the wave's 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) = (r & 3) + 8 (r >> 2) + 4 h
-    int wb, wi;
-    const bool wvalid = node_of(wave >> 1, wb, wi);
+    int wb = 0, wi = 0;
+    const bool wvalid = ROWS ? true : node_of(wave >> 1, wb, wi);
     const int mt = wave & 1;
-    const bool do_coord_wg = p.last != 0;
+    const bool do_coord_wg = !ROWS && p.last != 0;
     if (do_coord_wg) fetch_w(p.Wc1t, 0, 0);      // flies under the epilogue (every wave is past the last chunk's reads: barrier above)
     float part[16];
 #pragma unroll
@@ -633,12 +651,33 @@ __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKArgs p)
     {   // attention gate (egnn.py:102-104): computed by the lane that ends up with the row's sum, handed back by ds_bpermute
         const float logit = half_reduce_scatter(part, lane);
         const int rs_j = rs_index(lane), rs_row = (rs_j & 3) + 8 * (rs_j >> 2) + 4 * h, bp_base = (lane & 32) * 4;
-        const float gate = (wvalid && mt * 32 + rs_row < K) ? sigmoid_exact(logit + p.att_b) : 0.f;
+        const bool live = ROWS ? row_base + (uint32_t)(wave * 32 + rs_row) < n_rows : (wvalid && mt * 32 + rs_row < K);
+        const float gate = live ? sigmoid_exact(logit + p.att_b) : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int src = ((r & 8) >> 3) | ((r & 4) >> 1) | ((r & 2) << 1) | ((r & 1) << 3);
             part[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp_base + src * 4, __builtin_bit_cast(int, gate)));
         }
+    }
+    if constexpr (ROWS) {      // gated messages, row-major: a store instruction writes 128 contiguous bytes of two rows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t row = row_base + (uint32_t)(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+            if (row < n_rows) {
+                float *out = p.rows_out32 + (size_t)row * H + l31;
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) out[nt * 32] = acc[nt][r] * part[r];
+            }
+        }
+        if (p.range) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                pre_max = fmaxf(pre_max, __shfl_xor(pre_max, m, 64));
+                acc_max = fmaxf(acc_max, __shfl_xor(acc_max, m, 64));
+            }
+            if (lane == 0) { atomicMax(p.range, __float_as_uint(pre_max)); atomicMax(p.range + 1, __float_as_uint(acc_max)); }
+        }
+        return;
     }
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
@@ -1432,11 +1471,11 @@ hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s)
     static const bool scalar = [] { const char *e = getenv("DFM_EDGE_F32_SCALAR"); return e && atoi(e) != 0; }();      // diagnostics: the r01-r03 kernel
     if (!scalar) {
         static std::atomic<bool> attr_m[MAX_DEVICES];
-        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_f32m), LDS_F32M_BYTES, attr_m);
+        hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_f32m<0>), LDS_F32M_BYTES, attr_m);
         if (e != hipSuccess) return e;
         const EdgeKArgs k = to_kargs(a);
         const long long tasks = (long long)a.B * k.nodes;
-        hipLaunchKernelGGL(k_edge_f32m, dim3((unsigned)((tasks + 1) / 2)), dim3(256), LDS_F32M_BYTES, s, k);
+        hipLaunchKernelGGL(k_edge_f32m<0>, dim3((unsigned)((tasks + 1) / 2)), dim3(256), LDS_F32M_BYTES, s, k);
         return hipGetLastError();
     }
     static std::atomic<bool> attr_done[MAX_DEVICES];
@@ -1570,6 +1609,46 @@ __global__ __launch_bounds__(256) void k_l0_gather(const uint2 *__restrict__ tab
     agg[node * 64 + lane] = make_float4(acc.x * inv_s, acc.y * inv_s, acc.z * inv_s, acc.w * inv_s);
 }
 
+// fp32 engine: the same gather-sum over fp32 rows (1 KiB each: a wave instruction covers one row with 16-byte loads), no scale
+__global__ __launch_bounds__(256) void k_l0_gather32(const float4 *__restrict__ table, const float4 *__restrict__ X, const uint32_t *__restrict__ src,
+                                                     float4 *__restrict__ agg, int B, int N, int K, uint32_t *counter, unsigned long long *miss_total)
+{
+    const int lane = threadIdx.x & 63;
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t == 0 && lane == 0) {
+        *miss_total += *counter;
+        *counter = 0u;
+    }
+    if (t >= (long long)B * N) return;
+    const int i = (int)(t / B), b = (int)(t - (long long)i * B);
+    const size_t node = (size_t)b * N + i;
+    const uint32_t my = lane < K ? src[node * K + lane] : 0u;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < K; s0 += 6) {
+        float4 v[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my, (s0 + q) < K ? s0 + q : 0);
+            const float4 *row = (id & L0_MISS) ? X + (size_t)(id & ~L0_MISS) * 64 : table + (size_t)id * 64;
+            v[q] = (s0 + q) < K ? row[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            if (s0 + q < K) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
+        }
+    }
+    agg[node * 64 + lane] = acc;
+}
+
+hipError_t launch_l0_gather32(const float *table, const float *X, const uint32_t *src, float *agg, int B, int N, int K,
+                              uint32_t *counter, unsigned long long *miss_total, hipStream_t s)
+{
+    const long long waves = (long long)B * N;
+    hipLaunchKernelGGL(k_l0_gather32, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const float4 *>(table),
+                       reinterpret_cast<const float4 *>(X), src, reinterpret_cast<float4 *>(agg), B, N, K, counter, miss_total);
+    return hipGetLastError();
+}
+
 hipError_t launch_l0_gather(const uint16_t *table, const uint16_t *X, const uint32_t *src, float *agg, int B, int N, int K,
                             uint32_t *counter, unsigned long long *miss_total, hipStream_t s)
 {
@@ -1590,6 +1669,19 @@ hipError_t launch_edge_rows(const EdgeArgs &a, const uint4 *rows, const uint32_t
     hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_msg<1, 1, 1>), LDS_EDGE_BYTES, attr_done);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_edge_msg<1, 1, 1>), dim3(persistent_grid(((long long)n_rows_cap + 31) / 32)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
+    return hipGetLastError();
+}
+
+// fp32 engine: the edge model over a row list (a = layer 0's EdgeArgs with the complex's own fp32 A0 / Bm0, ab_bstride 0) -> fp32 rows
+hipError_t launch_edge_rows32(const EdgeArgs &a, const uint4 *rows, const uint32_t *n_rows_dev, uint32_t n_rows_cap, float *out, hipStream_t s)
+{
+    if (a.ab_bstride != 0 || n_rows_cap == 0) return hipErrorInvalidValue;
+    EdgeKArgs k = to_kargs(a);
+    k.rows = rows; k.n_rows_dev = n_rows_dev; k.n_rows = n_rows_cap; k.rows_out32 = out; k.last = 0;
+    static std::atomic<bool> attr_done[MAX_DEVICES];
+    hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_f32m<1>), LDS_F32M_BYTES, attr_done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_edge_f32m<1>, dim3((n_rows_cap + 127u) / 128u), dim3(256), LDS_F32M_BYTES, s, k);
     return hipGetLastError();
 }
 

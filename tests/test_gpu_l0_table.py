@@ -182,7 +182,49 @@ def test_flag_is_refused_where_the_table_does_not_apply(model):
     cx = make_complex(24, 16, seed=5)
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
     with pytest.raises(ValueError):
-        gx.score(cx["lig_pos"], 0.5, l0_table=True)                   # fp32 engine
-    with pytest.raises(ValueError):
-        gx.score(cx["lig_pos"], 0.5, f16=True, l0_table=True)         # fp32 A_i variant
+        gx.score(cx["lig_pos"], 0.5, f16=True, l0_table=True)         # fp32 A_i variant of the 16-bit engine (the fp32 engine has its own table)
+    gx.close()
+
+
+@pytest.mark.parametrize("case", ["fwd_syn_24_16", "fwd_syn_64_48_p1", "fwd_7CEI_p0", "fwd_c3_300_300"])
+def test_fp32_table_vs_direct_and_reference(case, model):
+    """The fp32 engine's own table (k_edge_f32m<1>, fp32 rows of 1 KiB): exact fp32 products and sums as in the direct evaluation, only the
+    order of the K-row sum differs (slot order instead of tile partials): <= 2e-5 against the direct fp32 result, the reference's 1e-4 gates
+    unchanged, batch invariance bitwise."""
+    g = load_golden(case + ".npz")
+    gx, _ = _complex(model, case)
+    kw = dict(edges=g["edges"], energy=True)
+    d = gx.score(g["lig_pos"], float(g["t"]), **kw)
+    t = gx.score(g["lig_pos"], float(g["t"]), l0_table=True, profile=True, **kw)
+    p = gx.profile()
+    assert p["l0_evals"] == 1 and p["l0_edges"] == g["edges"].size and p["l0_build_ms"] > 0
+    for k in ("f", "tr_score", "rot_score"):
+        assert rel_inf(t[k], d[k]) < 2e-5, (k, rel_inf(t[k], d[k]))
+        assert rel_inf(t[k][0], g[k].reshape(t[k][0].shape)) < 1e-4, (k, "vs the reference")
+    assert abs(float(t["energy"][0]) - float(g["energy"])) < 1e-4 * max(1.0, abs(float(g["energy"])))
+    t2 = gx.score(g["lig_pos"], float(g["t"]), l0_table=True, profile=True, **kw)
+    assert gx.profile()["l0_build_ms"] == 0
+    assert all((t2[k] == t[k]).all() for k in ("f", "tr_score", "rot_score", "energy"))
+    # both tables of a complex live side by side
+    m = gx.score(g["lig_pos"], float(g["t"]), l0_table=True, mfma16=True, **kw)
+    assert rel_inf(m["f"], d["f"]) < 1e-2
+    t3 = gx.score(g["lig_pos"], float(g["t"]), l0_table=True, **kw)
+    assert all((t3[k] == t[k]).all() for k in ("f", "tr_score", "rot_score", "energy"))
+    gx.close()
+
+
+def test_fp32_sampler_uses_the_table_and_is_batch_invariant(model):
+    from dfmdock_amd.synthetic import make_complex
+    from dfmdock_amd import engine
+    cx = make_complex(70, 50, seed=9)
+    gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    a = gx.sample(B=3, num_steps=6, seed=4, profile=True)
+    p = gx.profile()
+    assert p["l0_evals"] == 7 and 0 < p["l0_miss_rows"] < p["l0_edges"]
+    b = gx.sample(B=1, num_steps=6, seed=4)
+    np.testing.assert_array_equal(a["lig_pos"][0], b["lig_pos"][0])
+    np.testing.assert_array_equal(a["energy"][0], b["energy"][0])
+    off = gx.sample(B=3, num_steps=6, seed=4, l0_table=False, profile=True)
+    assert gx.profile()["l0_evals"] == 0
+    assert np.abs(off["lig_pos"] - a["lig_pos"]).max() < 1e-2      # same draws, fp32 either way: only the order of layer 0's row sums differs
     gx.close()
