@@ -158,7 +158,7 @@ class Complex:
               ires=False, return_edges=False, bf16_ops=False, dist=False, bf16=False, l0_table=False):
         """B score evaluations.  lig_pos [B,L,3,3] (or [L,3,3]), t [B] (or scalar).  mfma16: the 16-bit MFMA engine
         (`bf16=` is its deprecated keyword of rounds 1-3).  l0_table: layer 0 through the per-complex message table
-        (DFM_F_L0_TABLE; mfma16 only - `sample` uses it by default, `score` only on request)."""
+        (DFM_F_L0_TABLE; the mfma16 and the fp32 engine, a table each - `sample` uses it by default, `score` only on request)."""
         mfma16 = mfma16 or bf16
         lig_pos = _f32(lig_pos)
         if lig_pos.ndim == 3:

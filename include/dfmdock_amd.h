@@ -96,14 +96,14 @@ enum {
                                         plan; ~3 % faster).  OUTSIDE SURVEY 8(d)'s 1e-2 gate: measured up to 1.5e-2 on f /
                                         tr_score / rot_score over four weight draws (profiles/r03_tol_report.txt) - an opt-in
                                         for callers who accept that; tested at 2e-2                                      */
-    /* Layer 0 behind the per-complex message table (DFM_F_MFMA16 engine only; src/models/egnn.py:95-104 evaluated once per
+    /* Layer 0 behind the per-complex message table (DFM_F_MFMA16 engine and the fp32 engine, a table each; src/models/egnn.py:95-104 evaluated once per
        intra-chain residue pair instead of once per edge, trajectory and step - in layer 0 the node features are the pose-independent
        embedding, and the geometry of two residues of one chain does not change under the rigid motion of the ligand).  dfm_sample
        uses the table whenever the complex is eligible (depth >= 2, (R^2 + L^2) * 516 B and the per-batch row buffers within the
        budgets in api.hip), whatever the batch size; dfm_score is a pure function of its arguments and uses it only on request.
        Inter-chain edges, and intra-chain edges whose feature bins in the pose at hand differ from the table's, go through the edge
        model as before.  Against the direct evaluation the only difference is the fp16 rounding of each stored message before the
-       K-row sum (measured: tests/test_gpu_l0_table.py).                                                                  */
+       K-row sum (fp32 engine: fp32 rows of 1 KiB, only the ORDER of the K-row sum differs, <= 2e-5; measured: tests/test_gpu_l0_table.py).                                                                  */
     DFM_F_L0_TABLE = 1u << 11,       /* dfm_score: use (and if necessary build) the table                                */
     DFM_F_NO_L0_TABLE = 1u << 12,    /* dfm_sample: evaluate layer 0 directly                                            */
     DFM_F_GRAPH = 1u << 13           /* dfm_sample: capture ONE step (score evaluation + heads + update) as a hipGraph and replay it
