@@ -767,7 +767,7 @@ extern "C" const char *dfm_config_string(void)
         c += "; layer 0 through the per-complex message table in dfm_sample (DFM_F_NO_L0_TABLE: direct), on request in dfm_score (DFM_F_L0_TABLE)";
         c += "; build: TAB_MERGE=" + std::to_string((int)DFM_TAB_MERGE);
         std::string env;
-        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_GEMM_NARROW_MAXWG", "DFM_GEMM_QUARTER_MAXWG", "DFM_L0_TABLE", "DFM_GRAPH", "DFM_EDGE_F32_SCALAR", "DFM_PAIR_HEAD_VALU", "DFM_LIB"}) {
+        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_GEMM_NARROW_MAXWG", "DFM_GEMM_QUARTER_MAXWG", "DFM_L0_TABLE", "DFM_GRAPH", "DFM_EDGE_F32_SCALAR", "DFM_GEMM_F32_SCALAR", "DFM_PAIR_HEAD_VALU", "DFM_LIB"}) {
             const char *e = getenv(k);
             if (e) env += std::string(env.empty() ? "" : " ") + k + "=" + e;
         }
