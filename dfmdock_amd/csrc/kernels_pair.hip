@@ -354,11 +354,13 @@ __global__ __launch_bounds__(256) void k_pair_finish_s(const float *__restrict__
                                                        float cut_off, float inv_pool, int n_part, float *__restrict__ fvec,
                                                        float *__restrict__ spart, int32_t *__restrict__ clash_part, float *__restrict__ conf)
 {
+    // gridDim.y workgroups share a trajectory's ligand residues (modes 0 / 1: one partial slot per wave, 4 gridDim.y <= n_part; mode 2: 1)
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, N = R + L;
+    const int slot = blockIdx.y * 4 + wave, nslot = gridDim.y * 4;
     __shared__ double red[4];
     double s_acc = 0, c_acc = 0;
     int clash = 0;
-    for (int l = wave; l < L; l += 4) {
+    for (int l = slot; l < L; l += nslot) {
         const float4 xl = ca4[(size_t)b * N + R + l];
         const float *Sl = S + ((size_t)b * L + l) * Rp;
         float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -387,13 +389,13 @@ __global__ __launch_bounds__(256) void k_pair_finish_s(const float *__restrict__
     }
     if (mode == 0) {
         const int tot = (int)wave_sum((float)clash);       // <= 64 * ceil(R / 64) * L / 4 per wave: exact in fp32 below 2^24
-        if (lane == 0) clash_part[(size_t)b * n_part + wave] = tot;
-        for (int t = 4 + threadIdx.x; t < n_part; t += blockDim.x) clash_part[(size_t)b * n_part + t] = 0;
+        if (lane == 0) clash_part[(size_t)b * n_part + slot] = tot;
+        if (blockIdx.y == 0) for (int t = nslot + threadIdx.x; t < n_part; t += blockDim.x) clash_part[(size_t)b * n_part + t] = 0;
     } else {
         const double st = wave_sum_d(s_acc), ct = wave_sum_d(c_acc);
         if (mode == 1) {
-            if (lane == 0) { spart[((size_t)b * n_part + wave) * 2] = (float)st; spart[((size_t)b * n_part + wave) * 2 + 1] = (float)ct; }
-            for (int t = 4 + threadIdx.x; t < n_part; t += blockDim.x) { spart[((size_t)b * n_part + t) * 2] = 0.f; spart[((size_t)b * n_part + t) * 2 + 1] = 0.f; }
+            if (lane == 0) { spart[((size_t)b * n_part + slot) * 2] = (float)st; spart[((size_t)b * n_part + slot) * 2 + 1] = (float)ct; }
+            if (blockIdx.y == 0) for (int t = nslot + threadIdx.x; t < n_part; t += blockDim.x) { spart[((size_t)b * n_part + t) * 2] = 0.f; spart[((size_t)b * n_part + t) * 2 + 1] = 0.f; }
         } else {
             if (lane == 0) red[wave] = st;
             __syncthreads();
@@ -494,7 +496,12 @@ hipError_t launch_pair_head_m(const PairArgs &a, hipStream_t s)
 
 hipError_t launch_pair_finish_s(const PairArgs &a, int n_part, float inv_pool, float *fvec, float *conf, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pair_finish_s, dim3(a.B), dim3(256), 0, s, a.S, a.ca4, a.R, a.L, a.Rp, a.mode, a.cut_off, inv_pool, n_part, fvec, a.spart,
+    // split a trajectory's ligand residues over up to 8 workgroups (a partial slot per wave: 4 per workgroup of the n_part the heads sum; the
+    // confidence is one number per trajectory: one workgroup).  A function of (R, L) only: batch-invariant.
+    int ls = a.mode == 2 ? 1 : n_part / 4;
+    ls = ls < 1 ? 1 : (ls > 8 ? 8 : ls);
+    while (ls > 1 && ls * 4 > a.L) --ls;
+    hipLaunchKernelGGL(k_pair_finish_s, dim3(a.B, ls), dim3(256), 0, s, a.S, a.ca4, a.R, a.L, a.Rp, a.mode, a.cut_off, inv_pool, n_part, fvec, a.spart,
                        a.clash_part, conf);
     return hipGetLastError();
 }
