@@ -980,7 +980,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         // egnn_net.py:430-470: pair heads on cat[h_r, h_l, D].  Per head: one GEMM projects every node through the stacked
         // halves of Linear(513 -> 256) (reusing the A / Bm buffers), then the elementwise pair kernel.
         static const bool pair_valu = [] { const char *e = getenv("DFM_PAIR_HEAD_VALU"); return e && atoi(e) != 0; }();      // A/B: r02-r03 kernel
-        const bool pair_m = o.bf16 && !pair_valu;
+        const bool pair_m = !pair_valu;      // every engine: the kernel computes in fp32 (moment-based LayerNorm statistics, 1-ulp hardware exp2 / rcp)
         auto run_head = [&](int q, int mode) -> int {
             const PairHeadDev &Ph = m->pair[q];
             GemmArgs g;

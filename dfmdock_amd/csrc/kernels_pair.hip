@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void k_pair_head(PairKArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// The 16-bit engines' pair head (r04): the same arithmetic type (fp32 throughout), the rank-4 part of the pre-activation on the matrix pipe.
+// The pair head of every engine (r04; fp32 throughout): the rank-4 part of the pre-activation on the matrix pipe.  (DFM_PAIR_HEAD_VALU=1 selects
+// k_pair_head<EXACT> above: all-VALU, three-pass LayerNorm + expf / division for the fp32 engine.)
 // With S = -log2(e) folded in (SiLU as exp2 -> +1 -> rcp -> mul, see SILU_S in kernels_edge.hip) the LayerNorm output of pair (r, l) is
 //     y'_c = rstd P''[r][c]  +  [rstd D] wd''_c + [rstd] Q''[l][c] + [-mean rstd] lnw''_c + [1] lnb''_c          ('' = times S ln_w_c; lnb'' = S ln_b)
 // i.e. a per-row scaling of the resident P'' tile plus a K = 4 outer product of per-pair scalars (rstd D, rstd, -mean rstd, 1) with four

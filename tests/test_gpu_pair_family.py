@@ -166,7 +166,7 @@ def test_pair_family_dist_logits_vs_reference(blob_pair):
 @pytest.mark.parametrize("R,L", [(31, 3), (33, 65), (95, 131), (64, 64), (130, 40)])
 def test_pair_head_on_the_matrix_pipe_at_ragged_sizes(R, L, blob_pair):
     """k_pair_head_m tiles the receptor by 32 and the ligand by 64 (16 per wave): sizes on, just past and far from those edges.
-    The 16-bit engine's heads against the fp32 engine's (three-pass LayerNorm kernel) on the same graph, the clash count exactly,
+    The 16-bit engine's heads against the fp32 engine's on the same graph (the same pair kernel behind a different trunk), the clash count exactly,
     and a batch of poses against the same poses one at a time, bitwise."""
     from dfmdock_amd import engine
     from dfmdock_amd.synthetic import make_complex

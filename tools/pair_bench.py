@@ -36,9 +36,10 @@ if len(sys.argv) > 1:
     B = int(sys.argv[1])
     cx = make_complex(300, 300, seed=1)
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-    for prec in ("mfma16",):
-        gx.sample(B=B, num_steps=4, seed=1, mfma16=True)
+    for prec in (("fp32",) if os.environ.get("PAIR_FP32") else ("mfma16",)):      # PAIR_FP32=1: the fp32 engine of this family
+        m16 = prec == "mfma16"
+        gx.sample(B=B, num_steps=4 if m16 else 2, seed=1, mfma16=m16)
         t0 = time.perf_counter()
-        gx.sample(B=B, num_steps=STEPS, seed=2, mfma16=True)
+        gx.sample(B=B, num_steps=STEPS, seed=2, mfma16=m16)
         dt = time.perf_counter() - t0
         print(f"C3-shaped 300+300, B={B}, {STEPS} steps, {prec}: {dt*1e3:.0f} ms -> {B/dt:.1f} trajectories/s")
