@@ -4,6 +4,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,20 +50,92 @@ struct DeviceScope {
     if (_ds.err != hipSuccess) return fail(DFM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_ds.err))
 
 // ------------------------------------------------------------------------------------------------
+// Device blocks released by one handle and wanted by the next: a set driver creates and destroys a complex (about forty buffers, some of them
+// gigabytes) every few hundred milliseconds, and hipMalloc / hipFree of that size cost milliseconds each (hipFree also drains the device).
+// Released blocks are kept per device, up to a quarter of its memory, and handed out again to requests of at most twice-smaller size;
+// DFM_ALLOC_CACHE=0 turns the cache off.
+struct BlockCache {
+    std::mutex m;
+    std::multimap<size_t, void *> free_blocks[MAX_DEVICES];
+    size_t bytes[MAX_DEVICES] = {};
+    size_t cap[MAX_DEVICES] = {};
+    static bool enabled()
+    {
+        static const bool on = [] { const char *e = getenv("DFM_ALLOC_CACHE"); return !(e && atoi(e) == 0); }();
+        return on;
+    }
+    bool give(int dev, void *p, size_t size)
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (!cap[dev]) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0;
+            cap[dev] = tot / 4 + 1;
+        }
+        if (bytes[dev] + size > cap[dev]) return false;
+        free_blocks[dev].emplace(size, p);
+        bytes[dev] += size;
+        return true;
+    }
+};
+static BlockCache g_block_cache;
+
 struct DevPool {
-    std::vector<void *> ptrs;
+    struct Block { void *p; size_t size; int dev; };
+    std::vector<Block> ptrs;
     ~DevPool() { release(); }
     void release()
     {
-        for (void *p : ptrs) (void)hipFree(p);
+        if (ptrs.empty()) return;
+        if (BlockCache::enabled()) {
+            (void)hipDeviceSynchronize();      // what hipFree would have done: nothing in flight reads these blocks when the next owner gets them
+            for (const Block &b : ptrs)
+                if (b.dev < 0 || b.dev >= MAX_DEVICES || !g_block_cache.give(b.dev, b.p, b.size)) (void)hipFree(b.p);
+        } else {
+            for (const Block &b : ptrs) (void)hipFree(b.p);
+        }
         ptrs.clear();
     }
     template <typename T> hipError_t alloc(T **out, size_t n)
     {
+        size_t bytes = (n ? n : 1) * sizeof(T);
+        int dev = -1;
+        (void)hipGetDevice(&dev);
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
-        if (e == hipSuccess) { ptrs.push_back(p); *out = reinterpret_cast<T *>(p); }
-        return e;
+        if (BlockCache::enabled() && dev >= 0 && dev < MAX_DEVICES) {
+            bytes = (bytes + 65535) & ~(size_t)65535;      // 64 KiB granules: neighbouring sizes share blocks
+            // the block's true size travels with it: look it up by taking from the cache under the lock
+            {
+                std::lock_guard<std::mutex> g(g_block_cache.m);
+                auto &fb = g_block_cache.free_blocks[dev];
+                auto it = fb.lower_bound(bytes);
+                if (it != fb.end() && it->first <= 2 * bytes + (1u << 20)) {
+                    p = it->second;
+                    bytes = it->first;
+                    g_block_cache.bytes[dev] -= it->first;
+                    fb.erase(it);
+                }
+            }
+        }
+        if (!p) {
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess && BlockCache::enabled() && dev >= 0 && dev < MAX_DEVICES) {      // out of memory with blocks parked in the cache: drop them and retry
+                std::vector<void *> drop;
+                {
+                    std::lock_guard<std::mutex> g(g_block_cache.m);
+                    for (auto &kv : g_block_cache.free_blocks[dev]) drop.push_back(kv.second);
+                    g_block_cache.free_blocks[dev].clear();
+                    g_block_cache.bytes[dev] = 0;
+                }
+                for (void *q : drop) (void)hipFree(q);
+                (void)hipGetLastError();
+                e = hipMalloc(&p, bytes);
+            }
+            if (e != hipSuccess) return e;
+        }
+        ptrs.push_back({p, bytes, dev});
+        *out = reinterpret_cast<T *>(p);
+        return hipSuccess;
     }
     template <typename T> hipError_t upload(T **out, const T *host, size_t n)
     {
@@ -767,7 +841,7 @@ extern "C" const char *dfm_config_string(void)
         c += "; layer 0 through the per-complex message table in dfm_sample (DFM_F_NO_L0_TABLE: direct), on request in dfm_score (DFM_F_L0_TABLE)";
         c += "; build: TAB_MERGE=" + std::to_string((int)DFM_TAB_MERGE);
         std::string env;
-        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_GEMM_NARROW_MAXWG", "DFM_GEMM_QUARTER_MAXWG", "DFM_L0_TABLE", "DFM_GRAPH", "DFM_EDGE_F32_SCALAR", "DFM_GEMM_F32_SCALAR", "DFM_PAIR_HEAD_VALU", "DFM_LIB"}) {
+        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_GEMM_NARROW_MAXWG", "DFM_GEMM_QUARTER_MAXWG", "DFM_L0_TABLE", "DFM_GRAPH", "DFM_EDGE_F32_SCALAR", "DFM_GEMM_F32_SCALAR", "DFM_PAIR_HEAD_VALU", "DFM_ALLOC_CACHE", "DFM_LIB"}) {
             const char *e = getenv(k);
             if (e) env += std::string(env.empty() ? "" : " ") + k + "=" + e;
         }
