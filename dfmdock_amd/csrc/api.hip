@@ -78,7 +78,7 @@ struct BlockCache {
         return true;
     }
 };
-static BlockCache g_block_cache;
+static BlockCache &g_block_cache = *new BlockCache;      // never destroyed: a handle may outlive static destruction at process exit
 
 struct DevPool {
     struct Block { void *p; size_t size; int dev; };
