@@ -79,10 +79,12 @@ hipError_t launch_energy_pairs(const float *enA, const float *enB, const float4 
 // (every trajectory of a step shares t), dfm_score once per call for its B times.  r01-r03 evaluated both Linears inside k_heads
 // with one thread per output row: 256 dependent, uncoalesced row reads per evaluation (64 cache lines per wave instruction) - most
 // of that kernel's 25-33 us, which small batches cannot hide.  Here a wave owns an output and reads its row coalesced.
-__global__ __launch_bounds__(256) void k_time_embed(const float *__restrict__ t, HeadsDev hw, float *__restrict__ base)
+// (1024 threads, four outputs per wave in flight: with 256 threads and one output per iteration the kernel was 96 dependent L2 round
+// trips long - 50-60 us, 11 % of a dfm_score call at B = 1)
+__global__ __launch_bounds__(1024) void k_time_embed(const float *__restrict__ t, HeadsDev hw, float *__restrict__ base)
 {
     __shared__ float s_four[HI], s_temb[HI];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = 16;
     const float tv = t[n];
     if (tid < HI / 2) {
         const float xp = ((tv * hw.t_W[tid]) * 2.0f) * 3.14159265358979323846f;
@@ -90,23 +92,41 @@ __global__ __launch_bounds__(256) void k_time_embed(const float *__restrict__ t,
         s_four[HI / 2 + tid] = cosf(xp);
     }
     __syncthreads();
-    for (int o = wave; o < HI; o += 4) {
-        const float *row = hw.t_lin + (size_t)o * HI;
-        const float v = wave_sum(fmaf(s_four[lane], row[lane], s_four[64 + lane] * row[64 + lane]));
-        if (lane == 0) s_temb[o] = sigmoid_exact(v);
+    {
+        const float f0 = s_four[lane], f1 = s_four[64 + lane];
+        float p[HI / 16];      // HI / NW outputs per wave, their row loads all in flight
+#pragma unroll
+        for (int u = 0; u < HI / 16; ++u) {
+            const float *row = hw.t_lin + (size_t)(wave + u * NW) * HI;
+            p[u] = fmaf(f0, row[lane], f1 * row[64 + lane]);
+        }
+#pragma unroll
+        for (int u = 0; u < HI / 16; ++u) {
+            const float v = wave_sum(p[u]);
+            if (lane == 0) s_temb[wave + u * NW] = sigmoid_exact(v);
+        }
     }
     __syncthreads();
-    for (int q = wave; q < 2 * HI; q += 4) {
-        const int g = q >> 7, c = q & (HI - 1);
-        const float *row = (g ? hw.rots0 : hw.trs0) + (size_t)c * (HI + 1) + 1;
-        const float v = wave_sum(fmaf(s_temb[lane], row[lane], s_temb[64 + lane] * row[64 + lane]));
-        if (lane == 0) base[(size_t)n * (2 * HI) + q] = v;
+    {
+        const float e0 = s_temb[lane], e1 = s_temb[64 + lane];
+        float p[2 * HI / 16];
+#pragma unroll
+        for (int u = 0; u < 2 * HI / 16; ++u) {
+            const int q = wave + u * NW, g = q >> 7, c = q & (HI - 1);
+            const float *row = (g ? hw.rots0 : hw.trs0) + (size_t)c * (HI + 1) + 1;
+            p[u] = fmaf(e0, row[lane], e1 * row[64 + lane]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * HI / 16; ++u) {
+            const float v = wave_sum(p[u]);
+            if (lane == 0) base[(size_t)n * (2 * HI) + wave + u * NW] = v;
+        }
     }
 }
 
 hipError_t launch_time_embed(const float *t_dev, int n, const HeadsDev *hw, float *base, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_time_embed, dim3(n), dim3(256), 0, s, t_dev, *hw, base);
+    hipLaunchKernelGGL(k_time_embed, dim3(n), dim3(1024), 0, s, t_dev, *hw, base);
     return hipGetLastError();
 }
 
