@@ -625,6 +625,7 @@ int ora_score(const ora_hparams *hp, const float *blob, int R, int L, const floa
             const int j = edges[e];
             int8_t b[4];
             pair_bins(hp, i, j, pos + i * 9, pos + j * 9, cb[i], cb[j], b);
+            if (dbg && dbg->bins_in) memcpy(b, dbg->bins_in + e * 4, 4);
             const int rp = relpos_idx(i, j, R);
             if (dbg && dbg->bins) memcpy(dbg->bins + e * 4, b, 4);
             if (dbg && dbg->relpos) dbg->relpos[e] = (int8_t)rp;

@@ -47,6 +47,8 @@ typedef struct {
     int32_t *edges;  /* [N,K] edge list actually used                       */
     float *ires;     /* [N]                                                 */
     float *dist;     /* [R,L,64] family 1: dist_logits (egnn_net.py:447), or NULL */
+    const int8_t *bins_in; /* [N,K,4] INPUT, or NULL: use these feature bins instead of the computed ones (tests isolate a
+                              bin-boundary flip - one ulp of atan2 / acos between torch's kernels and libm - this way) */
 } ora_debug;
 
 typedef struct {

@@ -35,7 +35,7 @@ class OraScoreOut(C.Structure):
 
 class OraDebug(C.Structure):
     _fields_ = [("f", F32P), ("pos_out", F32P), ("h_layers", F32P), ("bins", I8P), ("relpos", I8P),
-                ("edges", I32P), ("ires", F32P), ("dist", F32P)]
+                ("edges", I32P), ("ires", F32P), ("dist", F32P), ("bins_in", I8P)]
 
 
 class OraInject(C.Structure):
@@ -119,7 +119,8 @@ class Oracle:
             ns = self.N - knn
         self.K = knn + ns
 
-    def score(self, lig_pos, t, edges=None, seed=0, want_energy=True, debug=True, dist=False):
+    def score(self, lig_pos, t, edges=None, seed=0, want_energy=True, debug=True, dist=False, bins=None):
+        """bins [N,K,4] int8: evaluate with THESE feature bins instead of the computed ones (isolates a bin-boundary flip)."""
         lig_pos = _f32(lig_pos)
         N, K, L, H = self.N, self.K, self.L, self.hp.node_dim
         out = OraScoreOut()
@@ -132,8 +133,10 @@ class Oracle:
                      ires=np.zeros((N,), np.float32))
             if dist and self.hp.family == 1:
                 d["dist_logits"] = np.zeros((self.R, L, 64), np.float32)
+            bins_in = None if bins is None else np.ascontiguousarray(bins, dtype=np.int8).reshape(N, K, 4)
             dbg = OraDebug(_p(d["f"]), _p(d["pos_out"]), _p(d["h_layers"]), _p(d["bins"], I8P),
-                           _p(d["relpos"], I8P), _p(d["edges"], I32P), _p(d["ires"]), _p(d.get("dist_logits")))
+                           _p(d["relpos"], I8P), _p(d["edges"], I32P), _p(d["ires"]), _p(d.get("dist_logits")),
+                           _p(bins_in, I8P))
         e = None if edges is None else np.ascontiguousarray(edges, dtype=np.int32)
         if e is not None:
             assert e.shape == (N, K), (e.shape, N, K)

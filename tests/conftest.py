@@ -121,9 +121,35 @@ def db5_complex(cid):
     return out
 
 
+REAL_ESM_IDS = ("1QA9", "1AVX", "1H1V", "7CEI")      # DB5 complexes whose ESM-2 block is committed (fp16)
+
+
+def real_db5_complex(cid):
+    """A DB5 test complex with the reference's REAL node features (src/datasets/ppi_dataset.py:249-265: x = cat[ESM-2 block,
+    one-hot(seq)]): backbone + sequence from db5_backbones.npz, ESM block from esm_<id>.npz (tests/golden/make_golden_r05.py;
+    float16 - the goldens were generated on the rounded values).  7CEI: cx_7CEI.npz (make_golden.py)."""
+    from dfmdock_amd.synthetic import seq_to_onehot
+    if cid == "7CEI":
+        cx = complex_for("7CEI")
+        d = load_golden("cx_7CEI.npz")
+        return dict(cx, id=cid, rec_seq=str(d["rec_seq"]), lig_seq=str(d["lig_seq"]))
+    db5_ids()
+    e = load_golden(f"esm_{cid}.npz")
+    out = {"id": cid}
+    for side in ("rec", "lig"):
+        seq = str(_db5[f"{cid}_{side}_seq"])
+        assert seq == str(e[side + "_seq"])
+        out[side + "_x"] = np.concatenate([e[side + "_esm16"].astype(np.float32), seq_to_onehot(seq)], 1)
+        out[side + "_pos"] = _db5[f"{cid}_{side}_pos"]
+        out[side + "_seq"] = seq
+    return out
+
+
 def complex_for(case):
     """Rebuild the complex a golden file was generated on (tests/golden/make_golden.py)."""
     from dfmdock_amd.synthetic import make_complex, seq_to_onehot
+    if "esm_" in case:       # DB5 backbone + the real ESM-2 block (tests/golden/make_golden_r05.py)
+        return real_db5_complex(case.split("esm_")[1].split(".")[0])
     if "7CEI" in case:
         d = load_golden("cx_7CEI.npz")
         rx = np.concatenate([d["rec_esm16"].astype(np.float32), seq_to_onehot(str(d["rec_seq"]))], 1)

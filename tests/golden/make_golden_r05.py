@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Round-5 golden vectors: REAL ESM-2 node features of three more DB5 test complexes, all outputs
+produced by RUNNING THE REFERENCE (make_golden.py's stand-ins and recording helpers are reused by importing it).
+
+  esm_<id>.npz           the complex's ESM-2 block as stored in the reference's data/db5_test/<id>.pt
+                         (src/datasets/ppi_dataset.py:249-265: x = cat[ESM, one-hot(seq)]), rounded to float16 - both the
+                         reference run below and every consumer use the ROUNDED values, as cx_7CEI.npz does.  Backbone and
+                         sequence are already in db5_backbones.npz.
+  fwd_esm_<id>.npz       one reference score evaluation at a rigidly noised pose (no [N,256] taps: h statistics only)
+  rollout_esm_<id>.npz   the reference's Euler_Maruyama_sampler (src/inference_base.py:390-468), 5 steps, every draw recorded
+
+ids: 1QA9 (102+95, the smallest), 1AVX (223+172, the pair SURVEY 8(d) names for C1 / C2), 1H1V (368+327, the largest and the
+nearest to the 300+300 headline shape).
+
+Usage:  python tests/golden/make_golden_r05.py [ids...]
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402
+import make_golden_r02 as mg2  # noqa: E402
+
+from dfmdock_amd.db5 import load_db5_pt  # noqa: E402
+
+IDS = {"1QA9": (0.35, 12.0, 2.5, 501), "1AVX": (0.7, 25.0, 5.0, 502), "1H1V": (0.9, 40.0, 7.0, 513)}   # t, rot deg, tr sigma, seed
+# 1H1V with seed 503 holds a pair (ligand residues 637 -> 673 in complex numbering) whose planar angle phi is 0 to the last bit:
+# torch's kernels evaluate cos(phi) = 1.0 exactly (phi = 0 -> bin 0, the bin of masked pairs), a left-to-right float32 evaluation
+# gives 0.99999994 (phi = 0.02 deg -> bin 1).  That pose is kept as the two-residue known answer phi0_pair.npz below; the forward
+# fixture uses another seed so that its 1e-4 gates do not hang on one ulp of one edge.
+PHI0 = ("1H1V", 503, 40.0, 7.0, 637, 673)
+
+
+def real_complex(cid):
+    d = load_db5_pt(os.path.join(mg.REF, f"data/db5_test/{cid}.pt"))
+    e_r, e_l = d["rec_esm"].astype(np.float16), d["lig_esm"].astype(np.float16)
+    assert np.isfinite(e_r.astype(np.float32)).all() and np.isfinite(e_l.astype(np.float32)).all()
+    mg.save(f"esm_{cid}.npz", rec_esm16=e_r, lig_esm16=e_l, rec_seq=d["rec_seq"], lig_seq=d["lig_seq"])
+    print(f"  {cid}: |ESM| max {max(np.abs(d['rec_esm']).max(), np.abs(d['lig_esm']).max()):.2f}, "
+          f"fp16 rounding max abs {max(np.abs(e_r.astype(np.float32) - d['rec_esm']).max(), np.abs(e_l.astype(np.float32) - d['lig_esm']).max()):.2e}")
+    return {"rec_x": np.concatenate([e_r.astype(np.float32), d["rec_x"][:, 1280:]], 1),
+            "lig_x": np.concatenate([e_l.astype(np.float32), d["lig_x"][:, 1280:]], 1),
+            "rec_pos": d["rec_pos"].astype(np.float32), "lig_pos": d["lig_pos"].astype(np.float32)}
+
+
+def slim_forward_bins(net, cx, lig_pos, t, seed):
+    """mg2.slim_forward plus the full per-edge bins / relpos (int8): a bin-boundary flip can then be located and counted."""
+    r = mg.forward_case(net, cx, lig_pos, t, seed)
+    keep = ("lig_pos", "t", "tr_score", "rot_score", "energy", "f", "num_clashes", "ires", "h_absmean", "h_absmax", "bins", "relpos")
+    out = {k: r[k] for k in keep}
+    out["edges"] = r["edges"].astype(np.int16)
+    return out
+
+
+def gen_phi0_pair():
+    import torch
+    from utils.coords6d import get_coords6d
+    cid, seed, rot, trs, i, j = PHI0
+    d = load_db5_pt(os.path.join(mg.REF, f"data/db5_test/{cid}.pt"))
+    cx = {"rec_pos": d["rec_pos"].astype(np.float32), "lig_pos": d["lig_pos"].astype(np.float32)}
+    lig = torch.from_numpy(mg.noised_pose(cx, np.random.Generator(np.random.PCG64(seed)), rot, trs))
+    center = lig[:, 1, :].mean(0)
+    pos = torch.cat([torch.from_numpy(cx["rec_pos"]) - center, lig - center], 0)[[i, j]]
+    dist, omega, theta, phi = get_coords6d(pos)
+    sp = mg.snm.get_spatial_matrix(pos).numpy()
+    bins = np.stack([sp[..., 0:40].argmax(-1), sp[..., 40:64].argmax(-1), sp[..., 64:88].argmax(-1), sp[..., 88:100].argmax(-1)], -1)
+    assert float(phi[0, 1]) == 0.0 and bins[0, 1, 3] == 0 and float(dist[0, 1]) < 22.0
+    mg.save("phi0_pair.npz", pos=pos.numpy(), dist=dist.numpy(), omega=omega.numpy(), theta=theta.numpy(), phi=phi.numpy(),
+            bins=bins.astype(np.int8))
+
+
+def main(which):
+    net = mg.build_net(0)
+    model = mg.Model(net).eval()
+    if not which or "phi0" in which:
+        gen_phi0_pair()
+        which = [w for w in which if w != "phi0"]
+        if not which and len(sys.argv) > 1:
+            return
+    for cid in (which or list(IDS)):
+        t, rot, trs, seed = IDS[cid]
+        cx = real_complex(cid)
+        rng = np.random.Generator(np.random.PCG64(seed))
+        mg.save(f"fwd_esm_{cid}.npz", **slim_forward_bins(net, cx, mg.noised_pose(cx, rng, rot, trs), t, seed=seed))
+        # gen_rollout stores int32 edge lists; N <= 695 fits int16 (tests cast back)
+        mg.gen_rollout(model, cx, f"rollout_esm_{cid}.npz", num_steps=5, seed=seed + 10)
+        path = os.path.join(HERE, f"rollout_esm_{cid}.npz")
+        d = dict(np.load(path))
+        d["edges"] = d["edges"].astype(np.int16)
+        np.savez_compressed(path, **d)
+        print(f"  rollout_esm_{cid}.npz repacked with int16 edges: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

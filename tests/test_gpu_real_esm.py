@@ -1,0 +1,112 @@
+"""DB5 test complexes with the reference's REAL node features (loader src/datasets/ppi_dataset.py:249-265:
+x = cat[ESM-2 block of the .pt file, one-hot(seq)]).  tests/golden/make_golden_r05.py ran the REFERENCE on 1QA9 (102+95),
+1AVX (223+172, SURVEY 8(d)'s C1 / C2 pair) and 1H1V (368+327, the largest of the set) with the ESM blocks rounded to fp16 (the
+committed esm_<id>.npz; 7CEI's block has been in cx_7CEI.npz since r01): one score evaluation at a rigidly noised pose and one
+5-step sampler run with every draw recorded.  Here, through the C ABI:
+
+  * the three engines against those goldens at SURVEY 8(d)'s gates (fp32 1e-4; 16-bit 1e-2 / 3e-2), per-edge bins compared
+    element by element (a bin boundary may be crossed by one ulp: <= 2 of N*K*4 bins, and then the oracle re-evaluates with the
+    ENGINE's bins so that everything downstream is still held to the gate)
+  * layer 0 through the per-complex message table (what dfm_sample runs) against the direct evaluation and the golden
+  * injected 5-step rollouts: CA-RMSD <= 0.05 A (fp32) / 0.5 A (16-bit), with and without the table
+  * dfm_complex_selfcheck on all four real feature blocks: must pass, fp16 headroom >= 4
+"""
+import numpy as np
+import pytest
+
+from conftest import REAL_ESM_IDS, complex_for, load_golden, real_db5_complex
+
+pytestmark = pytest.mark.gpu
+IDS = ("1QA9", "1AVX", "1H1V")
+
+
+def rel_inf(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def model(blob):
+    from dfmdock_amd import engine
+    engine.set_device(0)
+    m = engine.Model(blob)
+    yield m
+    m.close()
+
+
+def _gx(model, cid):
+    from dfmdock_amd import engine
+    cx = real_db5_complex(cid)
+    return engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"]), cx
+
+
+@pytest.mark.parametrize("cid", IDS)
+def test_forward_three_engines_vs_reference(cid, model, blob):
+    from oracle import oracle as ora
+    g = load_golden(f"fwd_esm_{cid}.npz")
+    gx, cx = _gx(model, cid)
+    e = g["edges"].astype(np.int32)
+    t = float(g["t"])
+    r32 = gx.score(g["lig_pos"], t, edges=e, energy=True, debug=True, ires=True)
+    flips = r32["bins"][0] != g["bins"]
+    assert flips.sum() <= 2, int(flips.sum())
+    np.testing.assert_array_equal(r32["relpos"][0], g["relpos"])
+    ref = {k: g[k] for k in ("f", "tr_score", "rot_score", "energy", "num_clashes")}
+    ref["ires"] = g["ires"][:, 0]
+    if flips.any():      # same bins on both sides: the oracle (pinned to the reference by tests/test_oracle_golden.py) with the engine's bins
+        o = ora.Oracle(blob, cx).score(g["lig_pos"], t, edges=e, bins=r32["bins"][0])
+        ref = {k: o[k] for k in ("f", "tr_score", "rot_score", "energy", "num_clashes", "ires")}
+    for name, r, tol, etol in (("fp32", r32, 1e-4, 1e-4),
+                               ("mfma16", gx.score(g["lig_pos"], t, edges=e, energy=True, mfma16=True, ires=True), 1e-2, 3e-2),
+                               ("mfma16+table", gx.score(g["lig_pos"], t, edges=e, energy=True, mfma16=True, l0_table=True), 1e-2, 3e-2),
+                               ("fp32+table", gx.score(g["lig_pos"], t, edges=e, energy=True, l0_table=True), 1e-4, 1e-4),
+                               ("f16", gx.score(g["lig_pos"], t, edges=e, energy=True, f16=True), 1e-2, 3e-2)):
+        assert rel_inf(r["f"][0], ref["f"]) < tol, (name, "f", rel_inf(r["f"][0], ref["f"]))
+        assert rel_inf(r["tr_score"][0], np.asarray(ref["tr_score"]).reshape(3)) < tol, (name, "tr_score")
+        assert rel_inf(r["rot_score"][0], np.asarray(ref["rot_score"]).reshape(3)) < tol, (name, "rot_score")
+        e_ref = float(ref["energy"])
+        assert abs(float(r["energy"][0]) - e_ref) < (etol * max(abs(e_ref), 0.1) if etol > 1e-3 else 1e-4), (name, "energy")
+        assert int(r["num_clashes"][0]) == int(ref["num_clashes"]), name
+        if "ires" in r:
+            assert rel_inf(r["ires"][0], ref["ires"]) < (1e-4 if name == "fp32" else 2e-2), (name, "ires")
+    # the reference's own per-layer magnitudes of h on REAL features (what the fp16 plan has to hold): taps of the fp32 engine
+    assert float(np.abs(r32["h_last"]).max()) == pytest.approx(float(g["h_absmax"][-1]), rel=1e-4)
+    assert float(np.abs(r32["h_first"]).max()) == pytest.approx(float(g["h_absmax"][0]), rel=1e-4)
+    gx.close()
+
+
+@pytest.mark.parametrize("cid", IDS)
+@pytest.mark.parametrize("prec,table", [("fp32", False), ("fp32", True), ("mfma16", False), ("mfma16", True), ("f16", False)])
+def test_rollout_vs_reference(cid, prec, table, model):
+    from dfmdock_amd import engine
+    g = load_golden(f"rollout_esm_{cid}.npz")
+    gx, _ = _gx(model, cid)
+    S = int(g["num_steps"])
+    inj = dict(R0=g["R0"].astype(np.float32), tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"].astype(np.int32))
+    r = gx.sample(B=1, num_steps=S, inject=inj, trace=True, l0_table=table, profile=True, **engine.precision_kwargs(prec))
+    assert gx.profile()["l0_evals"] == ((S + 1) if table else 0)
+    np.testing.assert_allclose(r["init_pose"][0], g["init_pose"], atol=3e-5)
+    rmsd = np.sqrt(((r["trace_pose"][0][:, :, 1] - g["poses"][:, :, 1]) ** 2).sum(-1).mean(-1))
+    assert rmsd.max() < (0.05 if prec == "fp32" else 0.5), (cid, prec, table, rmsd)
+    tol = 1e-4 if prec == "fp32" else 1e-2
+    assert rel_inf(r["trace_scores"][0][0, 0:3], g["tr_score"][0]) < tol
+    assert rel_inf(r["trace_scores"][0][0, 3:6], g["rot_score"][0]) < tol
+    if prec == "fp32" and rmsd.max() < 1e-3:
+        assert abs(float(r["energy"][0]) - float(g["final_energy"])) < 1e-3
+        assert int(r["num_clashes"][0]) == int(g["final_num_clashes"])
+    gx.close()
+
+
+@pytest.mark.parametrize("cid", REAL_ESM_IDS)
+def test_selfcheck_on_real_features(cid, model):
+    """The 16-bit engine's range and deviation self-check on the complex's own pose: OK, nothing saturated, and at least a factor 4
+    between the largest magnitude stored as fp16 and the fp16 limit (tools/selfcheck_db5.py prints the same lines into
+    profiles/r05_selfcheck_db5.txt)."""
+    from dfmdock_amd import engine
+    gx, _ = _gx(model, cid)
+    for prec in ("mfma16", "f16"):
+        r = gx.selfcheck(n_eval=4, seed=3, precision=prec)
+        line = engine.format_selfcheck(r, cid)
+        assert r["ok"] and r["range_ok"] and r["dev_ok"], line
+        assert r["saturated"] == 0 and r["headroom"] >= 4.0, line
+    gx.close()
