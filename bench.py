@@ -78,6 +78,10 @@ def cpu_baseline(blob, cx, num_steps, repeats=3):
     return {"value": med[best], "unit": "trajectories/s", "cores": best, "kind": "port", "host_cores": all_cores,
             "by_threads": {str(n): {"median": med[n], "repeats": [round(v, 5) for v in runs[n]]} for n in counts},
             "cpu_model": cpu_model(), "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
+            "note": "kind = port: the plain-C restatement of the reference AS WRITTEN (dense [E,641] edge MLP, N x N-free but otherwise "
+                    "unfactorised; 4 x 2 register tiles, no cache blocking).  It does NOT scale to the whole host: past ~32 threads the "
+                    "shared weight stream and ~200 fork / join regions per evaluation dominate (by_threads).  A stated baseline, not a "
+                    "tuned CPU implementation and never the target; the reference itself (PyTorch on CPU) cannot run on this box.",
             "sample": f"per thread count: median of {repeats} x (6 score evaluations at >= 32 threads, 2 below) of 1 trajectory of the "
                       f"same complex after one warm-up evaluation, extrapolated to {num_steps + 1} evaluations per trajectory; "
                       f"value = the best thread count ({best})"}
@@ -97,6 +101,108 @@ def replayed_counters(args):
             and "full" in t.get("edge", {}):
         return t, "replayed profiles/r04_traffic.json"
     return None, None
+
+
+def valu_issue(ctr, n_full, n_lig, rows_full, rows_lig, edge_ms):
+    """VALU-issue floor of the message kernel over the launches of this run: the kernel is bound by what the
+    vector ALU can ISSUE, not by the matrix pipe it is priced against in `roofline.frac`.  Per launch type: T = 4 transcendentals
+    per edge and channel (two SiLUs: v_exp + v_rcp each) / 64 lanes - from the algebra; the other VALU instructions = SQ_INSTS_VALU
+    of the committed PMC pass - T - MFMAs, split packed / plain in the static proportion of the kernel's ISA
+    (profiles/r05_valu_mix.json, tools/valu_mix.py); each class priced at its measured issue cost per wave64 instruction and SIMD
+    at two waves per SIMD (tools/ubench).  frac = floor time / LIVE launch time (HIP events of this run)."""
+    try:
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r05_valu_mix.json")))
+    except OSError:
+        return None
+    k, c = mix["k_edge_msg<1,1,0>"], mix["issue_cycles_per_wave64_instruction_at_2_waves_per_simd"]
+    simds, clock = 256 * 4, c["clock_GHz"] * 1e9
+    pk_share = k["packed_share_of_non_transcendental"]
+    pk_cost = (k["packed_f32"] * c["packed_f32"] + k["packed_16"] * c["packed_16"]) / max(k["packed_f32"] + k["packed_16"], 1)
+    floor_s, detail = 0.0, {}
+    for name, n, rows, key in (("full", n_full, rows_full, "full"), ("ligand_only", n_lig, rows_lig, "lig_only")):
+        if not n or key not in ctr["edge"]:
+            continue
+        insts = ctr["edge"][key]["insts_valu"]                      # wave64 VALU instructions per launch (incl. MFMA issues)
+        T = rows * H * 4 / 64.0
+        mfma = rows / 32.0 * 136                                    # 8 chunks x 16 + 8 bias / epilogue MFMAs per 32-row tile
+        rest = max(insts - T - mfma, 0.0)
+        cyc = T * c["transcendental"] + rest * (pk_share * pk_cost + (1 - pk_share) * c["plain"])
+        detail[name] = {"launches": int(n), "valu_instructions": insts, "transcendental": T, "mfma": mfma, "other": rest,
+                        "floor_ms_per_launch": cyc / simds / clock * 1e3}
+        floor_s += n * cyc / simds / clock
+    return {"frac": floor_s / (edge_ms * 1e-3) if edge_ms > 0 else None, "floor_ms_total": floor_s * 1e3, "measured_ms_total": edge_ms,
+            "by_launch_type": detail, "instruction_mix": {kk: k[kk] for kk in ("transcendental", "packed_f32", "packed_16", "plain", "mfma")},
+            "issue_cycles": {kk: c[kk] for kk in ("transcendental", "packed_f32", "packed_16", "plain")},
+            "source": "instruction counts: replayed SQ_INSTS_VALU (profiles/r04_traffic.json) + algebra; class split: static ISA mix "
+                      "(profiles/r05_valu_mix.json); issue costs: tools/ubench on MI355X; time: live HIP events"}
+
+
+def c5_line(engine, model, pk, num_steps):
+    """Secondary record: BASELINE config 5 (1000+1000 residues, batch 32): one timed dfm_sample call after one warm-up call."""
+    from dfmdock_amd.synthetic import make_complex
+    import torch
+    cx5 = make_complex(1000, 1000, seed=1)
+    g5 = engine.Complex(model, cx5["rec_x"], cx5["lig_x"], cx5["rec_pos"], cx5["lig_pos"])
+    g5.sample(B=32, num_steps=2, seed=3, **pk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g5.sample(B=32, num_steps=num_steps, seed=4, profile=True, **pk)
+    dt = time.perf_counter() - t0
+    p = g5.profile()
+    g5.close()
+    fl = p["edge_rows"] / K_DEG * FLOP_PER_NODE_LAYER
+    ach = fl / (p["edge_kernel_ms"] * 1e-3) / 1e12 if p["edge_kernel_ms"] > 0 else None
+    return {"workload": f"C5: synthetic 1000+1000-residue complex, batch=32 trajectories, {num_steps} steps", "value": 32 / dt,
+            "unit": "trajectories/s", "ms_per_step": dt * 1e3, "steps": 1,
+            "roofline": {"bound": "valu", "kernel": "k_edge_msg<1,1,0>", "achieved": ach, "peak": PEAK_MFMA16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_MFMA16_TFLOPS if ach else None,
+                         "avg_launch_ms": p["edge_kernel_ms"] / max(p["edge_kernel_launches"], 1), "launches": int(p["edge_kernel_launches"]),
+                         "share_of_call": p["edge_kernel_ms"] / (dt * 1e3)},
+            "layer0_table": {"evaluations": int(p["l0_evals"]), "edge_model_fraction": p["l0_miss_rows"] / max(p["l0_edges"], 1),
+                             "rows_launch_ms": p["l0_rows_ms"] / max(p["l0_evals"], 1), "gather_launch_ms": p["l0_gather_ms"] / max(p["l0_evals"], 1)},
+            "whole_path_reference_equivalent_tflops": FLOP_PER_NODE_EVAL * 2000 * (num_steps + 1) * 32 / dt / 1e12}
+
+
+DB5_SIZES = [(223, 172), (368, 327), (242, 101), (311, 145), (470, 105), (426, 200), (432, 129), (238, 91), (102, 95), (223, 129),
+             (195, 125), (269, 161), (170, 207), (355, 75), (275, 107), (275, 64), (574, 54), (263, 141), (120, 120), (420, 115),
+             (127, 246), (117, 471), (427, 65), (87, 127)]      # SURVEY Appendix A: the 24 DB5 test complexes present in the reference
+
+
+def c4_line(engine, model, precision, num_steps):
+    """Secondary record: BASELINE config 4 on ONE GPU - 24 complexes of the DB5 test set's sizes (synthetic chains + features: the
+    data set does not travel) x 40 trajectories through driver.run_set: handle creation, self-check, sampling, 40 x compute_metrics
+    and the CSV inside the clock.  Serial driver (the reference's loop shape, src/inference_mlsb.py:415-439) and the pipelined one."""
+    import tempfile
+    from dfmdock_amd import driver
+    from dfmdock_amd.synthetic import make_complex
+    cxs = []
+    for k, (R, L) in enumerate(DB5_SIZES):
+        c = make_complex(R, L, seed=300 + k)
+        c["id"] = f"S{k:02d}_{R}_{L}"
+        cxs.append(c)
+    tmp = tempfile.mkdtemp(prefix="dfm_c4_")
+    quiet = lambda m: None
+    out = {"workload": "C4 on one GPU: 24 complexes with the DB5 test set's sizes (N = 197..695, synthetic chains and features) x 40 "
+                       f"trajectories x {num_steps} steps through driver.run_set; clock includes handle creation, self-check, metrics, CSV",
+           "unit": "trajectories/s"}
+    driver.run_set(model, cxs[:3], num_samples=40, num_steps=num_steps, seed=0, precision=precision,
+                   out_csv=os.path.join(tmp, "warm.csv"), log=quiet)
+    res = {}
+    for name, kw in (("serial", dict(overlap=False)), ("pipelined", dict(overlap=True)), ("pipelined_2_samplers", dict(overlap=True, samplers=2))):
+        tim = []
+        t0 = time.perf_counter()
+        rows, _ = driver.run_set(model, cxs, num_samples=40, num_steps=num_steps, seed=0, precision=precision,
+                                 out_csv=os.path.join(tmp, name + ".csv"), timings_out=tim, log=quiet, **kw)
+        dt = time.perf_counter() - t0
+        res[name] = {"value": len(rows) / dt, "wall_s": dt, "trajectories": len(rows),
+                     "stage_sums_s": {k: sum(t[k] for t in tim) / 1e3 for k in ("prepare", "sample", "post")}}
+    base = open(os.path.join(tmp, "serial.csv"), "rb").read()
+    out["csv_identical_to_serial"] = all(open(os.path.join(tmp, n + ".csv"), "rb").read() == base for n in res)
+    best = max(res, key=lambda n: res[n]["value"])
+    out.update(value=res[best]["value"], wall_s=res[best]["wall_s"], driver=best, by_driver=res)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 # reference-equivalent work of one score evaluation per residue (SURVEY.md 8d: the reference's dense formulation, all six layers in full)
@@ -168,6 +274,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-l0-table", action="store_true", help="A/B: layer 0 evaluated edge by edge (DFM_F_NO_L0_TABLE)")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the secondary measurement of the fp32 engine (one more batched call)")
+    ap.add_argument("--no-c5-line", action="store_true", help="skip the secondary C5 record (1000+1000 residues, batch 32: one timed call)")
+    ap.add_argument("--no-c4-line", action="store_true", help="skip the secondary C4 record (24 DB5-sized complexes x 40 trajectories through driver.run_set, three drivers)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -305,20 +413,25 @@ def main():
                                     + engine.config_string(),
                        "env_switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DFM_") and k not in
                                         ("DFM_GATHER_DIR", "DFM_BENCH_SELF_SPAWNED")}},
-            "roofline": {"bound": "mfma", "kernel": "k_edge_msg<1,%d> (fp16 operands, all six layers)" % (0 if f16 else 1) if mfma16 else "k_edge_f32",
+            "roofline": {"bound": "valu" if mfma16 else "mfma", "kernel": "k_edge_msg<1,%d> (fp16 operands, all six layers)" % (0 if f16 else 1) if mfma16 else "k_edge_f32",
                          "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
                          "flop_per_launch": flop_per_launch, "traffic": traffic, "traffic_source": ctr_src,
                          "traffic_gbps": (traffic / avg_launch_s / 1e9) if traffic else None,
                          "mfma_busy": mfma_busy, "valu_busy": valu_busy,
+                         "valu_issue": valu_issue(ctr, n_full, n_lig, (edge_rows - lig_launches * B * args.L * K_DEG) / max(n_full, 1),
+                                                  B * args.L * K_DEG, edge_ms) if (ctr and mfma16) else None,
                          "launch_mix": {"full": int(n_full), "ligand_only": int(n_lig),
                                         "avg_full_ms": (edge_ms - lig_ms) / max(n_full, 1), "avg_ligand_only_ms": lig_ms / max(n_lig, 1),
                                         "traffic_full": ctr["edge"]["full"]["hbm_bytes"] if ctr else None,
                                         "traffic_ligand_only": ctr["edge"].get("lig_only", {}).get("hbm_bytes") if ctr else None},
                          "rows_per_launch": edge_rows / max(edge_launches, 1),
                          "algorithmic_bytes_per_launch": 8 * H * edge_rows / K_DEG / max(edge_launches, 1),
-                         "note": "achieved = B*N*(2*K*H*H + 2*K*H) FLOP / launch time from HIP events on the engine's stream, live; "
+                         "note": "bound = valu: the kernel is limited by VALU ISSUE (4 transcendentals + ~11 plain operations per edge and "
+                                 "channel), see valu_issue.frac; achieved / peak / frac price the same launches against the dense 16-bit "
+                                 "MFMA peak as BASELINE's metric asks. "
+                                 "achieved = B*N*(2*K*H*H + 2*K*H) FLOP / launch time from HIP events on the engine's stream, live; "
                                  "traffic = HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE), mfma_busy / valu_busy = pipe-busy fractions "
                                  "(SQ_VALU_MFMA_BUSY_CYCLES, SQ_ACTIVE_INST_VALU x 4 per SIMD over GRBM_GUI_ACTIVE): not measured in this "
                                  "run, see traffic_source; algorithmic bytes per launch = 8*N*H per trajectory (SURVEY 8d)"},
@@ -348,6 +461,11 @@ def main():
                                    "gather_tbps": 512 * l0["l0_edges"] / max(l0["l0_gather_ms"], 1e-9) / 1e9,
                                    "note": "per evaluation: k_edge_msg<1,1,1> over the row list (inter-chain edges + bin mismatches) and "
                                            "k_l0_gather (K rows of 512 B per node, out of L2 / the Infinity Cache) replace one full message launch"}
+        headline = (args.R, args.L, args.batch, args.num_steps) == (300, 300, 256, 40)
+        if world == 1 and mfma16 and headline and not args.no_c5_line:
+            out["c5"] = c5_line(engine, model, pk, args.num_steps)
+        if world == 1 and headline and not args.no_c4_line:
+            out["c4"] = c4_line(engine, model, args.precision, args.num_steps)
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(blob, cx, args.num_steps)
         print(json.dumps(out), flush=True)

@@ -35,7 +35,7 @@ EXPORTS = [
     "dfm_last_error", "dfm_config_string", "dfm_device_count", "dfm_set_device", "dfm_default_hparams", "dfm_param_count",
     "dfm_model_create", "dfm_model_destroy", "dfm_complex_create", "dfm_complex_destroy", "dfm_complex_degree",
     "dfm_complex_set_pose", "dfm_complex_set_homomer",
-    "dfm_score", "dfm_sample", "dfm_get_profile", "dfm_diffusion_coef", "dfm_complex_selfcheck",
+    "dfm_score", "dfm_sample", "dfm_get_profile", "dfm_diffusion_coef", "dfm_complex_selfcheck", "dfm_trim_cache",
 ]
 
 
@@ -118,6 +118,8 @@ def lib():
                              C.POINTER(InjectC), C.POINTER(TrajOutC)]
     L.dfm_get_profile.argtypes = [C.c_void_p, C.POINTER(ProfileC)]
     L.dfm_complex_selfcheck.argtypes = [C.c_void_p, C.c_int, F32P, C.c_uint64, C.c_uint32, C.POINTER(SelfcheckC)]
+    L.dfm_trim_cache.argtypes = [C.c_int]
+    L.dfm_trim_cache.restype = C.c_longlong
     L.dfm_diffusion_coef.argtypes = [C.POINTER(HParamsC), C.c_int, C.c_double, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
     _lib = L

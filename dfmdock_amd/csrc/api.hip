@@ -64,18 +64,46 @@ struct BlockCache {
         static const bool on = [] { const char *e = getenv("DFM_ALLOC_CACHE"); return !(e && atoi(e) == 0); }();
         return on;
     }
+    static double fraction()      // share of a device's memory the cache may park (DFM_ALLOC_CACHE_FRAC, default 0.25)
+    {
+        static const double f = [] {
+            const char *e = getenv("DFM_ALLOC_CACHE_FRAC");
+            const double v = e ? atof(e) : 0.25;
+            return v < 0.0 ? 0.0 : (v > 0.9 ? 0.9 : v);
+        }();
+        return f;
+    }
     bool give(int dev, void *p, size_t size)
     {
         std::lock_guard<std::mutex> g(m);
         if (!cap[dev]) {
             size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0;
-            cap[dev] = tot / 4 + 1;
+            DeviceScope ds(dev);      // the memory of the block's OWN device, whatever the calling thread's current device is
+            if (ds.err != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) tot = 0;
+            cap[dev] = (size_t)((double)tot * fraction()) + 1;
         }
         if (bytes[dev] + size > cap[dev]) return false;
         free_blocks[dev].emplace(size, p);
         bytes[dev] += size;
         return true;
+    }
+    // hand every parked block of `dev` (all devices: dev < 0) back to the driver; returns the bytes freed
+    size_t trim(int dev)
+    {
+        std::vector<std::pair<int, void *>> drop;
+        size_t freed = 0;
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (int d = 0; d < MAX_DEVICES; ++d) {
+                if (dev >= 0 && d != dev) continue;
+                for (auto &kv : free_blocks[d]) drop.emplace_back(d, kv.second);
+                freed += bytes[d];
+                free_blocks[d].clear();
+                bytes[d] = 0;
+            }
+        }
+        for (auto &dp : drop) { DeviceScope ds(dp.first); (void)hipFree(dp.second); }
+        return freed;
     }
 };
 static BlockCache &g_block_cache = *new BlockCache;      // never destroyed: a handle may outlive static destruction at process exit
@@ -83,12 +111,20 @@ static BlockCache &g_block_cache = *new BlockCache;      // never destroyed: a h
 struct DevPool {
     struct Block { void *p; size_t size; int dev; };
     std::vector<Block> ptrs;
+    hipStream_t owner = nullptr;      // bind(): the one stream that ever touches this pool's blocks
+    bool bound = false;
+    void bind(hipStream_t s) { owner = s; bound = true; }
     ~DevPool() { release(); }
-    void release()
+    // `drained`: the caller has synchronised the ONE stream that ever touched these blocks (a complex handle's own stream), so
+    // nothing in flight reads them and the device-wide wait - which would also wait for every OTHER handle's queued work, e.g. a
+    // whole dfm_sample call of the next complex of a set run - is not needed.
+    void release(bool drained = false)
     {
         if (ptrs.empty()) return;
         if (BlockCache::enabled()) {
-            (void)hipDeviceSynchronize();      // what hipFree would have done: nothing in flight reads these blocks when the next owner gets them
+            // what hipFree would have done: nothing in flight reads these blocks when the next owner gets them (a bound pool waits
+            // for its own stream only)
+            if (!drained) { if (bound) (void)hipStreamSynchronize(owner); else (void)hipDeviceSynchronize(); }
             for (const Block &b : ptrs)
                 if (b.dev < 0 || b.dev >= MAX_DEVICES || !g_block_cache.give(b.dev, b.p, b.size)) (void)hipFree(b.p);
         } else {
@@ -143,6 +179,13 @@ struct DevPool {
         if (e != hipSuccess) return e;
         return hipMemcpy(*out, host, n * sizeof(T), hipMemcpyHostToDevice);
     }
+    // the same on a handle's own (non-blocking) stream: the caller synchronises it before `host` may change
+    template <typename T> hipError_t upload_async(T **out, const T *host, size_t n, hipStream_t s)
+    {
+        hipError_t e = alloc(out, n);
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync(*out, host, n * sizeof(T), hipMemcpyHostToDevice, s);
+    }
 };
 
 struct dfm_model {
@@ -181,6 +224,9 @@ struct Workspace {
     unsigned long long *l0_miss_total = nullptr;
     // replayed step graph: {evaluations started, seed lo, seed hi, -} and the per-step scalars of the call's time grid
     uint32_t *step_ctl = nullptr; StepParams *step_params = nullptr;
+    // t_dev / hid_base / step_params live in their own pool, sized for max(Bcap, the longest time grid asked for so far)
+    DevPool tpool;
+    size_t Tcap = 0;
 };
 
 struct dfm_complex {
@@ -609,20 +655,26 @@ extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, con
     cx->K = degree_of(m->hp, cx->N, &cx->knn, &cx->nsamp);
     const int N = cx->N, lm = m->hp.lm_embed_dim;
     DevPool &P = cx->pool;
-    bool ok = hipStreamCreate(&cx->stream) == hipSuccess;
+    // A handle's stream is NON-BLOCKING and everything the handle does - uploads included - is ordered on it: nothing here goes
+    // through the legacy default stream, whose implicit synchronisation would make the creation of the next complex of a set run
+    // wait for the whole dfm_sample call of the current one (driver.run_set overlaps the two from separate host threads).
+    bool ok = hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreate(&cx->ev_total[0]) == hipSuccess && hipEventCreate(&cx->ev_total[1]) == hipSuccess;
     float *x = nullptr;
-    ok = ok && hipMalloc(reinterpret_cast<void **>(&x), (size_t)N * lm * sizeof(float)) == hipSuccess;
-    ok = ok && hipMemcpy(x, rec_x, (size_t)R * lm * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(x + (size_t)R * lm, lig_x, (size_t)L * lm * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && P.upload(&cx->rec_pos, rec_pos, (size_t)R * 9) == hipSuccess;
-    ok = ok && P.upload(&cx->lig0, lig_pos, (size_t)L * 9) == hipSuccess;
+    cx->pool.bind(cx->stream); cx->ws.pool.bind(cx->stream); cx->l0_pool.bind(cx->stream); cx->l0_pool32.bind(cx->stream);
+    DevPool tmp;      // staging of the raw node features: a cached block (hipMalloc / hipFree would drain the device)
+    tmp.bind(cx->stream);
+    ok = ok && tmp.alloc(&x, (size_t)N * lm) == hipSuccess;
+    ok = ok && hipMemcpyAsync(x, rec_x, (size_t)R * lm * sizeof(float), hipMemcpyHostToDevice, cx->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(x + (size_t)R * lm, lig_x, (size_t)L * lm * sizeof(float), hipMemcpyHostToDevice, cx->stream) == hipSuccess;
+    ok = ok && P.upload_async(&cx->rec_pos, rec_pos, (size_t)R * 9, cx->stream) == hipSuccess;
+    ok = ok && P.upload_async(&cx->lig0, lig_pos, (size_t)L * 9, cx->stream) == hipSuccess;
     ok = ok && P.alloc(&cx->h0, (size_t)N * H) == hipSuccess && P.alloc(&cx->A0, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->Bm0, (size_t)N * H) == hipSuccess && P.alloc(&cx->Bmb0, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->A0s, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->A0h, (size_t)N * H) == hipSuccess;
 #ifdef DFM_EDGE_STAMP
-    ok = ok && P.alloc(&cx->stamp_dev, 48) == hipSuccess && hipMemset(cx->stamp_dev, 0, 48 * 8) == hipSuccess;
+    ok = ok && P.alloc(&cx->stamp_dev, 48) == hipSuccess && hipMemsetAsync(cx->stamp_dev, 0, 48 * 8, cx->stream) == hipSuccess;
 #endif
     if (ok) {
         // node = single_embed(cat[rec_x, lig_x]) (score_net_mlsb.py:365-366): pose independent, once per complex
@@ -631,9 +683,11 @@ extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, con
         g.A0 = x; g.lda = lm; g.K = lm; g.W = m->single_embed; g.ldw = lm; g.M = N; g.Nout = H; g.C = cx->h0; g.ldc = H;
         ok = launch_gemm_f32(g, cx->stream) == hipSuccess;
         ok = ok && project_layer0(cx) == hipSuccess;
-        ok = ok && hipStreamSynchronize(cx->stream) == hipSuccess;
     }
-    if (x) (void)hipFree(x);
+    // (also on failure: the uploads above may still be reading the caller's buffers)
+    const bool drained = cx->stream && hipStreamSynchronize(cx->stream) == hipSuccess;
+    ok = ok && drained;
+    tmp.release(drained);
     if (!ok) {
         fail(DFM_E_HIP, std::string("complex creation failed: ") + hipGetErrorString(hipGetLastError()));
         dfm_complex_destroy(cx);
@@ -646,7 +700,11 @@ extern "C" void dfm_complex_destroy(dfm_complex *cx)
 {
     if (!cx) return;
     DeviceScope ds(cx->device);
-    if (cx->stream) { (void)hipStreamSynchronize(cx->stream); (void)hipStreamDestroy(cx->stream); }
+    bool drained = false;
+    if (cx->stream) drained = hipStreamSynchronize(cx->stream) == hipSuccess;
+    // every block of the handle was only ever touched by its own stream, which is drained now: no device-wide wait
+    cx->ws.pool.release(drained); cx->ws.tpool.release(drained); cx->l0_pool.release(drained); cx->l0_pool32.release(drained); cx->pool.release(drained);
+    if (cx->stream) (void)hipStreamDestroy(cx->stream);
     if (cx->step_exec) (void)hipGraphExecDestroy(cx->step_exec);
     for (hipEvent_t e : cx->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : cx->ev_l0) (void)hipEventDestroy(e);
@@ -660,8 +718,9 @@ extern "C" int dfm_complex_set_pose(dfm_complex *cx, const float *rec_pos, const
     DEVICE_SCOPE(cx->device);
     // the stream may still read the old poses (an earlier call never returns before its work is done, but stay safe)
     HIPCHK(hipStreamSynchronize(cx->stream));
-    if (rec_pos) HIPCHK(hipMemcpy(cx->rec_pos, rec_pos, (size_t)cx->R * 9 * sizeof(float), hipMemcpyHostToDevice));
-    if (lig_pos) HIPCHK(hipMemcpy(cx->lig0, lig_pos, (size_t)cx->L * 9 * sizeof(float), hipMemcpyHostToDevice));
+    if (rec_pos) HIPCHK(hipMemcpyAsync(cx->rec_pos, rec_pos, (size_t)cx->R * 9 * sizeof(float), hipMemcpyHostToDevice, cx->stream));
+    if (lig_pos) HIPCHK(hipMemcpyAsync(cx->lig0, lig_pos, (size_t)cx->L * 9 * sizeof(float), hipMemcpyHostToDevice, cx->stream));
+    HIPCHK(hipStreamSynchronize(cx->stream));
     cx->l0_valid = false; cx->l0_valid32 = false;      // the intra-chain geometry may have changed: the layer-0 message tables are rebuilt on next use
     return DFM_OK;
 }
@@ -692,6 +751,11 @@ extern "C" int dfm_complex_set_homomer(dfm_complex *cx, int flag)
 
 extern "C" int dfm_complex_degree(const dfm_complex *cx) { return cx ? cx->K : -1; }
 
+extern "C" long long dfm_trim_cache(int device)
+{
+    return (long long)g_block_cache.trim(device < 0 || device >= MAX_DEVICES ? -1 : device);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Layer 0 behind the message table: budgets.  The table costs 516 B per intra-chain ordered pair (8 M pairs = 4.1 GB: 2000 + 2000
 // residues), the per-batch buffers 532 B per edge of a batched evaluation (32 M edges = 17 GB: B = 890 at 300+300) - sized for
@@ -705,7 +769,23 @@ static bool l0_eligible(const dfm_complex *cx, int B)
     return pairs <= L0_MAX_PAIRS && (long long)B * cx->N * cx->K <= L0_MAX_EDGES;
 }
 
-constexpr int MAX_TIME_GRID = 4096;      // steps of a dfm_sample call whose time embeddings fit the workspace (more: DFM_E_INVALID)
+constexpr int MIN_TIME_GRID = 4096;      // smallest time grid the workspace is sized for (dfm_sample grows it for longer schedules)
+// t_dev [n], hid_base [n][2][128], step_params [n]: one entry per trajectory (dfm_score) or per step of the time grid (dfm_sample).
+// The reference's sampler takes any num_steps (inference_base.py:403-404: np.linspace(1, eps, num_steps)), so does this one.
+static int ensure_time_grid(dfm_complex *cx, size_t n)
+{
+    Workspace &W = cx->ws;
+    if (n < (size_t)MIN_TIME_GRID) n = MIN_TIME_GRID;
+    if (n <= W.Tcap) return DFM_OK;
+    HIPCHK(hipStreamSynchronize(cx->stream));
+    W.tpool.release(true);
+    W.tpool.bind(cx->stream);
+    W.Tcap = 0;
+    cx->buf_gen++;
+    HIPCHK(W.tpool.alloc(&W.t_dev, n)); HIPCHK(W.tpool.alloc(&W.hid_base, n * 2 * HI)); HIPCHK(W.tpool.alloc(&W.step_params, n));
+    W.Tcap = n;
+    return DFM_OK;
+}
 static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
 {
     Workspace &W = cx->ws;
@@ -719,8 +799,9 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
     if (B <= W.Bcap && !need_mbuf && !need_l0) return DFM_OK;
     if (B > W.Bcap) {
         HIPCHK(hipStreamSynchronize(cx->stream));
-        W.pool.release();
+        W.pool.release(true); W.tpool.release(true);
         W = Workspace();
+        W.pool.bind(cx->stream);
         cx->buf_gen++;
         const size_t N = cx->N, L = cx->L, R = cx->R, K = cx->K, b = B;
         HIPCHK(W.pool.alloc(&W.pos, b * N * 9)); HIPCHK(W.pool.alloc(&W.ca4, b * N)); HIPCHK(W.pool.alloc(&W.cb4, b * N));
@@ -741,9 +822,9 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
             HIPCHK(W.pool.alloc(&W.pair_s, b * L * (((R + 31) / 32) * 32)));
         }
         HIPCHK(W.pool.alloc(&W.lig_cur, b * L * 9)); HIPCHK(W.pool.alloc(&W.tr_update, b * 3));
-        HIPCHK(W.pool.alloc(&W.rot_update, b * 3)); HIPCHK(W.pool.alloc(&W.t_dev, b > MAX_TIME_GRID ? b : (size_t)MAX_TIME_GRID));
-        HIPCHK(W.pool.alloc(&W.hid_base, (b > MAX_TIME_GRID ? b : (size_t)MAX_TIME_GRID) * 2 * HI));
-        HIPCHK(W.pool.alloc(&W.step_ctl, 4)); HIPCHK(W.pool.alloc(&W.step_params, (size_t)MAX_TIME_GRID));
+        HIPCHK(W.pool.alloc(&W.rot_update, b * 3));
+        HIPCHK(W.pool.alloc(&W.step_ctl, 4));
+        { const int rc = ensure_time_grid(cx, b); if (rc) return rc; }
         W.Bcap = B;
     }
     if (wants_mbuf && !W.mbuf) { HIPCHK(W.pool.alloc(&W.mbuf, (size_t)W.Bcap * cx->L * KPAD * H)); cx->buf_gen++; }
@@ -791,7 +872,7 @@ static int build_l0_table(dfm_complex *cx, float *build_ms, bool fp32 = false)
     const size_t R = cx->R, L = cx->L, P = R * R + L * L;
     (fp32 ? cx->l0_valid32 : cx->l0_valid) = false;
     HIPCHK(hipStreamSynchronize(s));
-    (fp32 ? cx->l0_pool32 : cx->l0_pool).release();
+    (fp32 ? cx->l0_pool32 : cx->l0_pool).release(true);
     cx->buf_gen++;
     uint32_t *code0 = nullptr;
     if (fp32) {
@@ -804,6 +885,7 @@ static int build_l0_table(dfm_complex *cx, float *build_ms, bool fp32 = false)
         code0 = cx->l0_code0;
     }
     DevPool tmp;
+    tmp.bind(s);
     uint4 *rows = nullptr;
     HIPCHK(tmp.alloc(&rows, P));
     HIPCHK(hipEventRecord(cx->ev_total[0], s));
@@ -814,6 +896,7 @@ static int build_l0_table(dfm_complex *cx, float *build_ms, bool fp32 = false)
     else HIPCHK(launch_edge_rows(layer0_edge_args(cx), rows, nullptr, (uint32_t)P, cx->l0_table, s));
     HIPCHK(hipEventRecord(cx->ev_total[1], s));
     HIPCHK(hipStreamSynchronize(s));
+    tmp.release(true);
     if (build_ms) HIPCHK(hipEventElapsedTime(build_ms, cx->ev_total[0], cx->ev_total[1]));
     (fp32 ? cx->l0_valid32 : cx->l0_valid) = true;
     return DFM_OK;
@@ -1054,7 +1137,13 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         // egnn_net.py:430-470: pair heads on cat[h_r, h_l, D].  Per head: one GEMM projects every node through the stacked
         // halves of Linear(513 -> 256) (reusing the A / Bm buffers), then the elementwise pair kernel.
         static const bool pair_valu = [] { const char *e = getenv("DFM_PAIR_HEAD_VALU"); return e && atoi(e) != 0; }();      // A/B: r02-r03 kernel
-        const bool pair_m = !pair_valu;      // every engine: the kernel computes in fp32 (moment-based LayerNorm statistics, 1-ulp hardware exp2 / rcp)
+        // 16-bit engines: k_pair_head_m (LayerNorm statistics from fp32 row moments + a dot product, 1-ulp hardware exp2 / rcp).
+        // The fp32 engine - the baseline of dfm_complex_selfcheck and the fallback when a check fails - keeps the three-pass
+        // LayerNorm, expf and IEEE division of k_pair_head<EXACT>: z = P + Q + w_d * D with D up to hundreds of Angstroms, so
+        // E[z^2] - mean^2 loses digits to cancellation exactly when a trained checkpoint has a large mean / std ratio, which no
+        // synthetic draw shows.  DFM_PAIR_HEAD_M32=1 opts the fp32 engine into the matrix-pipe kernel (+10 %).
+        static const bool pair_m32 = [] { const char *e = getenv("DFM_PAIR_HEAD_M32"); return e && atoi(e) != 0; }();
+        const bool pair_m = !pair_valu && (o.bf16 || pair_m32);
         auto run_head = [&](int q, int mode) -> int {
             const PairHeadDev &Ph = m->pair[q];
             GemmArgs g;
@@ -1132,13 +1221,15 @@ static int finish_profile(dfm_complex *cx)
     }
     if (cx->prof.l0_evals > 0 && cx->ws.l0_miss_total) {
         unsigned long long tot = 0;
-        HIPCHK(hipMemcpy(&tot, cx->ws.l0_miss_total, sizeof(tot), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(&tot, cx->ws.l0_miss_total, sizeof(tot), hipMemcpyDeviceToHost, cx->stream));
+        HIPCHK(hipStreamSynchronize(cx->stream));
         cx->prof.l0_miss_rows = (int64_t)tot;
     }
 #ifdef DFM_EDGE_STAMP
     if (cx->stamp_dev) {
         unsigned long long st[48];
-        HIPCHK(hipMemcpy(st, cx->stamp_dev, sizeof(st), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(st, cx->stamp_dev, sizeof(st), hipMemcpyDeviceToHost, cx->stream));
+        HIPCHK(hipStreamSynchronize(cx->stream));
         for (int k = 0; k < 16; ++k) cx->prof.slot_cycles[k] = (double)st[32 + k];
         const double tiles = (double)cx->prof.edge_rows / (double)cx->prof.edge_kernel_launches / 32.0 / 2048.0;   // per wave
         for (int k = 0; k < 4; ++k) {
@@ -1193,6 +1284,7 @@ extern "C" int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const flo
     HIPCHK(hipMemcpyAsync(W.t_dev, t, (size_t)B * sizeof(float), hipMemcpyHostToDevice, s));
     HIPCHK(launch_time_embed(W.t_dev, B, &cx->m->heads, W.hid_base, s));      // one entry per trajectory (fill_head_args: stride 2 * HI)
     DevPool tmp;   // per-call device buffers (injected edges, debug tap); released on every return path
+    tmp.bind(cx->stream);
     int32_t *edges_dev = nullptr;
     float *h_first_dev = nullptr;
     if (edges) {
@@ -1285,14 +1377,18 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
 {
     if (!cx || !out) return fail(DFM_E_INVALID, "NULL argument");
     if (B < 1 || num_steps < 2) return fail(DFM_E_INVALID, "need B >= 1 and num_steps >= 2");
-    if (num_steps > MAX_TIME_GRID) return fail(DFM_E_INVALID, "num_steps above 4096");
+    if (num_steps > (1 << 24)) return fail(DFM_E_INVALID, "num_steps above 2^24");
     const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_MFMA16) || f16;
     DEVICE_SCOPE(cx->device);
-    // layer 0 through the complex's message table whenever the shipped 16-bit plan runs and the complex is eligible - a property of
-    // the complex, not of the batch (below the edge budget), so a trajectory's result does not depend on the batch it is sampled in
+    // layer 0 through the complex's message table whenever the shipped 16-bit plan (or the fp32 engine) runs and the complex is
+    // eligible.  Eligibility is a property of the complex EXCEPT for the edge budget of one batched evaluation (l0_eligible:
+    // B * N * K <= 32 M edges = B <= 890 at 300+300): a caller that wants a trajectory's bits not to depend on the batch it is
+    // sampled in keeps B below that budget - dfmdock_amd/score_model.py and driver.py cap a call at 256 - or passes
+    // DFM_F_NO_L0_TABLE (dfmdock_amd.h)
     const bool l0 = ((bf16 && !f16 && !(flags & DFM_F_BF16_OPS)) || !bf16) && !(flags & DFM_F_NO_L0_TABLE) && l0_eligible(cx, B);
     int rc = ensure_workspace(cx, B, bf16, l0);
     if (rc) return rc;
+    if ((rc = ensure_time_grid(cx, (size_t)(B > num_steps ? B : num_steps))) != DFM_OK) return rc;
     Workspace &W = cx->ws;
     hipStream_t s = cx->stream;
     const dfm_hparams &hp = cx->m->hp;
@@ -1325,6 +1421,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     }
 
     DevPool tmp;   // per-call device buffers (injections, traces)
+    tmp.bind(cx->stream);
     float *R0_d = nullptr, *trd_d = nullptr, *zr_d = nullptr, *zt_d = nullptr, *tp_d = nullptr, *tsc_d = nullptr,
           *ip_d = nullptr;
     int32_t *ed_d = nullptr;
@@ -1490,6 +1587,7 @@ extern "C" int dfm_complex_selfcheck(dfm_complex *cx, int n_eval, const float *t
     cx->ev_used = 0; cx->ev_l0_used = 0;
     cx->fwd_counter = 0;
     DevPool tmp;
+    tmp.bind(s);
     uint32_t *range_d = nullptr;
     unsigned long long *sat_d = nullptr;
     int32_t *edges_d = nullptr;
@@ -1525,12 +1623,14 @@ extern "C" int dfm_complex_selfcheck(dfm_complex *cx, int n_eval, const float *t
     Res r32, r16;
     std::vector<float4> ca(N);      // centred CA of the (one) pose: r of the torque pooling
     if ((rc = run(false, r32)) != DFM_OK) { (void)hipStreamSynchronize(s); return rc; }
-    HIPCHK(hipMemcpy(ca.data(), W.ca4, N * sizeof(float4), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(ca.data(), W.ca4, N * sizeof(float4), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     if ((rc = run(true, r16)) != DFM_OK) { (void)hipStreamSynchronize(s); return rc; }
     std::vector<uint32_t> rg((size_t)(depth + 1) * 8);
     unsigned long long sat = 0;
-    HIPCHK(hipMemcpy(rg.data(), range_d, rg.size() * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&sat, sat_d, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(rg.data(), range_d, rg.size() * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&sat, sat_d, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
 
     dfm_selfcheck_out &o = *out;
     std::memset(&o, 0, sizeof(o));

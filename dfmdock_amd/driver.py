@@ -69,11 +69,80 @@ def checked_precision(gx: engine.Complex, precision: str, name: str, selfcheck=T
     return precision, r
 
 
+class _Prepared:
+    """One complex ready to sample: its handle, the pose it was created on and everything derived from that pose alone."""
+    __slots__ = ("ci", "c", "gx", "rec_pos", "lig_pos", "native", "precision", "check", "ms")
+
+
+def _prepare(model, c, ci, rot_seed, global_rotation, precision, selfcheck, on_selfcheck_fail, seed, log=None) -> _Prepared:
+    """Stage 1 of run_set (host + a little device work on the new handle's own stream): loader semantics, handle, self-check."""
+    import time
+    t0 = time.perf_counter()
+    p = _Prepared()
+    p.ci, p.c = ci, c
+    rec_pos, lig_pos = np.asarray(c["rec_pos"], np.float32), np.asarray(c["lig_pos"], np.float32)
+    if global_rotation:
+        rec_pos, lig_pos = random_rotation(rec_pos, lig_pos, np.random.default_rng(rot_seed))
+    p.rec_pos, p.lig_pos = rec_pos, lig_pos
+    p.gx = engine.Complex(model, c["rec_x"], c["lig_x"], rec_pos, lig_pos)
+    p.native = NativeContext((rec_pos, lig_pos))
+    p.precision, p.check = checked_precision(p.gx, precision, str(c.get("id", ci)), selfcheck, on_selfcheck_fail, log=log, seed=seed)
+    p.ms = {"prepare": (time.perf_counter() - t0) * 1e3}
+    return p
+
+
+def _sample(p: _Prepared, t_lo, t_hi, num_steps, seed, max_batch, trace, sampler_kw):
+    """Stage 2: the trajectories of this rank's share, in batches of at most max_batch."""
+    import time
+    t0 = time.perf_counter()
+    batches, done = [], t_lo
+    while done < t_hi:
+        b = min(max_batch, t_hi - done)
+        r = p.gx.sample(B=b, num_steps=num_steps, seed=seed * 100003 + p.ci * 1009 + done, trace=trace,
+                        **engine.precision_kwargs(p.precision), **sampler_kw)
+        batches.append((done, b, r))
+        done += b
+    p.ms["sample"] = (time.perf_counter() - t0) * 1e3
+    return batches
+
+
+def _post(p: _Prepared, batches, traj_dir):
+    """Stage 3 (host): per-trajectory metrics against the native pose (inference_mlsb.py:232-262), trajectory PDBs, records;
+    releases the handle."""
+    import time
+    t0 = time.perf_counter()
+    c, rows, records = p.c, [], []
+    for done, b, r in batches:
+        for k in range(b):
+            m = compute_metrics((p.rec_pos, r["lig_pos"][k]), (p.rec_pos, p.lig_pos), p.native)
+            rows.append({"id": c.get("id", str(p.ci)), "index": str(done + k), **m, "energy": float(r["energy"][k]),
+                         "num_clashes": int(r["num_clashes"][k])})
+            if traj_dir is not None and "rec_seq" in c:
+                os.makedirs(traj_dir, exist_ok=True)
+                frames = r["trace_pose"][k]
+                pdbio.write_trajectory_pdb(os.path.join(traj_dir, f"{c.get('id', p.ci)}_p{done + k}.pdb"),
+                                           [p.rec_pos] * len(frames), frames, c["rec_seq"], c["lig_seq"])
+        records.append(D.make_records(p.ci, np.arange(done, done + b), r))
+    p.gx.close()
+    p.ms["post"] = (time.perf_counter() - t0) * 1e3
+    return rows, records
+
+
 def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0, precision="mfma16", global_rotation=True,
-            out_csv=None, traj_dir=None, max_batch=256, selfcheck=True, on_selfcheck_fail="fp32", checks_out=None, **sampler_kw):
+            out_csv=None, traj_dir=None, max_batch=256, selfcheck=True, on_selfcheck_fail="fp32", checks_out=None,
+            overlap=True, samplers=1, timings_out=None, log=None, **sampler_kw):
     """Sample `num_samples` trajectories for every complex dict (id, rec_x, lig_x, rec_pos, lig_pos[, rec_seq, lig_seq]);
     returns the metric rows of this rank's share; rank 0 writes the gathered CSV when `out_csv` is given.  Every complex is
-    self-checked first (checked_precision); `checks_out` (a list) collects {id, precision used, check dict}."""
+    self-checked first (checked_precision); `checks_out` (a list) collects {id, precision used, check dict}.
+
+    The reference's loop (src/inference_mlsb.py:415-439 over :188-262) is serial: load, sample, score, next.  Here the three
+    stages of a complex run on three host threads (`overlap=True`): while complex k samples on its handle's stream, complex k+1
+    is created and self-checked on ITS handle's stream (dfmdock_amd.h: handles are independent) and complex k-1's 40 Kabsch
+    fits / CSV rows are computed on the host; `samplers` > 1 lets that many complexes sample concurrently (small complexes do
+    not fill the GPU at B = 40).  Results do not depend on any of this: a trajectory is a pure function of (seed, complex,
+    trajectory index), so the rows equal the serial driver's (`overlap=False`) bit for bit.  `timings_out` (a list) collects
+    per-complex {id, N, prepare, sample, post} milliseconds; `log` receives the self-check lines
+    (default: stderr)."""
     rank, _, world = D.dist_env()
     complexes = list(complexes)
     split_trajectories = world > 1 and len(complexes) < 2 * world
@@ -85,36 +154,67 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
         t_lo, t_hi = 0, num_samples
     rng = np.random.default_rng(seed)
     rots = [rng.integers(0, 2 ** 31) for _ in complexes]      # per-complex streams, identical on every rank
+    if t_hi <= t_lo:
+        share = []
+    trace = traj_dir is not None
+
+    def prep(ci):
+        return _prepare(model, complexes[ci], ci, rots[ci], global_rotation, precision, selfcheck, on_selfcheck_fail, seed, log)
+
+    def samp(p):
+        return _sample(p, t_lo, t_hi, num_steps, seed, max_batch, trace, sampler_kw)
+
+    done = []      # (prepared, rows, records) in share order
+    if not overlap or len(share) < 2:
+        for ci in share:
+            p = prep(ci)
+            rows_c, recs_c = _post(p, samp(p), traj_dir)
+            done.append((p, rows_c, recs_c))
+    else:
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        ahead = threading.Semaphore(samplers + 1)      # handles prepared but not yet sampling: bounds the device memory in flight
+
+        def prep_gated(ci):
+            ahead.acquire()
+            try:
+                return prep(ci)
+            except BaseException:
+                ahead.release()
+                raise
+
+        def samp_of(fp):
+            p = fp.result()
+            ahead.release()
+            return p, samp(p)
+
+        def post_of(fs):
+            p, batches = fs.result()
+            rows_c, recs_c = _post(p, batches, traj_dir)
+            return p, rows_c, recs_c
+
+        with ThreadPoolExecutor(1, thread_name_prefix="dfm-prep") as ex_prep, \
+                ThreadPoolExecutor(max(1, int(samplers)), thread_name_prefix="dfm-sample") as ex_samp, \
+                ThreadPoolExecutor(1, thread_name_prefix="dfm-post") as ex_post:
+            f_prep = [ex_prep.submit(prep_gated, ci) for ci in share]
+            f_samp = [ex_samp.submit(samp_of, f) for f in f_prep]
+            f_post = [ex_post.submit(post_of, f) for f in f_samp]
+            try:
+                done = [f.result() for f in f_post]
+            except BaseException:
+                for f in f_prep + f_samp + f_post:
+                    f.cancel()
+                for _ in share:      # un-block a prepare stage parked on the gate
+                    ahead.release()
+                raise
     rows, records = [], []
-    for ci in share:
-        if t_hi <= t_lo:
-            break
-        c = complexes[ci]
-        rec_pos, lig_pos = np.asarray(c["rec_pos"], np.float32), np.asarray(c["lig_pos"], np.float32)
-        if global_rotation:
-            rec_pos, lig_pos = random_rotation(rec_pos, lig_pos, np.random.default_rng(rots[ci]))
-        gx = engine.Complex(model, c["rec_x"], c["lig_x"], rec_pos, lig_pos)
-        native = NativeContext((rec_pos, lig_pos))
-        use_prec, chk = checked_precision(gx, precision, str(c.get("id", ci)), selfcheck, on_selfcheck_fail, seed=seed)
+    for p, rows_c, recs_c in done:
+        rows += rows_c
+        records += recs_c
         if checks_out is not None:
-            checks_out.append({"id": c.get("id", str(ci)), "precision": use_prec, "selfcheck": chk})
-        done = t_lo
-        while done < t_hi:
-            b = min(max_batch, t_hi - done)
-            r = gx.sample(B=b, num_steps=num_steps, seed=seed * 100003 + ci * 1009 + done, trace=traj_dir is not None,
-                          **engine.precision_kwargs(use_prec), **sampler_kw)
-            for k in range(b):
-                m = compute_metrics((rec_pos, r["lig_pos"][k]), (rec_pos, lig_pos), native)
-                rows.append({"id": c.get("id", str(ci)), "index": str(done + k), **m, "energy": float(r["energy"][k]),
-                             "num_clashes": int(r["num_clashes"][k])})
-                if traj_dir is not None and "rec_seq" in c:
-                    os.makedirs(traj_dir, exist_ok=True)
-                    frames = r["trace_pose"][k]
-                    pdbio.write_trajectory_pdb(os.path.join(traj_dir, f"{c.get('id', ci)}_p{done + k}.pdb"),
-                                               [rec_pos] * len(frames), frames, c["rec_seq"], c["lig_seq"])
-            records.append(D.make_records(ci, np.arange(done, done + b), r))
-            done += b
-        gx.close()
+            checks_out.append({"id": p.c.get("id", str(p.ci)), "precision": p.precision, "selfcheck": p.check})
+        if timings_out is not None:
+            timings_out.append({"id": p.c.get("id", str(p.ci)), "N": p.gx.N, **p.ms})
     recs = np.concatenate(records, 0) if records else np.zeros((0, D.RECORD_WIDTH), np.float32)
     ranked = D.rank_by_energy(D.gather_records(recs)) if world > 1 or len(recs) else {}
     if out_csv is not None:
@@ -136,16 +236,18 @@ def _gather_rows(rows, world):
 
 
 def dock_pair(model: engine.Model, rec, lig, rec_x, lig_x, num_samples=120, num_steps=40, seed=0, precision="mfma16",
-              out_pdb="output.pdb", max_batch=256, selfcheck=True, on_selfcheck_fail="fp32"):
+              out_pdb="output.pdb", max_batch=256, selfcheck=True, on_selfcheck_fail="fp32", **sampler_kw):
     """inference() of the reference for two parsed PDB chains (pdbio.backbone_from_atoms dicts) and their
-    pre-computed node features; returns {'energy': min energy} and writes the best pose."""
+    pre-computed node features; returns {'energy': min energy} and writes the best pose.  `sampler_kw` are the sampler options
+    the reference's pair loop passes (src/inference_base.py:483-491: use_clash_force, noise_annealing, tr_noise_scale,
+    rot_noise_scale, ode)."""
     gx = engine.Complex(model, rec_x, lig_x, rec["bb_coords"], lig["bb_coords"])
     precision, chk = checked_precision(gx, precision, "pair", selfcheck, on_selfcheck_fail, seed=seed)
     best = None
     done = 0
     while done < num_samples:
         b = min(max_batch, num_samples - done)
-        r = gx.sample(B=b, num_steps=num_steps, seed=seed + done, **engine.precision_kwargs(precision))
+        r = gx.sample(B=b, num_steps=num_steps, seed=seed + done, **engine.precision_kwargs(precision), **sampler_kw)
         k = int(np.argmin(r["energy"]))
         if best is None or r["energy"][k] < best[0]:     # strict <: the first minimum wins, as in the reference
             best = (float(r["energy"][k]), r["rot_update"][k].copy(), r["tr_update"][k].copy())

@@ -60,6 +60,11 @@ def config_string() -> str:
     return L.lib().dfm_config_string().decode()
 
 
+def trim_cache(device: int = -1) -> int:
+    """Hand the device blocks parked by destroyed handles back to the driver (dfm_trim_cache); returns the bytes freed."""
+    return int(L.lib().dfm_trim_cache(int(device)))
+
+
 def device_count() -> int:
     n = C.c_int(0)
     rc = L.lib().dfm_device_count(C.byref(n))
@@ -207,11 +212,16 @@ class Complex:
 
     def sample(self, B=1, num_steps=40, eps=1e-3, tr_noise_scale=0.5, rot_noise_scale=0.5, noise_annealing=False,
                use_clash_force=False, ode=False, seed=0, mfma16=False, inject=None, trace=False, profile=False, f16=False, bf16_ops=False,
-               bf16=False, l0_table=True, graph=False):
+               bf16=False, l0_table=True, graph=False, step_energy=None):
         """B independent Euler-Maruyama trajectories (inference_base.py:390-468 batched).  l0_table=False: DFM_F_NO_L0_TABLE
         (layer 0 evaluated edge by edge even where the per-complex message table applies).  graph=True: DFM_F_GRAPH (one captured
-        step replayed as a hipGraph instead of every launch enqueued by the host; bitwise the same results, no faster on MI355X)."""
+        step replayed as a hipGraph instead of every launch enqueued by the host; bitwise the same results, no faster on MI355X).
+        trace=True returns the pose after every step and the scores of every evaluation; by default it also asks for the energy
+        head on every step (DFM_F_STEP_ENERGY - the step evaluations then run their last layer in full); step_energy=False keeps
+        the step evaluations exactly as an untraced call runs them (ligand-only last layer, no energy in trace_scores[:, :-1])."""
         mfma16 = mfma16 or bf16
+        if step_energy is None:
+            step_energy = bool(trace)
         Lg, N, K, S = self.L, self.N, self.K, int(num_steps)
         o = dict(lig_pos=np.zeros((B, Lg, 3, 3), np.float32), rot_update=np.zeros((B, 3), np.float32),
                  tr_update=np.zeros((B, 3), np.float32), energy=np.zeros((B,), np.float32),
@@ -239,7 +249,7 @@ class Complex:
                 inj.edges = _p(a, L.I32P)
         flags = (L.DFM_F_MFMA16 if mfma16 else 0) | (L.DFM_F_NOISE_ANNEALING if noise_annealing else 0) | \
                 (L.DFM_F_CLASH_FORCE if use_clash_force else 0) | (L.DFM_F_ODE if ode else 0) | \
-                (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if trace else 0) | (L.DFM_F_F16 if f16 else 0) | \
+                (L.DFM_F_PROFILE if profile else 0) | (L.DFM_F_STEP_ENERGY if step_energy else 0) | (L.DFM_F_F16 if f16 else 0) | \
                 (L.DFM_F_BF16_OPS if bf16_ops else 0) | (0 if l0_table else L.DFM_F_NO_L0_TABLE) | \
                 (L.DFM_F_GRAPH if graph else 0)
         rc = L.lib().dfm_sample(self._h, int(B), S, float(eps), float(tr_noise_scale), float(rot_noise_scale), flags,

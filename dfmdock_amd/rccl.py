@@ -37,22 +37,72 @@ def _load(names):
     raise RuntimeError(f"cannot load any of {names}: {err}")
 
 
+def _write_atomic(path: str, data: bytes):
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "wb") as f:
+        f.write(data)
+    os.replace(tmp, path)
+
+
+def _read(path: str):
+    try:
+        with open(path, "rb") as f:
+            return f.read()
+    except OSError:
+        return None
+
+
 def exchange_uid_file(uid: bytes | None, rank: int, world: int, gather_dir: str, token: str, timeout_s: float = 120.0) -> bytes:
-    """Rank 0 drops the id as `<token>_rccl_uid` (atomic rename), the others wait for it."""
-    path = os.path.join(gather_dir, f"{token}_rccl_uid")
-    if rank == 0:
-        tmp = path + ".tmp"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)
-        return uid
+    """Rank 0 hands the 128-byte id to the other ranks through files in `gather_dir`, with a handshake that a leftover file of
+    an EARLIER job with the same token (no DFM_JOB_ID: the token is just MASTER_PORT) cannot satisfy:
+
+      rank r > 0   writes `<token>_rccl_hello_<r>` = a fresh 16-byte nonce, then waits for a `<token>_rccl_uid` file that carries
+                   ITS nonce in slot r, answers with `<token>_rccl_ack_<r>` = the nonce and returns the id;
+      rank 0       collects the hello nonces, publishes id + nonces (atomic rename), waits for every ack to match - a stale hello
+                   file gives a nonce nobody acknowledges, so it re-reads the hellos and publishes again - and finally removes
+                   every file of the exchange, so that nothing is left behind for the next job.
+
+    A dead id read from a stale file would make ncclCommInitRank hang."""
+    base = os.path.join(gather_dir, f"{token}_rccl")
+    uid_path = base + "_uid"
     t0 = time.time()
-    while not os.path.exists(path):
+    if rank == 0:
+        assert uid is not None and len(uid) == NCCL_UNIQUE_ID_BYTES
+        others = list(range(1, world))
+        published = None
+        while True:
+            nonces = {r: _read(f"{base}_hello_{r}") for r in others}
+            if all(n is not None and len(n) == 16 for n in nonces.values()):
+                blob = uid + b"".join(nonces[r] for r in others)
+                if blob != published:
+                    _write_atomic(uid_path, blob)
+                    published = blob
+                if all(_read(f"{base}_ack_{r}") == nonces[r] for r in others):
+                    for r in others:
+                        for kind in ("hello", "ack"):
+                            try:
+                                os.remove(f"{base}_{kind}_{r}")
+                            except OSError:
+                                pass
+                    try:
+                        os.remove(uid_path)
+                    except OSError:
+                        pass
+                    return uid
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"rccl unique id: ranks {[r for r in others if _read(f'{base}_ack_{r}') != nonces.get(r)]} never acknowledged {uid_path}")
+            time.sleep(0.01)
+    nonce = os.urandom(16)
+    _write_atomic(f"{base}_hello_{rank}", nonce)
+    lo = NCCL_UNIQUE_ID_BYTES + 16 * (rank - 1)
+    while True:
+        blob = _read(uid_path)
+        if blob is not None and len(blob) == NCCL_UNIQUE_ID_BYTES + 16 * (world - 1) and blob[lo:lo + 16] == nonce:
+            _write_atomic(f"{base}_ack_{rank}", nonce)
+            return blob[:NCCL_UNIQUE_ID_BYTES]
         if time.time() - t0 > timeout_s:
-            raise TimeoutError(f"rccl unique id never appeared at {path}")
-        time.sleep(0.02)
-    with open(path, "rb") as f:
-        return f.read()
+            raise TimeoutError(f"rccl unique id for this job never appeared at {uid_path}")
+        time.sleep(0.01)
 
 
 def exchange_uid_tcp(uid: bytes | None, rank: int, world: int, addr: str, port: int, timeout_s: float = 120.0) -> bytes:

@@ -23,8 +23,14 @@
  * library owns device memory behind opaque handles, no global state besides the
  * thread-local error string.  All entry points return 0 on success and a
  * negative dfm_status otherwise (the reference raises Python exceptions:
- * ValueError for t outside [0,1] -> DFM_E_INVALID).  Handles must not be shared
- * between host threads without external locking; one process (or thread) per GPU.
+ * ValueError for t outside [0,1] -> DFM_E_INVALID).  A handle must not be used by
+ * two host threads at once (no internal locking per handle); DIFFERENT complex
+ * handles of one model may be driven from different host threads concurrently:
+ * each complex owns a non-blocking HIP stream and every upload, launch and
+ * release of the handle is ordered on that stream alone, so creating / checking
+ * the next complex of a set overlaps the sampling of the current one
+ * (dfmdock_amd/driver.py: run_set; the reference's loop is serial,
+ * src/inference_mlsb.py:415-439).  One process per GPU.
  * A model lives on the device that was current at dfm_model_create (dfm_set_device), a
  * complex on its model's device; every entry point switches to the handle's device for
  * the duration of the call and restores the caller's current device.
@@ -104,7 +110,16 @@ enum {
        Inter-chain edges, and intra-chain edges whose feature bins in the pose at hand differ from the table's, go through the edge
        model as before.  Against the direct evaluation the only difference is the fp16 rounding of each stored message before the
        K-row sum (fp32 engine: fp32 rows of 1 KiB, only the ORDER of the K-row sum differs, <= 2e-5; measured: tests/test_gpu_l0_table.py).                                                                  */
-    DFM_F_L0_TABLE = 1u << 11,       /* dfm_score: use (and if necessary build) the table                                */
+    DFM_F_L0_TABLE = 1u << 11,       /* dfm_score: use (and if necessary build) the table.  PRECONDITION: every lig_pos handed to
+                                        the call is a RIGID image of the ligand pose stored in the handle (dfm_complex_create /
+                                        dfm_complex_set_pose) - what the sampler produces.  A hit is decided by equality of the
+                                        edge's bin code in the pose at hand with the code the entry was built on; the entry's radial
+                                        term is that of the STORED pose (equal to the pose's own up to the last bits of fp32 under
+                                        rigid motion).  A different conformer or a perturbed backbone whose bins still match would
+                                        silently get the stored pose's radial: call dfm_complex_set_pose first (it invalidates the
+                                        table) or do not pass this flag.  Above the edge budget of one batched evaluation
+                                        (B * N * K > 32 M edges: B > 890 at 300+300) layer 0 is evaluated directly, so results are
+                                        batch-invariant bit for bit only among calls on the same side of that budget.            */
     DFM_F_NO_L0_TABLE = 1u << 12,    /* dfm_sample: evaluate layer 0 directly                                            */
     DFM_F_GRAPH = 1u << 13           /* dfm_sample: capture ONE step (score evaluation + heads + update) as a hipGraph and replay it
                                         num_steps times instead of enqueueing every launch (ignored when anything is injected,
@@ -249,6 +264,11 @@ int dfm_complex_set_pose(dfm_complex *cx, const float *rec_pos_or_null, const fl
 int dfm_complex_set_homomer(dfm_complex *cx, int flag);
 /* edges per node for this complex: min(N,20) + min(40, N-20) */
 int dfm_complex_degree(const dfm_complex *cx);
+/* Device blocks released by destroyed handles are parked per device for the next handle (a set driver creates and destroys a
+ * complex every ~100 ms; hipMalloc / hipFree of gigabyte workspaces cost milliseconds and drain the device): at most
+ * DFM_ALLOC_CACHE_FRAC (default 0.25) of the device's memory, DFM_ALLOC_CACHE=0 disables it.  dfm_trim_cache hands every parked
+ * block of `device` (< 0: all devices) back to the driver - for processes that share a GPU - and returns the bytes freed. */
+long long dfm_trim_cache(int device);
 
 /* B score evaluations of poses lig_pos[B,L,9] at times t[B] */
 int dfm_score(dfm_complex *cx, int B, const float *lig_pos, const float *t, const int32_t *edges_or_null,

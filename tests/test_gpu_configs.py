@@ -198,3 +198,27 @@ def test_c4_db5_set_one_gpu(model, blob, tmp_path):
             assert rmsd16.max() < 0.5, (cid, b, rmsd16)
             assert abs(float(r16["energy"][b]) - float(ob["energy"])) < 3e-2 * max(abs(float(ob["energy"])), 0.1) + 0.05, (cid, b)
         gx.close()
+
+
+def test_c4_overlapped_driver_equals_serial(model, tmp_path):
+    """driver.run_set pipelines the three stages of a complex over host threads (create + self-check of complex k+1 and the
+    metrics of complex k-1 while complex k samples; samplers=2: two complexes sampling at once on their own streams).  None of
+    that may change a number: CSV files byte-identical to the serial driver's, per-complex self-check lines included."""
+    from dfmdock_amd import driver
+    ids = [c for c in db5_ids() if c in ("1QA9", "4POU", "7CEI", "1AVX", "2SNI", "1ZHI", "1H1V")]
+    cxs = [db5_complex(c) for c in ids]
+    outs = {}
+    for name, kw in (("serial", dict(overlap=False)), ("overlap", dict(overlap=True)), ("overlap2", dict(overlap=True, samplers=2))):
+        checks, timings = [], []
+        rows, ranked = driver.run_set(model, cxs, num_samples=12, num_steps=10, seed=3, out_csv=str(tmp_path / f"{name}.csv"),
+                                      checks_out=checks, timings_out=timings, max_batch=8, **kw)
+        assert len(rows) == len(ids) * 12 and [t["id"] for t in timings] == [c["id"] for c in cxs] or name != "serial"
+        assert all(set(t) >= {"id", "N", "prepare", "sample", "post"} for t in timings)
+        outs[name] = (open(tmp_path / f"{name}.csv", "rb").read(), rows, {k: v.copy() for k, v in ranked.items()},
+                      [(c["id"], c["precision"], c["selfcheck"]["dev_f"], c["selfcheck"]["headroom"]) for c in checks])
+    for name in ("overlap", "overlap2"):
+        assert outs[name][0] == outs["serial"][0], name
+        assert outs[name][1] == outs["serial"][1], name
+        assert outs[name][3] == outs["serial"][3], name
+        for k in outs["serial"][2]:
+            np.testing.assert_array_equal(outs[name][2][k], outs["serial"][2][k])

@@ -452,3 +452,19 @@ def test_narrow_gemm_tiles_equal_wide_tiles_bitwise(tmp_path):
     for tag in ("narrow1", "wide7", "narrow7", "quarter1", "quarter7"):
         for k in outs["wide1"].files:
             assert (outs[tag][k] == outs["wide1"][k]).all(), (tag, k)
+
+
+def test_long_schedule_beyond_the_default_time_grid(model):
+    """The reference's sampler takes any num_steps (inference_base.py:403-404); the workspace's time grid (t, the time-dependent half
+    of the two scale MLPs, the replayed step parameters) is sized for 4096 steps and grows on demand (4097+ steps were
+    rejected).  A 4500-step run, then a short one on the grown grid equal to a fresh handle's."""
+    from dfmdock_amd import engine
+    cx = complex_for("fwd_syn_9_7")
+    gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    a = gx.sample(B=2, num_steps=40, seed=5, mfma16=True)
+    r = gx.sample(B=2, num_steps=4500, seed=5, mfma16=True)
+    assert np.isfinite(r["lig_pos"]).all() and np.isfinite(r["energy"]).all()
+    b = gx.sample(B=2, num_steps=40, seed=5, mfma16=True)
+    for k in ("lig_pos", "energy", "tr_update", "rot_update"):
+        np.testing.assert_array_equal(a[k], b[k])
+    gx.close()

@@ -341,3 +341,33 @@ def test_rccl_unique_id_handover_tcp_and_file(tmp_path):
     assert res["r1"] == uid
     with pytest.raises(TimeoutError):
         rccl.exchange_uid_file(None, 1, 2, d, "other-job", timeout_s=0.2)
+
+
+def test_rccl_uid_file_ignores_leftovers_of_an_earlier_job(tmp_path):
+    """without DFM_JOB_ID the token of the id file is just MASTER_PORT, so a second job in the same DFM_GATHER_DIR found
+    the first job's file at once and handed a dead id to ncclCommInitRank.  The exchange is now a nonce handshake: leftovers of an
+    earlier (crashed) job - an id file in the old or the new format, hello / ack files - are never accepted, and a completed
+    exchange leaves nothing behind."""
+    import threading, time
+    from dfmdock_amd import rccl
+    d = str(tmp_path / "g"); os.makedirs(d)
+    old, new = bytes([7] * 128), bytes(range(128, 256))
+    open(os.path.join(d, "29500_rccl_uid"), "wb").write(old)                                  # r04 format
+    for world in (2, 3):
+        open(os.path.join(d, "29500_rccl_uid"), "wb").write(old + os.urandom(16 * (world - 1)))   # this round's format, dead nonces
+        for r in range(1, world):
+            open(os.path.join(d, f"29500_rccl_hello_{r}"), "wb").write(os.urandom(16))            # a crashed job's hello / ack files
+            open(os.path.join(d, f"29500_rccl_ack_{r}"), "wb").write(os.urandom(16))
+        res = {}
+        th = [threading.Thread(target=lambda r=r: res.update({r: rccl.exchange_uid_file(None, r, world, d, "29500", timeout_s=30)}))
+              for r in range(1, world)]
+        th[0].start()
+        time.sleep(0.15)      # rank 1 is early: it must NOT take the stale file
+        assert not res
+        for t in th[1:]:
+            t.start()
+        assert rccl.exchange_uid_file(new, 0, world, d, "29500", timeout_s=30) == new
+        for t in th:
+            t.join(30)
+        assert res == {r: new for r in range(1, world)}
+        assert [f for f in os.listdir(d) if f.startswith("29500_rccl")] == []
