@@ -108,6 +108,13 @@ struct BlockCache {
 };
 static BlockCache &g_block_cache = *new BlockCache;      // never destroyed: a handle may outlive static destruction at process exit
 
+// diagnostic: DFM_ALLOC_GUARD=<KiB> puts that many KiB of 0xA5 before and after every block (cache off) and checks them at release:
+// a kernel writing outside its buffers is reported on stderr with the block's size and the first damaged offset
+static size_t guard_bytes()
+{
+    static const size_t g = [] { const char *e = getenv("DFM_ALLOC_GUARD"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
+    return g;
+}
 struct DevPool {
     struct Block { void *p; size_t size; int dev; };
     std::vector<Block> ptrs;
@@ -121,6 +128,25 @@ struct DevPool {
     void release(bool drained = false)
     {
         if (ptrs.empty()) return;
+        if (const size_t G = guard_bytes()) {
+            (void)hipDeviceSynchronize();
+            std::vector<unsigned char> h(G);
+            for (const Block &b : ptrs) {
+                unsigned char *base = reinterpret_cast<unsigned char *>(b.p) - G;
+                for (int side = 0; side < 2; ++side) {
+                    (void)hipMemcpy(h.data(), side ? base + G + b.size : base, G, hipMemcpyDeviceToHost);
+                    for (size_t k = 0; k < G; ++k)
+                        if (h[k] != 0xA5) {
+                            fprintf(stderr, "DFM_ALLOC_GUARD: block of %zu bytes: %s guard damaged at offset %zu (byte 0x%02x)\n", b.size,
+                                    side ? "TAIL" : "HEAD", k, h[k]);
+                            break;
+                        }
+                }
+                (void)hipFree(base);
+            }
+            ptrs.clear();
+            return;
+        }
         if (BlockCache::enabled()) {
             // what hipFree would have done: nothing in flight reads these blocks when the next owner gets them (a bound pool waits
             // for its own stream only)
@@ -138,6 +164,16 @@ struct DevPool {
         int dev = -1;
         (void)hipGetDevice(&dev);
         void *p = nullptr;
+        if (const size_t G = guard_bytes()) {
+            unsigned char *base = nullptr;
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&base), bytes + 2 * G);
+            if (e != hipSuccess) return e;
+            (void)hipMemset(base, 0xA5, G); (void)hipMemset(base + G + bytes, 0xA5, G);
+            (void)hipDeviceSynchronize();
+            ptrs.push_back({base + G, bytes, dev});
+            *out = reinterpret_cast<T *>(base + G);
+            return hipSuccess;
+        }
         if (BlockCache::enabled() && dev >= 0 && dev < MAX_DEVICES) {
             bytes = (bytes + 65535) & ~(size_t)65535;      // 64 KiB granules: neighbouring sizes share blocks
             // the block's true size travels with it: look it up by taking from the cache under the lock
@@ -171,6 +207,13 @@ struct DevPool {
         }
         ptrs.push_back({p, bytes, dev});
         *out = reinterpret_cast<T *>(p);
+        // diagnostic: DFM_ALLOC_POISON=<byte> fills every block handed out (fresh or from the cache) with that byte - 255 = NaN
+        // patterns in fp32 / fp16 - so that a kernel reading memory nobody wrote shows up as a changed or non-finite result
+        static const int poison = [] { const char *e = getenv("DFM_ALLOC_POISON"); return e ? atoi(e) & 255 : -1; }();
+        if (poison >= 0) {
+            hipError_t e = bound ? hipMemsetAsync(p, poison, bytes, owner) : hipMemset(p, poison, bytes);
+            if (e != hipSuccess) return e;
+        }
         return hipSuccess;
     }
     template <typename T> hipError_t upload(T **out, const T *host, size_t n)
@@ -205,7 +248,7 @@ struct dfm_model {
 struct Workspace {
     int Bcap = 0;
     DevPool pool;
-    float *pos = nullptr; float4 *ca4 = nullptr, *cb4 = nullptr;
+    float4 *pos = nullptr, *ca4 = nullptr, *cb4 = nullptr;      // centred backbone N / CA / virtual CB of every trajectory, [B][N] each
     int32_t *edges = nullptr; uint32_t *codes = nullptr; float *radial = nullptr;
     float *h = nullptr, *h2 = nullptr, *A = nullptr, *Bm = nullptr, *agg = nullptr, *u = nullptr;
     uint16_t *Bmb = nullptr, *mbuf = nullptr;
@@ -639,7 +682,7 @@ static hipError_t project_layer0(dfm_complex *cx)
     g.Nout = 2 * H; g.epi = 2; g.C = cx->A0; g.ldc = H; g.C2 = cx->Bm0;
     hipError_t e = launch_gemm_f32(g, cx->stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_scale_ab, dim3((N * H + 255) / 256), dim3(256), 0, cx->stream, cx->A0, cx->Bm0, cx->A0s, cx->A0h, cx->Bmb0, N * H);
+    hipLaunchKernelGGL(k_scale_ab, dim3((N * H + 255) / 256), dim3(256), token_lds(), cx->stream, cx->A0, cx->Bm0, cx->A0s, cx->A0h, cx->Bmb0, N * H);
     return hipGetLastError();
 }
 
@@ -804,7 +847,7 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
         W.pool.bind(cx->stream);
         cx->buf_gen++;
         const size_t N = cx->N, L = cx->L, R = cx->R, K = cx->K, b = B;
-        HIPCHK(W.pool.alloc(&W.pos, b * N * 9)); HIPCHK(W.pool.alloc(&W.ca4, b * N)); HIPCHK(W.pool.alloc(&W.cb4, b * N));
+        HIPCHK(W.pool.alloc(&W.pos, b * N)); HIPCHK(W.pool.alloc(&W.ca4, b * N)); HIPCHK(W.pool.alloc(&W.cb4, b * N));
         HIPCHK(W.pool.alloc(&W.edges, b * N * K)); HIPCHK(W.pool.alloc(&W.codes, b * N * K));
         HIPCHK(W.pool.alloc(&W.radial, b * N * K));
         HIPCHK(W.pool.alloc(&W.h, b * N * H)); HIPCHK(W.pool.alloc(&W.h2, b * N * H));
@@ -924,7 +967,7 @@ extern "C" const char *dfm_config_string(void)
         c += "; layer 0 through the per-complex message table in dfm_sample (DFM_F_NO_L0_TABLE: direct), on request in dfm_score (DFM_F_L0_TABLE)";
         c += "; build: TAB_MERGE=" + std::to_string((int)DFM_TAB_MERGE);
         std::string env;
-        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_GEMM_NARROW_MAXWG", "DFM_GEMM_QUARTER_MAXWG", "DFM_L0_TABLE", "DFM_GRAPH", "DFM_EDGE_F32_SCALAR", "DFM_GEMM_F32_SCALAR", "DFM_PAIR_HEAD_VALU", "DFM_ALLOC_CACHE", "DFM_LIB"}) {
+        for (const char *k : {"DFM_EDGE_SPLIT", "DFM_GEMM_NARROW_MAXWG", "DFM_GEMM_QUARTER_MAXWG", "DFM_L0_TABLE", "DFM_GRAPH", "DFM_EDGE_F32_SCALAR", "DFM_GEMM_F32_SCALAR", "DFM_PAIR_HEAD_VALU", "DFM_PAIR_HEAD_M32", "DFM_ALLOC_CACHE", "DFM_ALLOC_CACHE_FRAC", "DFM_ALLOC_POISON", "DFM_ALLOC_GUARD", "DFM_LIB"}) {
             const char *e = getenv(k);
             if (e) env += std::string(env.empty() ? "" : " ") + k + "=" + e;
         }
@@ -972,13 +1015,13 @@ __global__ void k_sat_count(const uint16_t *__restrict__ x, long long n, unsigne
 static hipError_t launch_absmax(const float *x, long long n, uint32_t *out, hipStream_t s)
 {
     const long long want = (n + 255) / 256;
-    hipLaunchKernelGGL(k_absmax, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, x, n, out);
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), token_lds(), s, x, n, out);
     return hipGetLastError();
 }
 static hipError_t launch_sat_count(const uint16_t *x, long long n, unsigned long long *out, hipStream_t s)
 {
     const long long want = (n + 255) / 256;
-    hipLaunchKernelGGL(k_sat_count, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, x, n, out);
+    hipLaunchKernelGGL(k_sat_count, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), token_lds(), s, x, n, out);
     return hipGetLastError();
 }
 

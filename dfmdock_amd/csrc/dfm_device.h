@@ -141,7 +141,7 @@ __device__ inline double block_sum_d(double v, double *scratch)
 // (score_net_mlsb.py:353-359; all backbone atoms for the second family, DFMDock.py:254-257), build the CA and virtual-CB arrays
 // (coords6d.py:71-75).  Used by k_prep_pose and - for the pose a step has just produced - by k_heads.  scratch: double[8], center: float[3]
 __device__ inline void prep_pose_block(const float *__restrict__ rec_pos, const float *__restrict__ lig, int R, int L, int all_atoms,
-                                       float *__restrict__ P, float4 *__restrict__ ca4, float4 *__restrict__ cb4, double *scratch, float *center)
+                                       float4 *__restrict__ n4, float4 *__restrict__ ca4, float4 *__restrict__ cb4, double *scratch, float *center)
 {
     const int N = R + L;
     double s0 = 0, s1 = 0, s2 = 0;
@@ -168,8 +168,10 @@ __device__ inline void prep_pose_block(const float *__restrict__ rec_pos, const 
             v[a * 3 + 1] = src[a * 3 + 1] - cy;
             v[a * 3 + 2] = src[a * 3 + 2] - cz;
         }
-#pragma unroll
-        for (int a = 0; a < 9; ++a) P[(size_t)i * 9 + a] = v[a];
+        // the centred backbone N (the one atom besides CA / CB the features read: theta = dih(N_i, CA_i, CB_i, CB_j)) as an ALIGNED
+        // float4 like ca4 / cb4.  r01-r04 kept the whole centred backbone as [N][9] floats: 36-byte records written with 4-byte-
+        // aligned 16-byte stores straddling cache lines - nothing but N was ever read back from it (r05).
+        n4[i] = make_float4(v[0], v[1], v[2], 0.f);
         // Cb = -0.58273431*a + 0.56802827*b - 0.54067466*c + Ca ;  b = Ca - N, c = C - Ca, a = b x c
         const float bx = v[3] - v[0], by = v[4] - v[1], bz = v[5] - v[2];
         const float cx_ = v[6] - v[3], cy_ = v[7] - v[4], cz_ = v[8] - v[5];

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include <atomic>
@@ -168,7 +169,20 @@ hipError_t launch_gemm_f32(const GemmArgs &a, hipStream_t s);
 hipError_t launch_gemm_split(const GemmArgs &a, const uint16_t *Whi, const uint16_t *Wlo, hipStream_t s);
 int gemm_rows_per_tile();   // 64: the row tile of k_gemm_split (tiles of the fused GraphNorm statistics)
 
-hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, int all_atoms, float *pos,
+// Dynamic LDS bytes for kernels that need none.  r05 (tools/concurrency_probe*.py, profiles/r05_concurrency.txt): a wave of a kernel
+// WITHOUT any LDS allocation can be placed on a CU whose LDS is entirely held by a 160 KiB workgroup of the message kernel of ANOTHER
+// complex handle (another stream, another hardware queue) - and then computed wrong values: k_edge_feat<0> returned theta bins of a
+// garbage N_i for scattered nodes in 11 of 12 concurrent calls, with GPU_MAX_HW_QUEUES <= 2 (both streams on one hardware queue) or
+// with as little as 64 bytes of LDS on the victim in 0 of 12.  The mechanism was not identified (no scratch, no LDS-DMA, no mode
+// change in either kernel; intra-stream serialisation does not help).  Every kernel of this library therefore holds at least a token
+// LDS allocation, which keeps it off CUs whose LDS is full.  DFM_TOKEN_LDS=0 restores the old launches (for reproducing the effect).
+inline unsigned token_lds()
+{
+    static const unsigned v = [] { const char *e = getenv("DFM_TOKEN_LDS"); return e ? (unsigned)atoi(e) : 64u; }();
+    return v;
+}
+
+hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, int all_atoms, float4 *n4,
                             float4 *ca4, float4 *cb4, hipStream_t s);
 // ctl (or nullptr): device words {evaluation index, seed lo, seed hi} that override seed / stream_id (replayed step graph)
 hipError_t launch_knn_sample(const float4 *ca4, int B, int N, int knn, int nsamp, uint64_t seed, uint32_t stream_id,
@@ -181,10 +195,10 @@ struct L0Classify {
     uint4 *rows;             // [capacity] (i, j, code, radial bits) of the misses
     uint32_t *counter;       // rows appended so far (zero at the start of an evaluation: k_l0_gather resets it)
 };
-hipError_t launch_edge_feat(const float *pos, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B,
+hipError_t launch_edge_feat(const float4 *n4, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B,
                             int N, int R, int K, float mask_dist, uint32_t *codes, float *radial, const L0Classify &cls,
                             uint32_t *eval_ctr /* or nullptr: incremented once per launch (replayed step graph) */, hipStream_t s);
-hipError_t launch_l0_pairs(const float *pos, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint32_t *code0,
+hipError_t launch_l0_pairs(const float4 *n4, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint32_t *code0,
                            uint4 *rows, hipStream_t s);
 
 struct EdgeArgs {
@@ -294,7 +308,7 @@ struct HeadArgs {
     // exactly what launch_prep_pose would write as that evaluation's first launch)
     int prep_next;
     const float *rec_pos;
-    float *prep_pos;
+    float4 *prep_pos;      // [B][N] centred backbone N
     float4 *prep_ca4, *prep_cb4;
 };
 hipError_t launch_heads(const HeadArgs &a, hipStream_t s);

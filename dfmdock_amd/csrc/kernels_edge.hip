@@ -1240,7 +1240,15 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             colsum[nt] += xt;
         }
         if (split || mt == ntile - 1) {
-            float *out = p.agg + ((size_t)b * p.N + i) * H + l31;
+            // The lane term of this address is re-derived HERE (v_mbcnt_lo = the lane index for the storing half-wave h == 0; the
+            // volatile asm keeps hipcc from hoisting `p.agg + l31` out of the task loop): hoisted, that 64-bit value was the one thing
+            // this 256-register kernel spilled to SCRATCH - and two of these kernels running at once on different streams (two complex
+            // handles, driver.run_set) then stored segment sums through each other's spilled pointer: rows of one handle's agg left
+            // stale, rows of the other's overwritten (r05: tools/concurrency_probe*.py).  No kernel of this library may use scratch;
+            // tests/test_abi_cpu.py checks the code objects' private_segment_fixed_size.
+            uint32_t le;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0" : "=v"(le));
+            float *out = p.agg + ((size_t)b * p.N + i) * H + le;
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
                 if (h == 0 && !p.no_agg) {
@@ -1644,7 +1652,7 @@ hipError_t launch_l0_gather32(const float *table, const float *X, const uint32_t
                               uint32_t *counter, unsigned long long *miss_total, hipStream_t s)
 {
     const long long waves = (long long)B * N;
-    hipLaunchKernelGGL(k_l0_gather32, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const float4 *>(table),
+    hipLaunchKernelGGL(k_l0_gather32, dim3((unsigned)((waves + 3) / 4)), dim3(256), token_lds(), s, reinterpret_cast<const float4 *>(table),
                        reinterpret_cast<const float4 *>(X), src, reinterpret_cast<float4 *>(agg), B, N, K, counter, miss_total);
     return hipGetLastError();
 }
@@ -1653,7 +1661,7 @@ hipError_t launch_l0_gather(const uint16_t *table, const uint16_t *X, const uint
                             uint32_t *counter, unsigned long long *miss_total, hipStream_t s)
 {
     const long long waves = (long long)B * N;
-    hipLaunchKernelGGL(k_l0_gather, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, reinterpret_cast<const uint2 *>(table),
+    hipLaunchKernelGGL(k_l0_gather, dim3((unsigned)((waves + 3) / 4)), dim3(256), token_lds(), s, reinterpret_cast<const uint2 *>(table),
                        reinterpret_cast<const uint2 *>(X), src, reinterpret_cast<float4 *>(agg), B, N, K, 1.0f / SILU_S, counter, miss_total);
     return hipGetLastError();
 }

@@ -13,20 +13,20 @@ namespace dfm {
 // prep_pose: centre receptor + ligand on the ligand CA centroid (score_net_mlsb.py:353-359), build
 // CA and virtual-CB arrays (coords6d.py:71-75).  One workgroup per trajectory.
 __global__ __launch_bounds__(256) void k_prep_pose(const float *__restrict__ rec_pos, const float *__restrict__ lig_cur,
-                                                   int R, int L, int all_atoms, float *__restrict__ pos,
+                                                   int R, int L, int all_atoms, float4 *__restrict__ n4,
                                                    float4 *__restrict__ ca4, float4 *__restrict__ cb4)
 {
     __shared__ double scratch[8];
     __shared__ float center[3];
     const int b = blockIdx.x, N = R + L;
-    prep_pose_block(rec_pos, lig_cur + (size_t)b * L * 9, R, L, all_atoms, pos + (size_t)b * N * 9, ca4 + (size_t)b * N, cb4 + (size_t)b * N,
+    prep_pose_block(rec_pos, lig_cur + (size_t)b * L * 9, R, L, all_atoms, n4 + (size_t)b * N, ca4 + (size_t)b * N, cb4 + (size_t)b * N,
                     scratch, center);
 }
 
-hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, int all_atoms, float *pos, float4 *ca4,
+hipError_t launch_prep_pose(const float *rec_pos, const float *lig_cur, int B, int R, int L, int all_atoms, float4 *n4, float4 *ca4,
                             float4 *cb4, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_prep_pose, dim3(B), dim3(256), 0, s, rec_pos, lig_cur, R, L, all_atoms, pos, ca4, cb4);
+    hipLaunchKernelGGL(k_prep_pose, dim3(B), dim3(256), 0, s, rec_pos, lig_cur, R, L, all_atoms, n4, ca4, cb4);
     return hipGetLastError();
 }
 
@@ -269,12 +269,12 @@ __device__ inline int bin_angle(float a)
 }
 
 // features of one ordered pair (i, j) of trajectory `base / N`: packed bin code + radial
-__device__ inline void edge_feature(const float *__restrict__ pos, const float4 *__restrict__ ca4, const float4 *__restrict__ cb4,
+__device__ inline void edge_feature(const float4 *__restrict__ n4, const float4 *__restrict__ ca4, const float4 *__restrict__ cb4,
                                     size_t base, int i, int j, int R, float mask_dist, uint32_t &code, float &r2_out)
 {
     const float4 cai4 = ca4[base + i], caj4 = ca4[base + j], cbi4 = cb4[base + i], cbj4 = cb4[base + j];
-    const float *pi = pos + (base + i) * 9;
-    const v3 Ni{pi[0], pi[1], pi[2]};
+    const float4 ni4 = n4[base + i];
+    const v3 Ni{ni4.x, ni4.y, ni4.z};
     const v3 Cai{cai4.x, cai4.y, cai4.z}, Caj{caj4.x, caj4.y, caj4.z}, Cbi{cbi4.x, cbi4.y, cbi4.z},
         Cbj{cbj4.x, cbj4.y, cbj4.z};
     const v3 dv = vsub(Cai, Caj);
@@ -313,7 +313,7 @@ __device__ inline uint32_t l0_pair_index(int i, int j, int R, int L)
 // evaluated like an inter-chain one, so the bins the engine uses are always those of the pose at hand.  Misses are appended to the
 // row list (one atomic per wave; the position of a row has no influence on its value).
 template <int CLS>      // CLS 1: with the table classification, 1024 threads per workgroup (one list reservation per workgroup)
-__global__ __launch_bounds__(CLS ? 1024 : 256) void k_edge_feat(const float *__restrict__ pos, const float4 *__restrict__ ca4,
+__global__ __launch_bounds__(CLS ? 1024 : 256) void k_edge_feat(const float4 *__restrict__ n4, const float4 *__restrict__ ca4,
                                                    const float4 *__restrict__ cb4, const int32_t *__restrict__ edges,
                                                    long long total, int N, int R, int K, float mask_dist,
                                                    uint32_t *__restrict__ codes, float *__restrict__ radial, L0Classify cls,
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(CLS ? 1024 : 256) void k_edge_feat(const float *__r
         const int b = (int)(node / N);
         i = (int)(node % N);
         j = edges[e];
-        edge_feature(pos, ca4, cb4, (size_t)b * N, i, j, R, mask_dist, code, r2);
+        edge_feature(n4, ca4, cb4, (size_t)b * N, i, j, R, mask_dist, code, r2);
         codes[e] = code;
         radial[e] = r2;
     }
@@ -363,23 +363,23 @@ __global__ __launch_bounds__(CLS ? 1024 : 256) void k_edge_feat(const float *__r
     }
 }
 
-hipError_t launch_edge_feat(const float *pos, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B, int N,
+hipError_t launch_edge_feat(const float4 *n4, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B, int N,
                             int R, int K, float mask_dist, uint32_t *codes, float *radial, const L0Classify &cls, uint32_t *eval_ctr,
                             hipStream_t s)
 {
     const long long total = (long long)B * N * K;
     if (cls.code0)
-        hipLaunchKernelGGL(k_edge_feat<1>, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, pos, ca4, cb4, edges, total,
+        hipLaunchKernelGGL(k_edge_feat<1>, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, s, n4, ca4, cb4, edges, total,
                            N, R, K, mask_dist, codes, radial, cls, eval_ctr);
     else
-        hipLaunchKernelGGL(k_edge_feat<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pos, ca4, cb4, edges, total,
+        hipLaunchKernelGGL(k_edge_feat<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), token_lds(), s, n4, ca4, cb4, edges, total,
                            N, R, K, mask_dist, codes, radial, cls, eval_ctr);
     return hipGetLastError();
 }
 
 // every intra-chain ordered pair of the complex (self pairs included: slot 0 of a node is the node itself) as a row list for the table
 // build, features from the prepared pose of trajectory 0; code0 = the code each table entry is built with
-__global__ __launch_bounds__(256) void k_l0_pairs(const float *__restrict__ pos, const float4 *__restrict__ ca4, const float4 *__restrict__ cb4,
+__global__ __launch_bounds__(256) void k_l0_pairs(const float4 *__restrict__ n4, const float4 *__restrict__ ca4, const float4 *__restrict__ cb4,
                                                   int R, int L, float mask_dist, uint32_t *__restrict__ code0, uint4 *__restrict__ rows)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x, RR = (uint32_t)R * (uint32_t)R, P = RR + (uint32_t)L * (uint32_t)L;
@@ -389,16 +389,16 @@ __global__ __launch_bounds__(256) void k_l0_pairs(const float *__restrict__ pos,
     else { const uint32_t w = q - RR; const int il = (int)(w / (uint32_t)L); i = R + il; j = R + (int)(w - (uint32_t)il * (uint32_t)L); }
     uint32_t code;
     float r2;
-    edge_feature(pos, ca4, cb4, 0, i, j, R, mask_dist, code, r2);
+    edge_feature(n4, ca4, cb4, 0, i, j, R, mask_dist, code, r2);
     code0[q] = code;
     rows[q] = make_uint4((uint32_t)i, (uint32_t)j, code, __float_as_uint(r2));
 }
 
-hipError_t launch_l0_pairs(const float *pos, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint32_t *code0,
+hipError_t launch_l0_pairs(const float4 *n4, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint32_t *code0,
                            uint4 *rows, hipStream_t s)
 {
     const long long P = (long long)R * R + (long long)L * L;
-    hipLaunchKernelGGL(k_l0_pairs, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, pos, ca4, cb4, R, L, mask_dist, code0, rows);
+    hipLaunchKernelGGL(k_l0_pairs, dim3((unsigned)((P + 255) / 256)), dim3(256), token_lds(), s, n4, ca4, cb4, R, L, mask_dist, code0, rows);
     return hipGetLastError();
 }
 

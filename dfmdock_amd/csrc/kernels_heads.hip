@@ -162,7 +162,7 @@ struct HeadKArgs {
     // evaluation's first launch: same workgroup shape, same code) - one dependent launch less per step
     int prep_next;
     const float *rec_pos;
-    float *prep_pos;
+    float4 *prep_pos;
     float4 *prep_ca4, *prep_cb4;
 };
 
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_heads(HeadKArgs p)
     }
     if (p.prep_next) {
         __syncthreads();      // the workgroup's new pose is complete (and its reads of this evaluation's centred CA are long done)
-        prep_pose_block(p.rec_pos, lig, R, L, p.all_atoms, p.prep_pos + (size_t)b * N * 9, p.prep_ca4 + (size_t)b * N, p.prep_cb4 + (size_t)b * N,
+        prep_pose_block(p.rec_pos, lig, R, L, p.all_atoms, p.prep_pos + (size_t)b * N, p.prep_ca4 + (size_t)b * N, p.prep_cb4 + (size_t)b * N,
                         dscr, s_center);
     }
 }

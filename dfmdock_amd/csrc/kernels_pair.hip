@@ -510,7 +510,7 @@ hipError_t launch_pair_finish_s(const PairArgs &a, int n_part, float inv_pool, f
 hipError_t launch_pair_finish(const float *fpart, int B, int R, int L, float inv_pool, float *fvec, const float *cpart,
                               float *conf, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pair_finish, dim3(B), dim3(256), 0, s, fpart, (R + 63) / 64, L, inv_pool, fvec, cpart, R, conf);
+    hipLaunchKernelGGL(k_pair_finish, dim3(B), dim3(256), token_lds(), s, fpart, (R + 63) / 64, L, inv_pool, fvec, cpart, R, conf);
     return hipGetLastError();
 }
 

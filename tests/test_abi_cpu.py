@@ -107,3 +107,36 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("# oracle", ""), f"{f} references the oracle"
+
+
+def test_no_kernel_uses_scratch():
+    """Every kernel of the shipped code objects must have private_segment_fixed_size == 0 (no register spills to scratch, no
+    private arrays).  r05 found two concurrently running instances of the message kernel - one per complex handle, each on its own
+    stream - storing their segment sums through EACH OTHER's spilled output pointer: the one 64-bit value that kernel kept in
+    scratch.  Scratch-free kernels cannot interfere that way; this test keeps it so (llvm-readelf on the gfx950 bundles)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from dfmdock_amd import _lib
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(tools, "llvm-readelf")):
+        pytest.skip("llvm-readelf not available")
+    td = tempfile.mkdtemp()
+    try:
+        lib = os.path.join(td, "lib.so")
+        shutil.copy(_lib.LIB_PATH, lib)
+        subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", lib], cwd=td, check=True, capture_output=True)
+        seen, bad = 0, []
+        for f in sorted(os.listdir(td)):
+            if "gfx950" not in f:
+                continue
+            notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", os.path.join(td, f)], capture_output=True, text=True).stdout
+            for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+)", notes, re.S):
+                seen += 1
+                if int(m.group(2)) != 0:
+                    bad.append((m.group(1), int(m.group(2))))
+        assert seen >= 40, seen
+        assert not bad, bad
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
