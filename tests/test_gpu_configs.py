@@ -212,7 +212,7 @@ def test_c4_overlapped_driver_equals_serial(model, tmp_path):
         checks, timings = [], []
         rows, ranked = driver.run_set(model, cxs, num_samples=12, num_steps=10, seed=3, out_csv=str(tmp_path / f"{name}.csv"),
                                       checks_out=checks, timings_out=timings, max_batch=8, **kw)
-        assert len(rows) == len(ids) * 12 and [t["id"] for t in timings] == [c["id"] for c in cxs] or name != "serial"
+        assert len(rows) == len(ids) * 12 and sorted(t["id"] for t in timings) == sorted(c["id"] for c in cxs)
         assert all(set(t) >= {"id", "N", "prepare", "sample", "post"} for t in timings)
         outs[name] = (open(tmp_path / f"{name}.csv", "rb").read(), rows, {k: v.copy() for k, v in ranked.items()},
                       [(c["id"], c["precision"], c["selfcheck"]["dev_f"], c["selfcheck"]["headroom"]) for c in checks])
