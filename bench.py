@@ -88,18 +88,19 @@ def cpu_baseline(blob, cx, num_steps, repeats=3):
 
 
 def replayed_counters(args):
-    """Counters of the committed rocprofv3 --pmc run of this exact configuration (profiles/r04_traffic.json, tools/make_traffic_json.py;
+    """Counters of the committed rocprofv3 --pmc run of this exact configuration (profiles/r05_traffic.json, tools/make_traffic_json.py;
     collected as MI355X_MICROARCH.md prescribes: separate passes, FETCH_SIZE x 2 + WRITE_SIZE).  PMC counters cannot be read from inside
     this process: they are REPLAYED, per launch TYPE of the message kernel (full / ligand-only), and weighted here by the launch mix this
     run measures itself; absent for any other configuration."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
-    except OSError:
-        return None, None
-    c = t["config"]
-    if (c["R"], c["L"], c["batch"], c["precision"], bool(c.get("layer0_table"))) == (args.R, args.L, args.batch, args.precision, not args.no_l0_table) \
-            and "full" in t.get("edge", {}):
-        return t, "replayed profiles/r04_traffic.json"
+    for name in ("r05_traffic.json", "r04_traffic.json"):      # the newest committed counter run of this configuration
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except OSError:
+            continue
+        c = t["config"]
+        if (c["R"], c["L"], c["batch"], c["precision"], bool(c.get("layer0_table"))) == (args.R, args.L, args.batch, args.precision, not args.no_l0_table) \
+                and "full" in t.get("edge", {}):
+            return t, "replayed profiles/" + name
     return None, None
 
 
@@ -133,7 +134,7 @@ def valu_issue(ctr, n_full, n_lig, rows_full, rows_lig, edge_ms):
     return {"frac": floor_s / (edge_ms * 1e-3) if edge_ms > 0 else None, "floor_ms_total": floor_s * 1e3, "measured_ms_total": edge_ms,
             "by_launch_type": detail, "instruction_mix": {kk: k[kk] for kk in ("transcendental", "packed_f32", "packed_16", "plain", "mfma")},
             "issue_cycles": {kk: c[kk] for kk in ("transcendental", "packed_f32", "packed_16", "plain")},
-            "source": "instruction counts: replayed SQ_INSTS_VALU (profiles/r04_traffic.json) + algebra; class split: static ISA mix "
+            "source": "instruction counts: replayed SQ_INSTS_VALU (the committed counter run named in traffic_source) + algebra; class split: static ISA mix "
                       "(profiles/r05_valu_mix.json); issue costs: tools/ubench on MI355X; time: live HIP events"}
 
 
@@ -397,6 +398,8 @@ def main():
             "backend": grp.backend,
             "backend_fallback": grp.fallback_reason,
             "ranks_in_gather": len(ranks_seen) if world > 1 else 1,
+            "records_in_gather": int(allrec.shape[0]) if allrec is not None else 0,
+            "distinct_record_ids": len({(int(a), int(b)) for a, b in allrec[:, 0:2]}) if allrec is not None else 0,
             "distinct_devices": len(set(per_rank[:, 1].astype(int).tolist())),
             "config": {"workload": workload_label(args),
                        "trajectories_per_gpu": B, "num_steps": args.num_steps, "parallelism": f"traj-shard x{world}",

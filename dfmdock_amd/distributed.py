@@ -281,6 +281,26 @@ def shard_range(total: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# Cost of one complex of a set run on one MI355X, milliseconds (profiles/r05_c4.txt: 24 DB5-sized complexes x 40 trajectories x 40
+# steps through the pipelined driver; least-squares over the per-complex `sample` times, N = 197 ... 695): the sampling call is
+# affine in the residue count - a fixed part (41 evaluations x ~27 dependent launches that no batch of 40 fills) plus a per-residue
+# part - and scales with the trajectories per call; creation, self-check and metrics overlap with the previous / next complex's
+# sampling in the pipelined driver and only add to the first and last complex of a rank.
+SET_COST_FIXED_MS = 21.0
+SET_COST_PER_RESIDUE_MS = 0.125
+SET_COST_EDGE_MS = 30.0      # un-overlapped prepare of a rank's first complex + post of its last
+
+
+def complex_cost(n_residues: int, num_samples: int = 40) -> float:
+    """Estimated milliseconds of one complex's sampling (see SET_COST_*): what driver.run_set balances over ranks."""
+    return (SET_COST_FIXED_MS + SET_COST_PER_RESIDUE_MS * float(n_residues)) * max(num_samples, 1) / 40.0
+
+
+def makespan(costs, assignment) -> float:
+    """Largest per-rank sum of `costs` under `assignment` (index lists per rank) + the un-overlapped pipeline edges."""
+    return max((sum(costs[i] for i in part) + (SET_COST_EDGE_MS if part else 0.0)) for part in assignment)
+
+
 def assign_work(costs, world: int):
     """Longest-processing-time-first assignment of work items (e.g. complexes weighted by N) to ranks.
 

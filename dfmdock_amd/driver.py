@@ -150,7 +150,8 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
         share = list(range(len(complexes)))
         t_lo, t_hi = D.shard_range(num_samples, world, rank)
     else:
-        share = D.assign_work([c["rec_x"].shape[0] + c["lig_x"].shape[0] for c in complexes], world)[rank]
+        # longest-first over the estimated sampling time of each complex (affine in N: a B = 40 call has a fixed cost no batch fills)
+        share = D.assign_work([D.complex_cost(c["rec_x"].shape[0] + c["lig_x"].shape[0], num_samples) for c in complexes], world)[rank]
         t_lo, t_hi = 0, num_samples
     rng = np.random.default_rng(seed)
     rots = [rng.integers(0, 2 ** 31) for _ in complexes]      # per-complex streams, identical on every rank

@@ -189,3 +189,27 @@ def test_rccl_direct_one_rank_without_torch():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0 and "RCCL_DIRECT_OK" in p.stdout.decode(), p.stderr.decode()[-3000:]
+
+
+def test_bench_eight_ranks_oversubscribed_on_one_gpu():
+    """The driver's 8-GPU command shape on the 1-GPU test box: `python bench.py --gpus 8` starts eight ranks itself, all of them land
+    on GPU 0 (local rank modulo the device count), RCCL cannot serve them there and the gather falls back (gloo / files).  What
+    must hold: ONE JSON line, n_gpus = 8, every rank's block in the gather - 8 ranks x 8 trajectories = 64 distinct record ids -
+    and value = the whole job's trajectories over the slowest rank's time.  No scaling claim: eight processes share one GPU."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "DFM_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--batch", "8",
+           "--num-steps", "4", "--no-cpu-baseline", "--no-fp32-line"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_in_gather"] == 8 and out["config"]["trajectories_per_gpu"] == 8
+    assert out["records_in_gather"] == 64 and out["distinct_record_ids"] == 64
+    assert out["backend"] in ("nccl", "gloo", "file") and out["scaling"] == "weak"
+    if out["distinct_devices"] == 1:
+        assert out["backend"] != "nccl" and out["backend_fallback"]
+    assert abs(out["value"] - 8 * 8 * 1 / (out["ms_per_step"] / 1e3)) < 1e-6 * out["value"]
+    assert "c4" not in out and "c5" not in out and "cpu_baseline" not in out      # secondary records: rank 0 at N = 1 only

@@ -371,3 +371,24 @@ def test_rccl_uid_file_ignores_leftovers_of_an_earlier_job(tmp_path):
             t.join(30)
         assert res == {r: new for r in range(1, world)}
         assert [f for f in os.listdir(d) if f.startswith("29500_rccl")] == []
+
+
+def test_set_run_assignment_over_eight_ranks_with_the_measured_cost_model():
+    """C4's sharding: the 24 DB5 test complexes over 8 ranks, longest first, under the cost model measured on one MI355X
+    (distributed.complex_cost: a B = 40 sampling call is AFFINE in the residue count - profiles/r05_c4.txt - so balancing on N
+    alone over-weights the large complexes).  Every complex on exactly one rank, three per rank here, estimated makespan within
+    10 % of the perfect split and no worse than balancing on N alone; run_set itself takes the same assignment (2-rank gloo test
+    above runs it end to end)."""
+    from dfmdock_amd import distributed as D
+    sizes = [395, 695, 343, 456, 575, 626, 561, 329, 197, 352, 320, 430, 377, 430, 382, 339, 628, 404, 240, 535, 373, 588, 492, 214]   # SURVEY Appendix A
+    assert len(sizes) == 24
+    costs = [D.complex_cost(n, 40) for n in sizes]
+    assert D.complex_cost(600, 80) == pytest.approx(2 * D.complex_cost(600, 40)) and costs[1] / costs[8] < sizes[1] / sizes[8]
+    a = D.assign_work(costs, 8)
+    assert sorted(i for part in a for i in part) == list(range(24)) and all(len(part) == 3 for part in a)
+    ideal = sum(costs) / 8 + D.SET_COST_EDGE_MS
+    assert D.makespan(costs, a) <= 1.10 * ideal, (D.makespan(costs, a), ideal)
+    by_n = D.assign_work([float(n) for n in sizes], 8)
+    assert D.makespan(costs, a) <= D.makespan(costs, by_n) + 1e-9
+    # fewer complexes than 2 x ranks: run_set splits TRAJECTORIES instead (every rank holds every complex)
+    assert [D.shard_range(40, 8, r) for r in range(8)] == [(5 * r, 5 * r + 5) for r in range(8)]

@@ -45,6 +45,8 @@ for name, kw in (("serial (r04 driver)", dict(overlap=False)), ("pipelined", dic
     rows, ranked = driver.run_set(model, cxs, num_samples=40, num_steps=40, seed=0, precision="mfma16", out_csv=out, timings_out=tim, **kw)
     dt = time.perf_counter() - t0
     csvs[name] = open(out, "rb").read()
+    if name == "pipelined":
+        per_complex = [(t["N"], t["prepare"], t["sample"], t["post"]) for t in tim]
     ph = {k: sum(t[k] for t in tim) / 1e3 for k in ("prepare", "sample", "post")}
     print(f"{name:24s}: {dt:6.3f} s wall -> {len(rows) / dt:6.1f} trajectories/s | summed over complexes: prepare (rotation, handle, "
           f"self-check) {ph['prepare']:.3f} s, sample {ph['sample']:.3f} s, post (metrics, records, close) {ph['post']:.3f} s "
@@ -52,3 +54,9 @@ for name, kw in (("serial (r04 driver)", dict(overlap=False)), ("pipelined", dic
 base = csvs["serial (r04 driver)"]
 print("CSV files byte-identical to the serial driver's:", all(v == base for v in csvs.values()), f"({len(base.splitlines()) - 1} rows)")
 print(base.decode().splitlines()[0]); print(base.decode().splitlines()[1])
+a = np.array(sorted(per_complex))
+fit = np.polyfit(a[:, 0], a[:, 2], 1)
+print(f"per complex (pipelined driver), ms: sample = {fit[1]:.1f} + {fit[0]:.4f} * N (least squares over {len(a)} complexes); "
+      f"prepare mean {a[:, 1].mean():.1f}, post mean {a[:, 3].mean():.1f}")
+print("  N: " + " ".join(f"{int(x):5d}" for x in a[:, 0]))
+print("  sample ms: " + " ".join(f"{x:5.0f}" for x in a[:, 2]))

@@ -18,15 +18,15 @@ pmc() {    # pmc <dir> <kernel regex> <bench args...>: one --pmc set per run, ke
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE"; do
     n=$(echo $c | cut -d' ' -f1-2 | tr ' ' '_')
-    ( cd /tmp && timeout 240 rocprofv3 --pmc $c --kernel-include-regex "$kr" --output-format csv -d $OUT/$dir -o $n -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fp32-line "$@" > $OUT/$dir/$n.log 2>&1 ) || echo "pass $c failed/timeout"
+    ( cd /tmp && timeout 240 rocprofv3 --pmc $c --kernel-include-regex "$kr" --output-format csv -d $OUT/$dir -o $n -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-fp32-line --no-c4-line --no-c5-line "$@" > $OUT/$dir/$n.log 2>&1 ) || echo "pass $c failed/timeout"
   done
   python tools/pmc_summary.py $OUT/$dir > $OUT/$dir.txt 2>&1
 }
-if [ -z "$SKIP_TESTS" ]; then timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log; fi
-prof bench_prof python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-line; tail -1 $OUT/bench_prof.log | cut -c1-200; head -12 $OUT/bench_prof_kernel_stats.csv | cut -c1-160
+if [ -z "$SKIP_TESTS" ]; then timeout 2400 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log; fi
+prof bench_prof python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-line --no-c4-line --no-c5-line; tail -1 $OUT/bench_prof.log | cut -c1-200; head -12 $OUT/bench_prof_kernel_stats.csv | cut -c1-160
 pmc pmc_all 'k_edge_msg|k_l0_gather|k_gemm_split|k_edge_coord|k_knn_sample|k_edge_feat|k_heads' --batch 256 --num-steps 3
 python tools/make_traffic_json.py $OUT > $OUT/traffic_summary.txt 2>&1; cat $OUT/traffic_summary.txt
-cp $OUT/traffic.json profiles/r04_traffic.json      # so that the bench line below replays THIS run's counters
+cp $OUT/traffic.json profiles/r05_traffic.json      # so that the bench line below replays THIS run's counters
 timeout 900 python bench.py > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log | cut -c1-400
 pmc pmc_knn_c5 'k_knn_sample' --R 1000 --L 1000 --batch 32 --num-steps 3; grep -E "INSTS_VALU |ACTIVE_INST_VALU|GRBM" $OUT/pmc_knn_c5.txt
 prof c5 python $GRAFT_REPO_ROOT/bench.py --R 1000 --L 1000 --batch 32 --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-line; tail -1 $OUT/c5.log | cut -c1-200; head -8 $OUT/c5_kernel_stats.csv | cut -c1-160
@@ -35,3 +35,6 @@ timeout 900 python tools/tol_report.py > $OUT/tol_report.txt 2>&1; grep -E "^dra
 timeout 600 python tools/size_sweep.py > $OUT/size_sweep.txt 2>&1; cat $OUT/size_sweep.txt
 timeout 300 python tools/graph_ab.py 1 8 40 120 > $OUT/small_batches.txt 2>&1; cat $OUT/small_batches.txt
 bash tools/b1_profile.sh > $OUT/b1_profile.txt 2>&1; BATCH=8 bash tools/b1_profile.sh > $OUT/b8_profile.txt 2>&1; tail -3 $OUT/b1_profile.txt
+timeout 600 python tools/c4_run.py > $OUT/c4_syn.txt 2> $OUT/c4_syn.err; grep -v "^SYN\|^id," $OUT/c4_syn.txt | cut -c1-300
+timeout 600 python tools/c4_run.py --db5 > $OUT/c4_db5.txt 2> $OUT/c4_db5.err; grep -v "^1AVX,\|^id," $OUT/c4_db5.txt | cut -c1-300
+timeout 600 python tools/selfcheck_db5.py > $OUT/selfcheck_db5.txt 2>&1
