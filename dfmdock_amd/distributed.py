@@ -286,8 +286,8 @@ def shard_range(total: int, world: int, rank: int):
 # affine in the residue count - a fixed part (41 evaluations x ~27 dependent launches that no batch of 40 fills) plus a per-residue
 # part - and scales with the trajectories per call; creation, self-check and metrics overlap with the previous / next complex's
 # sampling in the pipelined driver and only add to the first and last complex of a rank.
-SET_COST_FIXED_MS = 21.0
-SET_COST_PER_RESIDUE_MS = 0.125
+SET_COST_FIXED_MS = 10.0
+SET_COST_PER_RESIDUE_MS = 0.16
 SET_COST_EDGE_MS = 30.0      # un-overlapped prepare of a rank's first complex + post of its last
 
 
