@@ -130,7 +130,7 @@ def _post(p: _Prepared, batches, traj_dir):
 
 def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0, precision="mfma16", global_rotation=True,
             out_csv=None, traj_dir=None, max_batch=256, selfcheck=True, on_selfcheck_fail="fp32", checks_out=None,
-            overlap=True, samplers=1, timings_out=None, log=None, **sampler_kw):
+            overlap=True, samplers=2, timings_out=None, log=None, **sampler_kw):
     """Sample `num_samples` trajectories for every complex dict (id, rec_x, lig_x, rec_pos, lig_pos[, rec_seq, lig_seq]);
     returns the metric rows of this rank's share; rank 0 writes the gathered CSV when `out_csv` is given.  Every complex is
     self-checked first (checked_precision); `checks_out` (a list) collects {id, precision used, check dict}.
@@ -138,8 +138,8 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
     The reference's loop (src/inference_mlsb.py:415-439 over :188-262) is serial: load, sample, score, next.  Here the three
     stages of a complex run on three host threads (`overlap=True`): while complex k samples on its handle's stream, complex k+1
     is created and self-checked on ITS handle's stream (dfmdock_amd.h: handles are independent) and complex k-1's 40 Kabsch
-    fits / CSV rows are computed on the host; `samplers` > 1 lets that many complexes sample concurrently (small complexes do
-    not fill the GPU at B = 40).  Results do not depend on any of this: a trajectory is a pure function of (seed, complex,
+    fits / CSV rows are computed on the host; `samplers` complexes sample concurrently (default 2: a B = 40 batch of a 200-400-residue
+    complex does not fill 256 CUs; measured +4 ... +8 % over one sampler on the C4 set, profiles/r05_c4.txt; 3 buys nothing more).  Results do not depend on any of this: a trajectory is a pure function of (seed, complex,
     trajectory index), so the rows equal the serial driver's (`overlap=False`) bit for bit.  `timings_out` (a list) collects
     per-complex {id, N, prepare, sample, post} milliseconds; `log` receives the self-check lines
     (default: stderr)."""

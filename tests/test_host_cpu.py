@@ -392,3 +392,68 @@ def test_set_run_assignment_over_eight_ranks_with_the_measured_cost_model():
     assert D.makespan(costs, a) <= D.makespan(costs, by_n) + 1e-9
     # fewer complexes than 2 x ranks: run_set splits TRAJECTORIES instead (every rank holds every complex)
     assert [D.shard_range(40, 8, r) for r in range(8)] == [(5 * r, 5 * r + 5) for r in range(8)]
+
+
+def test_run_set_pipeline_stages_overlap_and_fail_cleanly(monkeypatch):
+    """driver.run_set's three-stage pipeline with the engine stubbed out (CPU): rows come back in share order whatever the stage
+    timings, the stages of neighbouring complexes really overlap (wall clock well below the serial sum), at most `samplers + 1`
+    handles are ever prepared ahead of sampling, and an exception in any stage surfaces in the caller instead of hanging the pools."""
+    import threading, time
+    from dfmdock_amd import driver
+    log, lock = [], threading.Lock()
+    live = {"prepared": 0, "max_prepared": 0}
+
+    class P:
+        pass
+
+    def prep(model, c, ci, rot_seed, global_rotation, precision, selfcheck, on_fail, seed, log_=None):
+        with lock:
+            live["prepared"] += 1
+            live["max_prepared"] = max(live["max_prepared"], live["prepared"])
+        time.sleep(0.03)
+        p = P(); p.ci, p.c, p.precision, p.check, p.ms = ci, c, precision, None, {"prepare": 30.0}
+        p.gx = type("G", (), {"N": c["rec_x"].shape[0] + c["lig_x"].shape[0]})()
+        return p
+
+    def samp(p, t_lo, t_hi, num_steps, seed, max_batch, trace, kw):
+        with lock:
+            live["prepared"] -= 1
+            log.append(("sample", p.ci))
+        if p.c.get("boom") == "sample":
+            raise RuntimeError("sampling failed")
+        time.sleep(0.06)
+        p.ms["sample"] = 60.0
+        return [(t_lo, t_hi - t_lo, None)]
+
+    def post(p, batches, traj_dir):
+        if p.c.get("boom") == "post":
+            raise RuntimeError("post failed")
+        time.sleep(0.03)
+        p.ms["post"] = 30.0
+        return [{"id": p.c["id"], "index": str(k)} for k in range(batches[0][1])], []
+
+    monkeypatch.setattr(driver, "_prepare", prep)
+    monkeypatch.setattr(driver, "_sample", samp)
+    monkeypatch.setattr(driver, "_post", post)
+    cxs = [{"id": f"C{k}", "rec_x": np.zeros((10 + k, 4)), "lig_x": np.zeros((5, 4))} for k in range(8)]
+    for samplers in (1, 2):
+        log.clear(); live.update(prepared=0, max_prepared=0)
+        tim = []
+        t0 = time.perf_counter()
+        rows, ranked = driver.run_set(None, cxs, num_samples=3, overlap=True, samplers=samplers, timings_out=tim)
+        dt = time.perf_counter() - t0
+        order = [c["id"] for c in sorted(cxs, key=lambda c: -c["rec_x"].shape[0])]      # one rank: longest first
+        assert [r["id"] for r in rows] == [i for i in order for _ in range(3)] and ranked == {}
+        assert [t["id"] for t in tim] == order
+        assert dt < 0.8 * 8 * 0.12, dt                                   # serial would be 8 x (30 + 60 + 30) ms
+        assert live["max_prepared"] <= samplers + 1, live
+    t0 = time.perf_counter()
+    rows_serial, _ = driver.run_set(None, cxs, num_samples=3, overlap=False)
+    assert rows_serial == rows and time.perf_counter() - t0 > 0.9 * 8 * 0.12
+    for where in ("sample", "post"):
+        bad = [dict(c) for c in cxs]
+        bad[3]["boom"] = where
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match=where[:4]):
+            driver.run_set(None, bad, num_samples=3, overlap=True)
+        assert time.perf_counter() - t0 < 5.0
