@@ -273,7 +273,15 @@ __device__ inline void edge_feature(const float4 *__restrict__ n4, const float4 
                                     size_t base, int i, int j, int R, float mask_dist, uint32_t &code, float &r2_out)
 {
     const float4 cai4 = ca4[base + i], caj4 = ca4[base + j], cbi4 = cb4[base + i], cbj4 = cb4[base + j];
+#ifdef DFM_N4_COHERENT      // experiment (r05): read N_i past L1 and L2 (system-coherent load)
+    float4 ni4;
+    {
+        const float4 *ap = n4 + base + i;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(ni4) : "v"(ap) : "memory");
+    }
+#else
     const float4 ni4 = n4[base + i];
+#endif
     const v3 Ni{ni4.x, ni4.y, ni4.z};
     const v3 Cai{cai4.x, cai4.y, cai4.z}, Caj{caj4.x, caj4.y, caj4.z}, Cbi{cbi4.x, cbi4.y, cbi4.z},
         Cbj{cbj4.x, cbj4.y, cbj4.z};
@@ -298,6 +306,17 @@ __device__ inline void edge_feature(const float4 *__restrict__ n4, const float4 
     off = off < 0 ? 0 : (off > 64 ? 64 : off);
     const int rp = same ? off : 65;
     code = pack_code(bd, bo, bt, bp, rp);
+#ifdef DFM_FEAT_PROBE      // experiment (r05): load N_i again and compute theta again - bit 30: the two loads differ; bit 31: same loads, different bin
+    if (d < mask_dist && i != j) {
+        float4 nb;
+        const float4 *ap = n4 + base + i;
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(nb) : "v"(ap) : "memory");
+        const bool same = nb.x == ni4.x && nb.y == ni4.y && nb.z == ni4.z;
+        const int bt2 = bin_angle(dihedral_deg(v3{nb.x, nb.y, nb.z}, Cai, Cbi, Cbj));
+        if (!same) code |= 1u << 30;
+        else if (bt2 != bt) code |= 1u << 31;
+    }
+#endif
     r2_out = r2;
 }
 
