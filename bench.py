@@ -189,7 +189,7 @@ def c4_line(engine, model, precision, num_steps):
     driver.run_set(model, cxs[:3], num_samples=40, num_steps=num_steps, seed=0, precision=precision,
                    out_csv=os.path.join(tmp, "warm.csv"), log=quiet)
     res = {}
-    for name, kw in (("serial", dict(overlap=False)), ("pipelined", dict(overlap=True)), ("pipelined_2_samplers", dict(overlap=True, samplers=2))):
+    for name, kw in (("serial", dict(overlap=False)), ("pipelined", dict(overlap=True, samplers=1)), ("pipelined_2_samplers", dict(overlap=True, samplers=2))):
         tim = []
         t0 = time.perf_counter()
         rows, _ = driver.run_set(model, cxs, num_samples=40, num_steps=num_steps, seed=0, precision=precision,

@@ -37,7 +37,7 @@ print(f"C4-shaped run: {label}, N = {min(Ns)}..{max(Ns)}, 40 trajectories each, 
 driver.run_set(model, cxs[:2], num_samples=40, num_steps=40, seed=0, precision="mfma16", out_csv=os.path.join(tmp, "warm.csv"),
                selfcheck=True, on_selfcheck_fail="warn")      # warm-up: code objects, the block cache
 csvs = {}
-for name, kw in (("serial (r04 driver)", dict(overlap=False)), ("pipelined", dict(overlap=True)),
+for name, kw in (("serial (r04 driver)", dict(overlap=False)), ("pipelined", dict(overlap=True, samplers=1)),
                  ("pipelined, 2 samplers", dict(overlap=True, samplers=2)), ("pipelined, 3 samplers", dict(overlap=True, samplers=3))):
     out = os.path.join(tmp, name.split()[0] + str(kw.get("samplers", 1)) + ".csv")
     tim = []
