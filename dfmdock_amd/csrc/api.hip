@@ -294,9 +294,9 @@ struct dfm_complex {
     // layer-0 message table of the 16-bit engine (kernels_edge.hip: k_l0_gather): gated messages of every intra-chain ordered pair
     // [R*R + L*L][256] fp16 and the feature code each entry was built with; rebuilt after set_pose / set_homomer
     DevPool l0_pool, l0_pool32;
-    uint16_t *l0_table = nullptr; uint32_t *l0_code0 = nullptr;
+    uint16_t *l0_table = nullptr; uint2 *l0_code0 = nullptr;
     bool l0_valid = false;
-    float *l0_table32 = nullptr; uint32_t *l0_code0_32 = nullptr; bool l0_valid32 = false;      // the fp32 engine's table (1 KiB per pair)
+    float *l0_table32 = nullptr; uint2 *l0_code0_32 = nullptr; bool l0_valid32 = false;      // the fp32 engine's table (1 KiB per pair)
     std::vector<hipEvent_t> ev_l0;   // profiling events of the table path (triples: before rows | between | after gather)
     size_t ev_l0_used = 0;
     // One step of dfm_sample (score evaluation + heads + Euler-Maruyama update [+ clash force]) captured as a hipGraph and replayed
@@ -917,7 +917,7 @@ static int build_l0_table(dfm_complex *cx, float *build_ms, bool fp32 = false)
     HIPCHK(hipStreamSynchronize(s));
     (fp32 ? cx->l0_pool32 : cx->l0_pool).release(true);
     cx->buf_gen++;
-    uint32_t *code0 = nullptr;
+    uint2 *code0 = nullptr;
     if (fp32) {
         HIPCHK(cx->l0_pool32.alloc(&cx->l0_table32, P * H));
         HIPCHK(cx->l0_pool32.alloc(&cx->l0_code0_32, P));

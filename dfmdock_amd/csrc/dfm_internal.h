@@ -190,7 +190,7 @@ hipError_t launch_knn_sample(const float4 *ca4, int B, int N, int knn, int nsamp
 // layer 0 behind the per-complex message table (kernels_edge.hip: k_l0_gather): k_edge_feat's classification of every edge into
 // table hits (src = pair index) and row-list entries (src = 0x80000000 | position).  code0 == nullptr: no classification.
 struct L0Classify {
-    const uint32_t *code0;   // [pairs] feature code each table entry was built with
+    const uint2 *code0;      // [pairs] (feature code, bits of |x_i - x_j|^2) each table entry was built with
     uint32_t *src;           // [B][N][K]
     uint4 *rows;             // [capacity] (i, j, code, radial bits) of the misses
     uint32_t *counter;       // rows appended so far (zero at the start of an evaluation: k_l0_gather resets it)
@@ -198,7 +198,7 @@ struct L0Classify {
 hipError_t launch_edge_feat(const float4 *n4, const float4 *ca4, const float4 *cb4, const int32_t *edges, int B,
                             int N, int R, int K, float mask_dist, uint32_t *codes, float *radial, const L0Classify &cls,
                             uint32_t *eval_ctr /* or nullptr: incremented once per launch (replayed step graph) */, hipStream_t s);
-hipError_t launch_l0_pairs(const float4 *n4, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint32_t *code0,
+hipError_t launch_l0_pairs(const float4 *n4, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint2 *code0,
                            uint4 *rows, hipStream_t s);
 
 struct EdgeArgs {

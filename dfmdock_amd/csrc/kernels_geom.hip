@@ -364,7 +364,12 @@ __global__ __launch_bounds__(CLS ? 1024 : 256) void k_edge_feat(const float4 *__
         __syncthreads();
         const bool same = (i < R) == (j < R);
         const uint32_t idx = (live && same) ? l0_pair_index(i, j, R, N - R) : 0u;
-        const bool hit = live && same && cls.code0[idx] == code;
+        // a HIT needs the pair's code AND its squared distance to be those the entry was built with: under the rigid motion of a chain
+        // the distance moves by rounding only (|d r2| <= 2 d x ~1e-5 A), a different conformer or a perturbed backbone moves it by
+        // >= 2 d x 1e-2 A - such an edge is a miss and goes through the edge model, so DFM_F_L0_TABLE is safe for ANY lig_pos
+        // (the rigid-image precondition is now checked instead of assumed)
+        const uint2 c0 = cls.code0[idx];
+        const bool hit = live && same && c0.x == code && fabsf(__uint_as_float(c0.y) - r2) <= 1e-3f * fmaxf(sqrtf(r2), 1.0f);
         const bool is_miss = live && !hit;
         const unsigned long long miss = __ballot(is_miss);
         const int lane = threadIdx.x & 63;
@@ -399,7 +404,7 @@ hipError_t launch_edge_feat(const float4 *n4, const float4 *ca4, const float4 *c
 // every intra-chain ordered pair of the complex (self pairs included: slot 0 of a node is the node itself) as a row list for the table
 // build, features from the prepared pose of trajectory 0; code0 = the code each table entry is built with
 __global__ __launch_bounds__(256) void k_l0_pairs(const float4 *__restrict__ n4, const float4 *__restrict__ ca4, const float4 *__restrict__ cb4,
-                                                  int R, int L, float mask_dist, uint32_t *__restrict__ code0, uint4 *__restrict__ rows)
+                                                  int R, int L, float mask_dist, uint2 *__restrict__ code0, uint4 *__restrict__ rows)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x, RR = (uint32_t)R * (uint32_t)R, P = RR + (uint32_t)L * (uint32_t)L;
     if (q >= P) return;
@@ -409,11 +414,11 @@ __global__ __launch_bounds__(256) void k_l0_pairs(const float4 *__restrict__ n4,
     uint32_t code;
     float r2;
     edge_feature(n4, ca4, cb4, 0, i, j, R, mask_dist, code, r2);
-    code0[q] = code;
+    code0[q] = make_uint2(code, __float_as_uint(r2));
     rows[q] = make_uint4((uint32_t)i, (uint32_t)j, code, __float_as_uint(r2));
 }
 
-hipError_t launch_l0_pairs(const float4 *n4, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint32_t *code0,
+hipError_t launch_l0_pairs(const float4 *n4, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint2 *code0,
                            uint4 *rows, hipStream_t s)
 {
     const long long P = (long long)R * R + (long long)L * L;

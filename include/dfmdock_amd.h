@@ -110,14 +110,11 @@ enum {
        Inter-chain edges, and intra-chain edges whose feature bins in the pose at hand differ from the table's, go through the edge
        model as before.  Against the direct evaluation the only difference is the fp16 rounding of each stored message before the
        K-row sum (fp32 engine: fp32 rows of 1 KiB, only the ORDER of the K-row sum differs, <= 2e-5; measured: tests/test_gpu_l0_table.py).                                                                  */
-    DFM_F_L0_TABLE = 1u << 11,       /* dfm_score: use (and if necessary build) the table.  PRECONDITION: every lig_pos handed to
-                                        the call is a RIGID image of the ligand pose stored in the handle (dfm_complex_create /
-                                        dfm_complex_set_pose) - what the sampler produces.  A hit is decided by equality of the
-                                        edge's bin code in the pose at hand with the code the entry was built on; the entry's radial
-                                        term is that of the STORED pose (equal to the pose's own up to the last bits of fp32 under
-                                        rigid motion).  A different conformer or a perturbed backbone whose bins still match would
-                                        silently get the stored pose's radial: call dfm_complex_set_pose first (it invalidates the
-                                        table) or do not pass this flag.  Above the edge budget of one batched evaluation
+    DFM_F_L0_TABLE = 1u << 11,       /* dfm_score: use (and if necessary build) the table.  A hit needs the edge's bin code AND its squared
+                                        C-alpha distance in the pose at hand to equal those the entry was built with on the handle's stored
+                                        pose (the distance up to the rounding of a rigid motion, 1e-3 A x max(d, 1)): any lig_pos is safe - an
+                                        intra-chain pair whose geometry differs (another conformer, a perturbed backbone) is a miss and goes
+                                        through the edge model like an inter-chain edge.  Above the edge budget of one batched evaluation
                                         (B * N * K > 32 M edges: B > 890 at 300+300) layer 0 is evaluated directly, so results are
                                         batch-invariant bit for bit only among calls on the same side of that budget.            */
     DFM_F_NO_L0_TABLE = 1u << 12,    /* dfm_sample: evaluate layer 0 directly                                            */

@@ -228,3 +228,35 @@ def test_fp32_sampler_uses_the_table_and_is_batch_invariant(model):
     assert gx.profile()["l0_evals"] == 0
     assert np.abs(off["lig_pos"] - a["lig_pos"]).max() < 1e-2      # same draws, fp32 either way: only the order of layer 0's row sums differs
     gx.close()
+
+
+def test_table_is_safe_for_a_pose_that_is_not_a_rigid_image(model):
+    """a hit used to be decided by the bin code alone, so a DIFFERENT conformer handed to dfm_score(DFM_F_L0_TABLE) whose
+    bins still matched silently got the stored pose's radial term.  A table entry now carries its squared distance and a hit needs it
+    to match up to the rounding of a rigid motion: on a ligand whose residues are jittered by 0.3 A (not a rigid image) the intra-
+    ligand edges become misses - evaluated by the edge model on the pose at hand - and the result equals the direct evaluation at
+    the table-vs-direct tolerance; on a rigid image of the same size nothing but inter-chain edges and bin mismatches misses."""
+    from dfmdock_amd import engine
+    from dfmdock_amd.synthetic import make_complex
+    cx = make_complex(120, 90, seed=3)
+    gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    R, N = 120, 210
+    rng = np.random.default_rng(5)
+    rigid = (cx["lig_pos"] + np.float32([3.0, -2.0, 1.5])).astype(np.float32)
+    bent = (cx["lig_pos"] + 0.3 * rng.standard_normal((90, 1, 3)).astype(np.float32)).astype(np.float32)      # per-residue jitter
+    res = {}
+    for name, pose in (("rigid", rigid), ("bent", bent)):
+        d = gx.score(pose, 0.5, seed=11, mfma16=True, energy=True, debug=True)
+        t = gx.score(pose, 0.5, edges=d["edges"], mfma16=True, energy=True, l0_table=True, profile=True)
+        p = gx.profile()
+        same = (np.arange(N)[None, :, None] < R) == (d["edges"] < R)
+        intra_lig = int((same & (np.arange(N)[None, :, None] >= R)).sum())
+        res[name] = (p["l0_miss_rows"], int((~same).sum()), intra_lig)
+        for k in ("f", "tr_score", "rot_score"):
+            assert rel_inf(t[k], d[k]) < 2e-3, (name, k, rel_inf(t[k], d[k]))
+        assert abs(float(t["energy"][0]) - float(d["energy"][0])) < 1e-3 * max(1.0, abs(float(d["energy"][0])))
+    miss, inter, intra_lig = res["rigid"]
+    assert inter <= miss < inter + 0.02 * intra_lig, res["rigid"]                 # inter-chain edges + a few bin mismatches
+    miss, inter, intra_lig = res["bent"]
+    assert miss > inter + 0.9 * (intra_lig - 90), res["bent"]                    # (all but the 90 self edges of) the ligand's own edges miss
+    gx.close()
