@@ -72,7 +72,28 @@ def gen_phi0_pair():
             bins=bins.astype(np.int8))
 
 
+def gen_pair_family(ids):
+    """Second model family (DFMDock.forward = move_to_lig_center + EGNN_Net, src/models/DFMDock.py:68-75, src/models/egnn_net.py:408-505)
+    on the same real feature blocks and poses: fwd2_esm_<id>.npz (no [N,256] taps: |h| maxima only)."""
+    import make_golden_pair as mgp
+    net1 = mgp.build_net(0)
+    for cid in ids:
+        t, rot, trs, seed = IDS[cid]
+        d = load_db5_pt(os.path.join(mg.REF, f"data/db5_test/{cid}.pt"))
+        cx = {"rec_x": np.concatenate([d["rec_esm"].astype(np.float16).astype(np.float32), d["rec_x"][:, 1280:]], 1),
+              "lig_x": np.concatenate([d["lig_esm"].astype(np.float16).astype(np.float32), d["lig_x"][:, 1280:]], 1),
+              "rec_pos": d["rec_pos"].astype(np.float32), "lig_pos": d["lig_pos"].astype(np.float32)}
+        lp = mg.noised_pose(cx, np.random.Generator(np.random.PCG64(seed)), rot, trs)      # the pose of fwd_esm_<id>.npz
+        r = mgp.slim(mgp.forward_case(net1, cx, lp, t, seed=seed + 20))
+        out = {k: r[k] for k in ("lig_pos", "t", "tr_score", "rot_score", "energy", "f", "num_clashes", "confidence_logits", "ires_logits")}
+        out["edges"] = r["edges"].astype(np.int16)
+        out["h_absmax"] = np.array([np.abs(r["h_first"]).max(), np.abs(r["h_last"]).max()])
+        mg.save(f"fwd2_esm_{cid}.npz", **out)
+
+
 def main(which):
+    if which and which[0] == "pair":
+        return gen_pair_family(which[1:] or list(IDS))
     net = mg.build_net(0)
     model = mg.Model(net).eval()
     if not which or "phi0" in which:

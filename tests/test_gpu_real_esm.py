@@ -102,6 +102,30 @@ def test_rollout_vs_reference(cid, prec, table, model):
     gx.close()
 
 
+@pytest.mark.parametrize("cid", IDS)
+def test_pair_family_on_real_features(cid, blob_pair):
+    """Second model family (DFMDock.forward, src/models/DFMDock.py:68-75 -> src/models/egnn_net.py:408-505) on the same real
+    feature blocks: fp32 engine at 1e-4, 16-bit engines at SURVEY 8(d)'s gates, against the reference's evaluation."""
+    from conftest import pair_hparams
+    from dfmdock_amd import engine
+    g = load_golden(f"fwd2_esm_{cid}.npz")
+    engine.set_device(0)
+    m = engine.Model(blob_pair, pair_hparams())
+    cx = real_db5_complex(cid)
+    gx = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    e, t = g["edges"].astype(np.int32), float(g["t"])
+    for name, kw, tol, etol in (("fp32", {}, 1e-4, 1e-4), ("mfma16", dict(mfma16=True), 1e-2, 3e-2), ("f16", dict(f16=True), 1e-2, 3e-2)):
+        r = gx.score(g["lig_pos"], t, edges=e, energy=True, **kw)
+        assert rel_inf(r["f"][0], g["f"]) < tol, (name, "f", rel_inf(r["f"][0], g["f"]))
+        assert rel_inf(r["tr_score"][0], g["tr_score"].reshape(3)) < tol, (name, "tr_score")
+        assert rel_inf(r["rot_score"][0], g["rot_score"].reshape(3)) < tol, (name, "rot_score")
+        assert abs(float(r["energy"][0]) - float(g["energy"])) < etol * max(1.0, abs(float(g["energy"]))), (name, "energy")
+        assert abs(float(r["confidence"][0]) - float(g["confidence_logits"])) < etol * max(1.0, abs(float(g["confidence_logits"]))), (name, "confidence")
+        assert int(r["num_clashes"][0]) == int(g["num_clashes"]), name
+    gx.close()
+    m.close()
+
+
 @pytest.mark.parametrize("cid", REAL_ESM_IDS)
 def test_selfcheck_on_real_features(cid, model):
     """The 16-bit engine's range and deviation self-check on the complex's own pose: OK, nothing saturated, and at least a factor 4
