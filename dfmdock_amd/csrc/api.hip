@@ -801,15 +801,18 @@ extern "C" long long dfm_trim_cache(int device)
 
 // ------------------------------------------------------------------------------------------------
 // Layer 0 behind the message table: budgets.  The table costs 516 B per intra-chain ordered pair (8 M pairs = 4.1 GB: 2000 + 2000
-// residues), the per-batch buffers 532 B per edge of a batched evaluation (32 M edges = 17 GB: B = 890 at 300+300) - sized for
-// 288 GB of HBM.  Beyond either budget layer 0 is evaluated directly (DFM_L0_TABLE=0 in the environment: always).
-constexpr long long L0_MAX_PAIRS = 8ll << 20, L0_MAX_EDGES = 32ll << 20;
-static bool l0_eligible(const dfm_complex *cx, int B)
+// residues); beyond it layer 0 is evaluated directly (DFM_L0_TABLE=0 in the environment: always).  Eligibility is a property of the
+// COMPLEX alone (r04 also switched to the direct evaluation above 32 M edges per batched evaluation, so a trajectory's bits
+// changed with the batch size at B = 890 for 300+300): the per-batch buffers cost 532 B per edge of a batched evaluation (19 MB per
+// trajectory at 300+300, next to 14 MB of workspace) for every batch the 2^31-byte guard of ensure_workspace admits; a batch whose
+// buffers do not fit fails with DFM_E_OOM - split it, or pass DFM_F_NO_L0_TABLE - instead of silently changing the arithmetic.
+constexpr long long L0_MAX_PAIRS = 8ll << 20;
+static bool l0_eligible(const dfm_complex *cx, int /*B*/)
 {
     static const bool env_off = [] { const char *e = getenv("DFM_L0_TABLE"); return e && atoi(e) == 0; }();
     if (env_off || cx->m->hp.depth < 2) return false;      // (a depth-1 model's first layer is its last: it stores messages for the coordinate MLP)
     const long long pairs = (long long)cx->R * cx->R + (long long)cx->L * cx->L;
-    return pairs <= L0_MAX_PAIRS && (long long)B * cx->N * cx->K <= L0_MAX_EDGES;
+    return pairs <= L0_MAX_PAIRS;
 }
 
 constexpr int MIN_TIME_GRID = 4096;      // smallest time grid the workspace is sized for (dfm_sample grows it for longer schedules)
@@ -1424,10 +1427,7 @@ extern "C" int dfm_sample(dfm_complex *cx, int B, int num_steps, float eps, floa
     const bool f16 = flags & DFM_F_F16, bf16 = (flags & DFM_F_MFMA16) || f16;
     DEVICE_SCOPE(cx->device);
     // layer 0 through the complex's message table whenever the shipped 16-bit plan (or the fp32 engine) runs and the complex is
-    // eligible.  Eligibility is a property of the complex EXCEPT for the edge budget of one batched evaluation (l0_eligible:
-    // B * N * K <= 32 M edges = B <= 890 at 300+300): a caller that wants a trajectory's bits not to depend on the batch it is
-    // sampled in keeps B below that budget - dfmdock_amd/score_model.py and driver.py cap a call at 256 - or passes
-    // DFM_F_NO_L0_TABLE (dfmdock_amd.h)
+    // eligible - a property of the complex alone (l0_eligible), so a trajectory's bits do not depend on the batch it is sampled in
     const bool l0 = ((bf16 && !f16 && !(flags & DFM_F_BF16_OPS)) || !bf16) && !(flags & DFM_F_NO_L0_TABLE) && l0_eligible(cx, B);
     int rc = ensure_workspace(cx, B, bf16, l0);
     if (rc) return rc;

@@ -114,9 +114,9 @@ enum {
                                         C-alpha distance in the pose at hand to equal those the entry was built with on the handle's stored
                                         pose (the distance up to the rounding of a rigid motion, 1e-3 A x max(d, 1)): any lig_pos is safe - an
                                         intra-chain pair whose geometry differs (another conformer, a perturbed backbone) is a miss and goes
-                                        through the edge model like an inter-chain edge.  Above the edge budget of one batched evaluation
-                                        (B * N * K > 32 M edges: B > 890 at 300+300) layer 0 is evaluated directly, so results are
-                                        batch-invariant bit for bit only among calls on the same side of that budget.            */
+                                        through the edge model like an inter-chain edge.  Whether a complex uses the table depends on the
+                                        complex alone (R^2 + L^2 <= 8 M pairs), never on B: a batch whose per-edge buffers (532 B per edge)
+                                        do not fit fails with DFM_E_OOM instead of changing the arithmetic.                       */
     DFM_F_NO_L0_TABLE = 1u << 12,    /* dfm_sample: evaluate layer 0 directly                                            */
     DFM_F_GRAPH = 1u << 13           /* dfm_sample: capture ONE step (score evaluation + heads + update) as a hipGraph and replay it
                                         num_steps times instead of enqueueing every launch (ignored when anything is injected,

@@ -260,3 +260,16 @@ def test_table_is_safe_for_a_pose_that_is_not_a_rigid_image(model):
     miss, inter, intra_lig = res["bent"]
     assert miss > inter + 0.9 * (intra_lig - 90), res["bent"]                    # (all but the 90 self edges of) the ligand's own edges miss
     gx.close()
+
+
+def test_table_eligibility_does_not_depend_on_the_batch(model):
+    """r04 left the table path above 32 M edges per batched evaluation, so a trajectory's bits depended on B there.
+    Eligibility is now a property of the complex: a batch of 40 M edges (B = 1100 x N = 600 x K = 60) runs layer 0 through the
+    table and its first trajectories equal those of a small batch bit for bit."""
+    gx, _ = _complex(model, "fwd_c3_300_300")
+    big = gx.sample(B=1100, num_steps=2, seed=21, mfma16=True, profile=True)
+    assert gx.profile()["l0_evals"] == 3
+    small = gx.sample(B=4, num_steps=2, seed=21, mfma16=True)
+    for k in ("lig_pos", "energy", "tr_update", "rot_update"):
+        np.testing.assert_array_equal(big[k][:4], small[k], err_msg=k)
+    gx.close()
