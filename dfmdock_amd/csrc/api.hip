@@ -717,7 +717,7 @@ extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, con
     ok = ok && P.alloc(&cx->A0s, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->A0h, (size_t)N * H) == hipSuccess;
 #ifdef DFM_EDGE_STAMP
-    ok = ok && P.alloc(&cx->stamp_dev, 48) == hipSuccess && hipMemsetAsync(cx->stamp_dev, 0, 48 * 8, cx->stream) == hipSuccess;
+    ok = ok && P.alloc(&cx->stamp_dev, 48 + 8 * 130) == hipSuccess && hipMemsetAsync(cx->stamp_dev, 0, (48 + 8 * 130) * 8, cx->stream) == hipSuccess;
 #endif
     if (ok) {
         // node = single_embed(cat[rec_x, lig_x]) (score_net_mlsb.py:365-366): pose independent, once per complex
@@ -1271,6 +1271,14 @@ static int finish_profile(dfm_complex *cx)
         HIPCHK(hipStreamSynchronize(cx->stream));
         cx->prof.l0_miss_rows = (int64_t)tot;
     }
+#ifdef DFM_EDGE_TRACE      // diagnostic build: raw wave timelines of workgroup 0 -> $DFM_EDGE_TRACE_FILE (tools/edge_trace.py)
+    if (cx->stamp_dev && getenv("DFM_EDGE_TRACE_FILE")) {
+        static unsigned long long tr[8 * 130];
+        HIPCHK(hipMemcpyAsync(tr, cx->stamp_dev + 48, sizeof(tr), hipMemcpyDeviceToHost, cx->stream));
+        HIPCHK(hipStreamSynchronize(cx->stream));
+        if (FILE *f = fopen(getenv("DFM_EDGE_TRACE_FILE"), "wb")) { fwrite(tr, 1, sizeof(tr), f); fclose(f); }
+    }
+#endif
 #ifdef DFM_EDGE_STAMP
     if (cx->stamp_dev) {
         unsigned long long st[48];

@@ -32,6 +32,20 @@
 #define DFM_EDGE_WAVES 8
 #endif
 
+// r06 experiments on the producer's dependent chains (profiles/r06_exp_edge_sched.txt):
+#ifndef DFM_EDGE_ILV        // 1: the two 16-row passes of a chunk interleaved slot by slot (both passes' operands needed from slot 0 / 1)
+#define DFM_EDGE_ILV 0
+#endif
+#ifndef DFM_EDGE_SKEW       // 1: a pair's two v_exp go out at the end of its pre-activation slice, one MFMA slot ahead of the rest of its SiLU
+#define DFM_EDGE_SKEW 0
+#endif
+#ifndef DFM_EDGE_PRIO       // n > 0: s_setprio n for waves 4..7 (the second-dispatched wave of every SIMD)
+#define DFM_EDGE_PRIO 0
+#endif
+#ifndef DFM_EDGE_KO         // knock-out builds, WRONG RESULTS: bit 0 no MFMA, bit 1 no producer transcendentals, bit 2 no epilogue transcendentals
+#define DFM_EDGE_KO 0
+#endif
+
 // ---- memory-side choices ---------------------------------------------------------------------------------------------------------
 #ifndef DFM_EDGE_NT         // 1: single-pass streams (edge data, agg / message stores) carry the non-temporal hint
 #define DFM_EDGE_NT 1

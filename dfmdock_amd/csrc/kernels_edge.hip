@@ -333,6 +333,10 @@ struct RawP { uint4 bm, t0, t1, t2; };
 // one MFMA step on bf16 (F16 = 0) or fp16 (F16 = 1) operands, fp32 accumulate - same rate on gfx950
 template <int F16> __device__ inline f32x16 mfma16(const Frag &a, const Frag &b, f32x16 c)
 {
+#if DFM_EDGE_KO & 1      // knock-out build (wrong results): no matrix instruction, operands still read
+    asm volatile("" : "+v"(c) : "v"(a.u.x), "v"(a.u.w), "v"(b.u.x), "v"(b.u.w));      // (opaque: the epilogue is not folded away)
+    return c;
+#endif
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.f, b.f, c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.b, b.b, c, 0, 0, 0);
 }
@@ -395,6 +399,9 @@ __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void *base)
 {   // raw buffer (stride 0), 2 GiB window, dword-format descriptor word 3 of gfx9
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00027000);
 }
+// knock-out builds (DFM_EDGE_KO; WRONG results by design): bit 0 no MFMA, bit 1 no producer transcendentals, bit 2 no epilogue transcendentals
+template <int KO> __device__ inline float ko_exp2(float x) { if constexpr (KO) return x; else return __builtin_amdgcn_exp2f(x); }
+template <int KO> __device__ inline float ko_rcp(float x) { if constexpr (KO) return x; else return __builtin_amdgcn_rcpf(x); }
 // SiLU of two pre-scaled values (see SILU_S): 2 v_exp_f32 + 2 v_rcp_f32 + 2 packed ops
 __device__ inline f2 silu2s(f2 x)
 {
@@ -941,9 +948,10 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
 #endif
     };
 #endif
-    H8 pt, pbm;
-    f2 pv[4];
-    Frag pf;
+    H8 pt[2], pbm;
+    f2 pv[2][4];
+    f2 pex[2];      // DFM_EDGE_SKEW: exp2 of the pair in flight, issued at the end of the pair's pre-activation slice
+    Frag pf[2];
     // The producer arithmetic of one pass (8 channels of one row per lane) cut into eight slices, so that it can be laid between
     // MFMAs in program order: even slice 2e = pre-activation of channel pair e, odd slice 2e + 1 = its SiLU + conversion; slice 7
     // also stores the finished 16 bytes.
@@ -951,18 +959,18 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         const int e = k >> 1;
         if (k == 0) {
             H8 t1;
-            pt.u = r.t0; t1.u = r.t1; pbm.u = r.bm;
+            pt[q].u = r.t0; t1.u = r.t1; pbm.u = r.bm;
 #if !DFM_TAB_MERGE
             H8 t2;
             t2.u = r.t2;
 #endif
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                pt.h[x] = __hadd2(pt.h[x], t1.h[x]);
+                pt[q].h[x] = __hadd2(pt[q].h[x], t1.h[x]);
 #if !DFM_TAB_MERGE
-                pt.h[x] = __hadd2(pt.h[x], t2.h[x]);
+                pt[q].h[x] = __hadd2(pt[q].h[x], t2.h[x]);
 #endif
-                pt.h[x] = __hadd2(pt.h[x], pbm.h[x]);      // Bm_j joins the table rows in the packed fp16 sum (one add for two channels)
+                pt[q].h[x] = __hadd2(pt[q].h[x], pbm.h[x]);      // Bm_j joins the table rows in the packed fp16 sum (one add for two channels)
             }
         }
         if ((k & 1) == 0) {
@@ -970,32 +978,35 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             if constexpr (AW16) {      // w * radial (fp32) + a (fp16), one v_fma_mix_f32 per channel
                 const float4 &aq = (ROWS && q == 1) ? a1 : a0;
                 const uint32_t ah = __float_as_uint(e == 0 ? aq.x : (e == 1 ? aq.y : (e == 2 ? aq.z : aq.w)));
-                pv[e] = (f2){fma_half_lo(wv.x, radq[q], ah), fma_half_hi(wv.y, radq[q], ah)};
+                pv[q][e] = (f2){fma_half_lo(wv.x, radq[q], ah), fma_half_hi(wv.y, radq[q], ah)};
             } else {
                 const f2 rad2 = {radq[q], radq[q]};
                 const f2 av = e == 0 ? (f2){a0.x, a0.y} : (e == 1 ? (f2){a0.z, a0.w} : (e == 2 ? (f2){a1.x, a1.y} : (f2){a1.z, a1.w}));
-                pv[e] = wv * rad2 + av;
+                pv[q][e] = wv * rad2 + av;
             }
-            pv[e] = add_half2(pv[e], pt.h[e]);
+            pv[q][e] = add_half2(pv[q][e], pt[q].h[e]);
+            if constexpr (DFM_EDGE_SKEW && F16) pex[q] = (f2){ko_exp2<DFM_EDGE_KO & 2>(pv[q][e].x), ko_exp2<DFM_EDGE_KO & 2>(pv[q][e].y)};
         } else {
             if constexpr (F16) {
                 // fp16 operand from ONE v_cvt_pkrtz per pair: truncation saturates for free (no separate clamp), and the reciprocal
                 // carries a (1 + 2^-12) bias - its addend and multiplier are (1 - 2^-12) instead of 1 - so that the truncated value is
                 // within (-0.625, 0.375) ulp of the exact one: round-to-nearest-like (RMS 0.315 vs 0.289 ulp).  Same-box A/B with the
                 // packed fp16 sum above: 2.211 vs 2.251 ms per launch, deviations unchanged (profiles/r03_exp_edge_trims.txt)
-                const f2 x = pv[e];
-                f2 ex = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                const f2 x = pv[q][e];
+                f2 ex;
+                if constexpr (DFM_EDGE_SKEW) ex = pex[q];
+                else ex = (f2){ko_exp2<DFM_EDGE_KO & 2>(x.x), ko_exp2<DFM_EDGE_KO & 2>(x.y)};
                 ex = ex * (f2){0.999755859375f, 0.999755859375f} + (f2){0.999755859375f, 0.999755859375f};
-                const f2 r = {__builtin_amdgcn_rcpf(ex.x), __builtin_amdgcn_rcpf(ex.y)};
+                const f2 r = {ko_rcp<DFM_EDGE_KO & 2>(ex.x), ko_rcp<DFM_EDGE_KO & 2>(ex.y)};
                 const f2 m = x * r;
-                (&pf.u.x)[e] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(m.x, m.y));
+                (&pf[q].u.x)[e] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(m.x, m.y));
             } else {
-                const f2 m = silu2s(pv[e]);
-                pf.b[2 * e] = (__bf16)m.x; pf.b[2 * e + 1] = (__bf16)m.y;
+                const f2 m = silu2s(pv[q][e]);
+                pf[q].b[2 * e] = (__bf16)m.x; pf[q].b[2 * e + 1] = (__bf16)m.y;
             }
             if (k == 7) {
                 const int row = q * 16 + r16;
-                *reinterpret_cast<uint4 *>(buf + ((c4 * 32 + (row ^ (4 * c4))) << 4)) = pf.u;
+                *reinterpret_cast<uint4 *>(buf + ((c4 * 32 + (row ^ (4 * c4))) << 4)) = pf[q].u;
             }
         }
     };
@@ -1010,6 +1021,14 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
 #else
 #define STAMP(k)
 #define STAMP0()
+#endif
+#ifdef DFM_EDGE_TRACE      // diagnostic build: absolute s_memtime of tile start / epilogue start of the first 64 tiles of every wave of workgroup 0
+    int tr_n = 0;          // -> p.stamp[48 + wave * 130 ...] ([0] = HW_ID register: SIMD id in bits 5:4); tools/edge_trace.py
+#define TRACE(w) { if (p.stamp && blockIdx.x == 0 && tr_n < 64) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+                   if (lane == 0) p.stamp[48 + wave * 130 + 1 + 2 * tr_n + (w)] = _t; __builtin_amdgcn_sched_barrier(0); } }
+    if (p.stamp && blockIdx.x == 0 && lane == 0) p.stamp[48 + wave * 130] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+#else
+#define TRACE(w)
 #endif
 
     // ---- the only prologue of the wave: first tile's chunk 0 built, its chunk 1 requested
@@ -1027,6 +1046,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
     for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
     __syncthreads();
     if (!has_task) return;
+    if constexpr (DFM_EDGE_PRIO) { if (wave >= EDGE_WAVES / 2) __builtin_amdgcn_s_setprio(DFM_EDGE_PRIO); }      // the second wave of every SIMD
     compute_store(0, r0, stage); gather(1, 0, r0);
     compute_store(1, r1, stage); gather(1, 1, r1);
     gather_chunk(1);
@@ -1038,6 +1058,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
 
     while (true) {
         STAMP0();
+        TRACE(0);
         // the tile after this one (lookahead); none left: this tile again, requested and built but never consumed
         unsigned ntt = tt;
         int nb = b, ni = i, nmt = mt + 1;
@@ -1081,7 +1102,8 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
                 if constexpr (decltype(last)::value) {
                     if (m < 8) bp[m] = p.biasp[m * 64 + lane];      // older than this chunk's gathers: the bias step does not wait for them
                 }
-                if (m < 8) slice(0, m & 7, r0, bufn); else slice(1, m & 7, r1, bufn);
+                if constexpr (DFM_EDGE_ILV) { if (m & 1) slice(1, m >> 1, r1, bufn); else slice(0, m >> 1, r0, bufn); }      // passes interleaved slot by slot
+                else { if (m < 8) slice(0, m & 7, r0, bufn); else slice(1, m & 7, r1, bufn); }
                 if (m == DFM_EDGE_G0) gather(cg, 0, r0);
                 if constexpr (!decltype(last)::value || DFM_EDGE_DEFER < 1) { if (m == DFM_EDGE_GC) gather_chunk(cg); }
                 if constexpr (!decltype(last)::value || DFM_EDGE_DEFER < 2) { if (m == DFM_EDGE_G1) gather(cg, 1, r1); }
@@ -1107,6 +1129,10 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             acc[nt] = mfma16<F16>(onef, bb, acc[nt]);
         }
         STAMP(2);
+        TRACE(1);
+#ifdef DFM_EDGE_TRACE
+        ++tr_n;
+#endif
 
         // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) = (r & 3) + 8 (r >> 2) + 4 h
         float part[16];
@@ -1119,7 +1145,9 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
                 const f2 vv = {dv[nt], dv[nt]};
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const f2 m = silu2s((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
+                    f2 m;
+                    if constexpr (DFM_EDGE_KO & 4) m = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){0.5f, 0.5f};      // knock-out: no transcendentals
+                    else m = silu2s((f2){acc[nt][2 * q], acc[nt][2 * q + 1]});
                     acc[nt][2 * q] = m.x; acc[nt][2 * q + 1] = m.y;
                     part2[q] = m * vv + part2[q];
                 }
@@ -1271,6 +1299,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
 #endif
 #undef STAMP
 #undef STAMP0
+#undef TRACE
 }
 
 // Coordinate MLP of the last layer (egnn.py:118-137) over the stored gated messages of the ligand nodes: same tile and epilogue

@@ -1035,3 +1035,35 @@ int ora_sample(const ora_hparams *hp, const float *blob, int R, int L, const flo
     free(lig); free(ts);
     return forwards;
 }
+
+/* Trajectory-parallel form of the sampler: n_traj INDEPENDENT trajectories (inference_base.py:644-657 runs them one after the other;
+ * they interact only in the final arg-min over energies), one single-threaded trajectory per OpenMP thread, seeds seed0 + index.
+ * This is how a CPU would run the headline metric (trajectories/s) on all its cores: no fork / join inside an evaluation, no shared
+ * write traffic - every nested parallel region of ora_score runs on the calling thread.  bench.py's cpu_baseline times it on a
+ * bounded number of evaluations per trajectory (max_forwards).  energy / clashes / forwards: per-trajectory outputs [n_traj] or NULL. */
+int ora_sample_many(const ora_hparams *hp, const float *blob, int R, int L, const float *rec_x, const float *lig_x,
+                    const float *rec_pos, const float *lig_pos0, int num_steps, float eps, float tr_noise_scale,
+                    float rot_noise_scale, int max_forwards, uint64_t seed0, int n_traj, int n_threads,
+                    float *energy, int64_t *clashes, int *forwards, float *updates)
+{
+    if (n_traj <= 0) return 0;
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+    if (n_threads > n_traj) n_threads = n_traj;
+    const int levels = omp_get_max_active_levels();
+    omp_set_max_active_levels(1);      /* the evaluations' own parallel regions stay on the trajectory's thread */
+    int total = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : total)
+    for (int k = 0; k < n_traj; ++k) {
+        ora_traj_out out;
+        memset(&out, 0, sizeof(out));
+        const int nf = ora_sample(hp, blob, R, L, rec_x, lig_x, rec_pos, lig_pos0, num_steps, eps, tr_noise_scale, rot_noise_scale,
+                                  0, 0, 0, max_forwards, seed0 + (uint64_t)k, NULL, &out);
+        if (energy) energy[k] = out.energy;
+        if (clashes) clashes[k] = out.num_clashes;
+        if (forwards) forwards[k] = nf;
+        if (updates) { memcpy(updates + 6 * k, out.rot_update, 12); memcpy(updates + 6 * k + 3, out.tr_update, 12); }
+        total += nf;
+    }
+    omp_set_max_active_levels(levels);
+    return total;
+}

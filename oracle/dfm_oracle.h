@@ -118,6 +118,15 @@ int ora_sample(const ora_hparams *hp, const float *blob, int R, int L, const flo
                int use_clash_force, int ode, int max_forwards /* <=0: all */, uint64_t seed,
                const ora_inject *inj, ora_traj_out *out);
 
+/* n_traj independent trajectories, one single-threaded trajectory per OpenMP thread (inference_base.py:644-657 runs them in
+ * sequence; they only meet in the arg-min over energies): the all-cores CPU form of the headline metric.  Returns the number of
+ * score evaluations done in total; per-trajectory outputs may be NULL. */
+int ora_sample_many(const ora_hparams *hp, const float *blob, int R, int L, const float *rec_x, const float *lig_x,
+                    const float *rec_pos, const float *lig_pos, int num_steps, float eps, float tr_noise_scale,
+                    float rot_noise_scale, int max_forwards, uint64_t seed0, int n_traj, int n_threads,
+                    float *energy /*[n_traj]*/, int64_t *clashes /*[n_traj]*/, int *forwards /*[n_traj]*/,
+                    float *updates /*[n_traj,6]: rot_update, tr_update*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,9 @@ def lib():
         L.ora_sample.argtypes = [C.POINTER(OraHParams), F32P, C.c_int, C.c_int, F32P, F32P, F32P, F32P,
                                  C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_uint64, C.POINTER(OraInject), C.POINTER(OraTrajOut)]
+        L.ora_sample_many.argtypes = [C.POINTER(OraHParams), F32P, C.c_int, C.c_int, F32P, F32P, F32P, F32P,
+                                      C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                      F32P, C.POINTER(C.c_int64), I32P, F32P]
         L.ora_modify_coords_all_atom.argtypes = [F32P, C.c_int, F32P, F32P]
         L.ora_modify_coords_all_atom.restype = None
         L.ora_set_num_threads.argtypes = [C.c_int]
@@ -126,6 +129,7 @@ class Oracle:
         out = OraScoreOut()
         d = {}
         dbg = None
+        bins_in = None if bins is None else np.ascontiguousarray(bins, dtype=np.int8).reshape(N, K, 4)
         if debug:
             d = dict(f=np.zeros((L, 3), np.float32), pos_out=np.zeros((N, 3), np.float32),
                      h_layers=np.zeros((self.hp.depth, N, H), np.float32), bins=np.zeros((N, K, 4), np.int8),
@@ -133,10 +137,11 @@ class Oracle:
                      ires=np.zeros((N,), np.float32))
             if dist and self.hp.family == 1:
                 d["dist_logits"] = np.zeros((self.R, L, 64), np.float32)
-            bins_in = None if bins is None else np.ascontiguousarray(bins, dtype=np.int8).reshape(N, K, 4)
             dbg = OraDebug(_p(d["f"]), _p(d["pos_out"]), _p(d["h_layers"]), _p(d["bins"], I8P),
                            _p(d["relpos"], I8P), _p(d["edges"], I32P), _p(d["ires"]), _p(d.get("dist_logits")),
                            _p(bins_in, I8P))
+        elif bins_in is not None:      # the bins override applies without the debug outputs too
+            dbg = OraDebug(None, None, None, None, None, None, None, None, _p(bins_in, I8P))
         e = None if edges is None else np.ascontiguousarray(edges, dtype=np.int32)
         if e is not None:
             assert e.shape == (N, K), (e.shape, N, K)
@@ -179,6 +184,20 @@ class Oracle:
         return dict(lig_pos=lig, rot_update=np.array(out.rot_update, np.float32)[None],
                     tr_update=np.array(out.tr_update, np.float32)[None], energy=np.float32(out.energy),
                     num_clashes=int(out.num_clashes), trace_pose=tp, trace_scores=tsc, init_pose=ip, forwards=nf)
+
+
+    def sample_many(self, n_traj, num_steps=40, eps=1e-3, tr_noise_scale=0.5, rot_noise_scale=0.5, max_forwards=0, seed=0, n_threads=0):
+        """n_traj independent trajectories (seeds seed .. seed + n_traj - 1), one single-threaded trajectory per OpenMP thread
+        (ora_sample_many): the trajectory-parallel CPU form of inference_base.py:644-657."""
+        en = np.zeros(n_traj, np.float32)
+        cl = np.zeros(n_traj, np.int64)
+        fw = np.zeros(n_traj, np.int32)
+        up = np.zeros((n_traj, 6), np.float32)
+        tot = lib().ora_sample_many(C.byref(self.hp), _p(self.blob), self.R, self.L, _p(self.rec_x), _p(self.lig_x),
+                                    _p(self.rec_pos), _p(self.lig_pos), int(num_steps), float(eps), float(tr_noise_scale),
+                                    float(rot_noise_scale), int(max_forwards), int(seed), int(n_traj), int(n_threads),
+                                    _p(en), cl.ctypes.data_as(C.POINTER(C.c_int64)), _p(fw, I32P), _p(up))
+        return dict(energy=en, num_clashes=cl, forwards=fw, total_forwards=int(tot), rot_update=up[:, :3], tr_update=up[:, 3:])
 
 
 # ---------------------------------------------------------------------------

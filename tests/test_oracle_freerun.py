@@ -48,3 +48,21 @@ def test_oracle_free_runs_match_the_reference_distribution():
     pp = ((mine["energy"] == 0).sum() + (ref["energy"] == 0).sum()) / (mine["energy"].size + ref["energy"].size)
     z = (a - b) / max(np.sqrt(pp * (1 - pp) * (1 / mine["energy"].size + 1 / ref["energy"].size)), 1e-12)
     assert abs(z) < 4.0, (a, b, z)
+
+
+def test_sample_many_equals_sequential_trajectories():
+    """ora_sample_many (bench.py's trajectory-parallel CPU baseline: one single-threaded trajectory per OpenMP thread) is the same
+    computation as ora_sample called once per seed (inference_base.py:644-657 runs the trajectories one after the other)."""
+    from dfmdock_amd.synthetic import make_complex
+    from dfmdock_amd.weights import make_random_weights, pack_blob
+    from oracle import oracle as ora
+    o = ora.Oracle(pack_blob(make_random_weights(0)), make_complex(24, 16, seed=5))
+    many = o.sample_many(6, num_steps=5, seed=900, n_threads=3)
+    assert many["total_forwards"] == 6 * 6 and (many["forwards"] == 6).all()
+    for k in range(6):
+        one = o.sample(num_steps=5, seed=900 + k)
+        assert np.array_equal(many["tr_update"][k], one["tr_update"][0]) and np.array_equal(many["rot_update"][k], one["rot_update"][0])
+        assert many["energy"][k] == one["energy"] and many["num_clashes"][k] == one["num_clashes"]
+    assert np.linalg.norm(many["tr_update"][0] - many["tr_update"][1]) > 1.0      # different seeds: different trajectories
+    part = o.sample_many(4, num_steps=5, max_forwards=2, seed=900)                # the bounded sample bench.py times
+    assert (part["forwards"] == 2).all()
