@@ -217,6 +217,49 @@ def c4_line(engine, model, precision, num_steps):
     return out
 
 
+def c4_sharded_line(model, precision, num_steps, rank, world, backend):
+    """BASELINE config 4 as it is DEFINED: the 24 DB5-sized complexes x 40 trajectories sharded over the ranks of this job (one
+    process per GPU) with one gather of the ranked energy records (the loop it replaces: src/inference_mlsb.py:415-439 over
+    src/inference_base.py:561-580).  driver.run_set assigns whole complexes longest-first on the measured cost model
+    (distributed.complex_cost; 3 per rank at 8 ranks).  wall_s = max over ranks of the time between two barriers around run_set
+    (handle creation, self-check, sampling, metrics, record + row gathers, CSV on rank 0); per_rank_makespan_s = each rank's own
+    time to the end of its share.  A record, not a scaling claim."""
+    import tempfile
+    from dfmdock_amd import distributed as D
+    from dfmdock_amd import driver
+    from dfmdock_amd.synthetic import make_complex
+    import torch
+    cxs = []
+    for k, (R, L) in enumerate(DB5_SIZES):
+        c = make_complex(R, L, seed=300 + k)
+        c["id"] = f"S{k:02d}_{R}_{L}"
+        cxs.append(c)
+    tmp = tempfile.mkdtemp(prefix=f"dfm_c4s_{rank}_")
+    quiet = lambda m: None
+    driver.run_set(model, cxs[:2], num_samples=max(8, world), num_steps=2, seed=0, precision=precision, log=quiet, canary=False)      # warm-up (collectives included)
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tim, can = [], {}
+    rows, ranked = driver.run_set(model, cxs, num_samples=40, num_steps=num_steps, seed=0, precision=precision,
+                                  out_csv=os.path.join(tmp, "c4.csv"), timings_out=tim, log=quiet, canary_out=can)
+    mine = time.perf_counter() - t0
+    D.barrier(); torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    per_rank = D.allgather_scalars([mine, float(len(tim)), float(len(rows))])
+    n_rec = int(sum(len(v) for v in ranked.values()))
+    ids = {(int(cid), int(r[1])) for cid, v in ranked.items() for r in v}
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    costs = [D.complex_cost(R + L, 40) for R, L in DB5_SIZES]
+    assign = D.assign_work(costs, world)
+    return {"workload": f"C4: 24 complexes with the DB5 test set's sizes (synthetic chains and features) x 40 trajectories x {num_steps} steps, "
+                        f"sharded over {world} ranks by driver.run_set, one gather of the ranked energy records",
+            "wall_s": wall, "value": n_rec / wall, "unit": "trajectories/s", "per_rank_makespan_s": [float(x) for x in per_rank[:, 0]],
+            "complexes_per_rank": [int(x) for x in per_rank[:, 1]], "rows_per_rank": [int(x) for x in per_rank[:, 2]],
+            "predicted_makespan_ms": D.makespan(costs, assign), "backend": backend, "records_in_gather": n_rec,
+            "distinct_record_ids": len(ids), "complexes_in_gather": len(ranked), "canary": can or None}
+
+
 # reference-equivalent work of one score evaluation per residue (SURVEY.md 8d: the reference's dense formulation, all six layers in full)
 FLOP_PER_NODE_EVAL = 59.2e6
 
@@ -354,6 +397,10 @@ def main():
     elapsed = time.perf_counter() - t0
     per_rank = D.allgather_scalars([elapsed, float(dev)])      # max over ranks of the time; which device every rank ran on
     elapsed = float(per_rank[:, 0].max())
+    headline = (args.R, args.L, args.batch, args.num_steps) == (300, 300, 256, 40)
+    c4s = None
+    if world > 1 and headline and not args.no_c4_line:      # every rank takes part (outside the timed C3 region)
+        c4s = c4_sharded_line(model, args.precision, args.num_steps, rank, world, grp.backend)
     fp32_line = None
     if rank == 0 and world == 1 and mfma16 and not args.no_fp32_line:
         # secondary record: the fp32 engine - the reference's own arithmetic - on the same workload, one batched call
@@ -475,11 +522,12 @@ def main():
                                    "gather_tbps": 512 * l0["l0_edges"] / max(l0["l0_gather_ms"], 1e-9) / 1e9,
                                    "note": "per evaluation: k_edge_msg<1,1,1> over the row list (inter-chain edges + bin mismatches) and "
                                            "k_l0_gather (K rows of 512 B per node, out of L2 / the Infinity Cache) replace one full message launch"}
-        headline = (args.R, args.L, args.batch, args.num_steps) == (300, 300, 256, 40)
         if world == 1 and mfma16 and headline and not args.no_c5_line:
             out["c5"] = c5_line(engine, model, pk, args.num_steps)
         if world == 1 and headline and not args.no_c4_line:
             out["c4"] = c4_line(engine, model, args.precision, args.num_steps)
+        if world > 1 and headline and not args.no_c4_line:
+            out["c4_sharded"] = c4s      # measured by every rank below the timed C3 region (collectives inside), reported by rank 0
         if not args.no_cpu_baseline and world == 1:     # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(blob, cx, args.num_steps)
         print(json.dumps(out), flush=True)

@@ -1272,6 +1272,7 @@ static int finish_profile(dfm_complex *cx)
         cx->prof.l0_miss_rows = (int64_t)tot;
     }
 #ifdef DFM_EDGE_TRACE      // diagnostic build: raw wave timelines of workgroup 0 -> $DFM_EDGE_TRACE_FILE (tools/edge_trace.py)
+    fprintf(stderr, "[DFM_EDGE_TRACE] finish_profile: stamp_dev %p file %s\n", (void *)cx->stamp_dev, getenv("DFM_EDGE_TRACE_FILE") ? getenv("DFM_EDGE_TRACE_FILE") : "(unset)");
     if (cx->stamp_dev && getenv("DFM_EDGE_TRACE_FILE")) {
         static unsigned long long tr[8 * 130];
         HIPCHK(hipMemcpyAsync(tr, cx->stamp_dev + 48, sizeof(tr), hipMemcpyDeviceToHost, cx->stream));

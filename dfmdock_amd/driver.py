@@ -71,7 +71,7 @@ def checked_precision(gx: engine.Complex, precision: str, name: str, selfcheck=T
 
 class _Prepared:
     """One complex ready to sample: its handle, the pose it was created on and everything derived from that pose alone."""
-    __slots__ = ("ci", "c", "gx", "rec_pos", "lig_pos", "native", "precision", "check", "ms")
+    __slots__ = ("ci", "c", "gx", "N", "rec_pos", "lig_pos", "native", "precision", "check", "ms")
 
 
 def _prepare(model, c, ci, rot_seed, global_rotation, precision, selfcheck, on_selfcheck_fail, seed, log=None) -> _Prepared:
@@ -85,30 +85,36 @@ def _prepare(model, c, ci, rot_seed, global_rotation, precision, selfcheck, on_s
         rec_pos, lig_pos = random_rotation(rec_pos, lig_pos, np.random.default_rng(rot_seed))
     p.rec_pos, p.lig_pos = rec_pos, lig_pos
     p.gx = engine.Complex(model, c["rec_x"], c["lig_x"], rec_pos, lig_pos)
+    p.N = p.gx.N
     p.native = NativeContext((rec_pos, lig_pos))
     p.precision, p.check = checked_precision(p.gx, precision, str(c.get("id", ci)), selfcheck, on_selfcheck_fail, log=log, seed=seed)
     p.ms = {"prepare": (time.perf_counter() - t0) * 1e3}
     return p
 
 
-def _sample(p: _Prepared, t_lo, t_hi, num_steps, seed, max_batch, trace, sampler_kw):
-    """Stage 2: the trajectories of this rank's share, in batches of at most max_batch."""
+def _sample(p: _Prepared, t_lo, t_hi, num_steps, seed, max_batch, trace, sampler_kw, keep_open=False):
+    """Stage 2: the trajectories of this rank's share, in batches of at most max_batch.  The results are host arrays, so the
+    handle (and its ~GB of device workspace) is released HERE, not after the host-side stage 3: however far the metrics /
+    trajectory-PDB stage falls behind, the live handles are bounded by the prepare gate + the samplers."""
     import time
     t0 = time.perf_counter()
     batches, done = [], t_lo
-    while done < t_hi:
-        b = min(max_batch, t_hi - done)
-        r = p.gx.sample(B=b, num_steps=num_steps, seed=seed * 100003 + p.ci * 1009 + done, trace=trace,
-                        **engine.precision_kwargs(p.precision), **sampler_kw)
-        batches.append((done, b, r))
-        done += b
+    try:
+        while done < t_hi:
+            b = min(max_batch, t_hi - done)
+            r = p.gx.sample(B=b, num_steps=num_steps, seed=seed * 100003 + p.ci * 1009 + done, trace=trace,
+                            **engine.precision_kwargs(p.precision), **sampler_kw)
+            batches.append((done, b, r))
+            done += b
+    finally:
+        if not keep_open:
+            p.gx.close()
     p.ms["sample"] = (time.perf_counter() - t0) * 1e3
     return batches
 
 
 def _post(p: _Prepared, batches, traj_dir):
-    """Stage 3 (host): per-trajectory metrics against the native pose (inference_mlsb.py:232-262), trajectory PDBs, records;
-    releases the handle."""
+    """Stage 3 (host only): per-trajectory metrics against the native pose (inference_mlsb.py:232-262), trajectory PDBs, records."""
     import time
     t0 = time.perf_counter()
     c, rows, records = p.c, [], []
@@ -123,14 +129,13 @@ def _post(p: _Prepared, batches, traj_dir):
                 pdbio.write_trajectory_pdb(os.path.join(traj_dir, f"{c.get('id', p.ci)}_p{done + k}.pdb"),
                                            [p.rec_pos] * len(frames), frames, c["rec_seq"], c["lig_seq"])
         records.append(D.make_records(p.ci, np.arange(done, done + b), r))
-    p.gx.close()
     p.ms["post"] = (time.perf_counter() - t0) * 1e3
     return rows, records
 
 
 def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0, precision="mfma16", global_rotation=True,
             out_csv=None, traj_dir=None, max_batch=256, selfcheck=True, on_selfcheck_fail="fp32", checks_out=None,
-            overlap=True, samplers=2, timings_out=None, log=None, **sampler_kw):
+            overlap=True, samplers=2, timings_out=None, log=None, canary=True, canary_out=None, **sampler_kw):
     """Sample `num_samples` trajectories for every complex dict (id, rec_x, lig_x, rec_pos, lig_pos[, rec_seq, lig_seq]);
     returns the metric rows of this rank's share; rank 0 writes the gathered CSV when `out_csv` is given.  Every complex is
     self-checked first (checked_precision); `checks_out` (a list) collects {id, precision used, check dict}.
@@ -142,7 +147,13 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
     complex does not fill 256 CUs; measured +4 ... +8 % over one sampler on the C4 set, profiles/r05_c4.txt; 3 buys nothing more).  Results do not depend on any of this: a trajectory is a pure function of (seed, complex,
     trajectory index), so the rows equal the serial driver's (`overlap=False`) bit for bit.  `timings_out` (a list) collects
     per-complex {id, N, prepare, sample, post} milliseconds; `log` receives the self-check lines
-    (default: stderr)."""
+    (default: stderr).
+
+    `canary` (overlapped driver only): r05 found - and fenced, without naming the mechanism - a silent miscompute between two handles
+    running at once (profiles/r05_concurrency.txt; tests/test_gpu_concurrency.py holds the shipped build to 0 deviations).  As a
+    run-time tripwire on whatever box / ROCm this runs on, the cheapest complex that sampled with others in flight is sampled AGAIN
+    after the pipeline has drained, alone, and compared bit for bit; on a mismatch the whole share is re-run by the serial driver and
+    those rows are returned (`canary_out`, a dict, receives {checked, id, ok, reran_serial})."""
     rank, _, world = D.dist_env()
     complexes = list(complexes)
     split_trajectories = world > 1 and len(complexes) < 2 * world
@@ -189,8 +200,15 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
             ahead.release()
             return p, samp(p)
 
+        # the canary complex: cheapest of those that are neither first nor last of the share (so something else was always in flight)
+        inner = share[1:-1] if len(share) > 2 else share[-1:]
+        canary_ci = min(inner, key=lambda ci: complexes[ci]["rec_x"].shape[0] + complexes[ci]["lig_x"].shape[0]) if canary else None
+        canary_ref = {}
+
         def post_of(fs):
             p, batches = fs.result()
+            if p.ci == canary_ci:
+                canary_ref["batches"], canary_ref["precision"] = batches, p.precision
             rows_c, recs_c = _post(p, batches, traj_dir)
             return p, rows_c, recs_c
 
@@ -208,6 +226,27 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
                 for _ in share:      # un-block a prepare stage parked on the gate
                     ahead.release()
                 raise
+        if canary_ci is not None and "batches" in canary_ref:
+            again = _prepare(model, complexes[canary_ci], canary_ci, rots[canary_ci], global_rotation, canary_ref["precision"], False,
+                             on_selfcheck_fail, seed, log)
+            solo = samp(again)
+            same = len(solo) == len(canary_ref["batches"]) and all(
+                all(np.array_equal(ra[k], rb[k]) for k in ("lig_pos", "energy", "num_clashes", "rot_update", "tr_update"))
+                for (_, _, ra), (_, _, rb) in zip(solo, canary_ref["batches"]))
+            info = {"checked": True, "id": complexes[canary_ci].get("id", str(canary_ci)), "ok": bool(same), "reran_serial": False}
+            if not same:
+                import sys
+                (log or (lambda m: print(m, file=sys.stderr, flush=True)))(
+                    f"run_set canary: complex {info['id']} sampled next to other handles differs from the same complex sampled alone - "
+                    "concurrent handles are NOT independent on this system; re-running this rank's share serially")
+                done = []
+                for ci in share:
+                    p = prep(ci)
+                    rows_c, recs_c = _post(p, samp(p), traj_dir)
+                    done.append((p, rows_c, recs_c))
+                info["reran_serial"] = True
+            if canary_out is not None:
+                canary_out.update(info)
     rows, records = [], []
     for p, rows_c, recs_c in done:
         rows += rows_c
@@ -215,7 +254,7 @@ def run_set(model: engine.Model, complexes, num_samples=40, num_steps=40, seed=0
         if checks_out is not None:
             checks_out.append({"id": p.c.get("id", str(p.ci)), "precision": p.precision, "selfcheck": p.check})
         if timings_out is not None:
-            timings_out.append({"id": p.c.get("id", str(p.ci)), "N": p.gx.N, **p.ms})
+            timings_out.append({"id": p.c.get("id", str(p.ci)), "N": p.N, **p.ms})
     recs = np.concatenate(records, 0) if records else np.zeros((0, D.RECORD_WIDTH), np.float32)
     ranked = D.rank_by_energy(D.gather_records(recs)) if world > 1 or len(recs) else {}
     if out_csv is not None:

@@ -213,3 +213,59 @@ def test_bench_eight_ranks_oversubscribed_on_one_gpu():
         assert out["backend"] != "nccl" and out["backend_fallback"]
     assert abs(out["value"] - 8 * 8 * 1 / (out["ms_per_step"] / 1e3)) < 1e-6 * out["value"]
     assert "c4" not in out and "c5" not in out and "cpu_baseline" not in out      # secondary records: rank 0 at N = 1 only
+
+
+def test_bench_c4_sharded_record_on_two_ranks(tmp_path):
+    """BASELINE config 4 is DEFINED as a sharded run (24 DB5-sized complexes x 40 trajectories over the ranks of one node, one gather
+    of the ranked energy records; the loop it replaces: src/inference_mlsb.py:415-439).  `bench.py --gpus N` puts it on the line as
+    `c4_sharded`.  Two ranks on the one GPU of the test box: 960 records with 960 distinct (complex,
+    trajectory) ids reach every rank, both ranks took complexes, and the sharded CSV is byte-identical to the one-rank CSV of the
+    same call (a trajectory is a pure function of seed, complex and index)."""
+    env = dict(os.environ, DFM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    c4 = out["c4_sharded"]
+    assert out["n_gpus"] == 2 and out["config"]["workload"].startswith("C3") and "c4" not in out
+    assert c4["records_in_gather"] == 960 and c4["distinct_record_ids"] == 960 and c4["complexes_in_gather"] == 24
+    assert sum(c4["complexes_per_rank"]) == 24 and min(c4["complexes_per_rank"]) >= 8 and sum(c4["rows_per_rank"]) == 960
+    assert len(c4["per_rank_makespan_s"]) == 2 and c4["wall_s"] >= max(c4["per_rank_makespan_s"]) > 0
+    assert c4["canary"]["ok"] is True and c4["backend"] in ("gloo", "nccl", "file")
+
+    # the same set through run_set on 2 ranks and on 1 rank: byte-identical CSV
+    worker = tmp_path / "c4_worker.py"
+    worker.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        from dfmdock_amd import distributed as D, driver, engine
+        from dfmdock_amd.synthetic import make_complex
+        from dfmdock_amd.weights import make_random_weights, pack_blob
+        rank, local, world = D.dist_env()
+        grp = D.init(device_index=0)
+        engine.set_device(0)
+        model = engine.Model(pack_blob(make_random_weights(0)))
+        cxs = []
+        for k, (R, L) in enumerate(bench.DB5_SIZES):
+            c = make_complex(R, L, seed=300 + k); c["id"] = f"S{{k:02d}}_{{R}}_{{L}}"; cxs.append(c)
+        rows, ranked = driver.run_set(model, cxs, num_samples=40, num_steps=10, seed=0, out_csv=os.path.join({str(tmp_path)!r}, f"c4_w{{world}}.csv"),
+                                      log=lambda m: None)
+        assert sum(len(v) for v in ranked.values()) == 960
+        D.shutdown()
+    """))
+    port = _port() + 7
+    for world in (1, 2):
+        procs = []
+        for r in range(world):
+            e2 = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port + world),
+                      DFM_GATHER_DIR=str(tmp_path))
+            procs.append(subprocess.Popen([sys.executable, str(worker)], env=e2, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [q.communicate(timeout=900)[0].decode() for q in procs]
+        assert all(q.returncode == 0 for q in procs), "\n".join(o[-3000:] for o in outs)
+    a, b = open(tmp_path / "c4_w1.csv", "rb").read(), open(tmp_path / "c4_w2.csv", "rb").read()
+    assert a == b and a.count(b"\n") == 961

@@ -412,18 +412,25 @@ def test_run_set_pipeline_stages_overlap_and_fail_cleanly(monkeypatch):
             live["max_prepared"] = max(live["max_prepared"], live["prepared"])
         time.sleep(0.03)
         p = P(); p.ci, p.c, p.precision, p.check, p.ms = ci, c, precision, None, {"prepare": 30.0}
-        p.gx = type("G", (), {"N": c["rec_x"].shape[0] + c["lig_x"].shape[0]})()
+        p.N = c["rec_x"].shape[0] + c["lig_x"].shape[0]
         return p
+
+    calls = {}
 
     def samp(p, t_lo, t_hi, num_steps, seed, max_batch, trace, kw):
         with lock:
             live["prepared"] -= 1
             log.append(("sample", p.ci))
+            calls[p.ci] = calls.get(p.ci, 0) + 1
+            nth = calls[p.ci]
         if p.c.get("boom") == "sample":
             raise RuntimeError("sampling failed")
         time.sleep(0.06)
         p.ms["sample"] = 60.0
-        return [(t_lo, t_hi - t_lo, None)]
+        # results as the engine returns them; a complex marked "flaky" gives a different answer the first time it is sampled (= next to others)
+        val = float(p.ci) + (0.5 if (p.c.get("flaky") and nth == 1) else 0.0)
+        r = {k: np.full((t_hi - t_lo, 1), val, np.float32) for k in ("lig_pos", "energy", "num_clashes", "rot_update", "tr_update")}
+        return [(t_lo, t_hi - t_lo, r)]
 
     def post(p, batches, traj_dir):
         if p.c.get("boom") == "post":
@@ -440,7 +447,7 @@ def test_run_set_pipeline_stages_overlap_and_fail_cleanly(monkeypatch):
         log.clear(); live.update(prepared=0, max_prepared=0)
         tim = []
         t0 = time.perf_counter()
-        rows, ranked = driver.run_set(None, cxs, num_samples=3, overlap=True, samplers=samplers, timings_out=tim)
+        rows, ranked = driver.run_set(None, cxs, num_samples=3, overlap=True, samplers=samplers, timings_out=tim, canary=False)
         dt = time.perf_counter() - t0
         order = [c["id"] for c in sorted(cxs, key=lambda c: -c["rec_x"].shape[0])]      # one rank: longest first
         assert [r["id"] for r in rows] == [i for i in order for _ in range(3)] and ranked == {}
@@ -457,3 +464,13 @@ def test_run_set_pipeline_stages_overlap_and_fail_cleanly(monkeypatch):
         with pytest.raises(RuntimeError, match=where[:4]):
             driver.run_set(None, bad, num_samples=3, overlap=True)
         assert time.perf_counter() - t0 < 5.0
+    # the canary (default on): the cheapest complex that sampled with others in flight is sampled again, alone, and compared bit for bit
+    calls.clear(); can = {}
+    rows_c, _ = driver.run_set(None, cxs, num_samples=3, overlap=True, canary_out=can)
+    assert rows_c == rows and can == {"checked": True, "id": "C1", "ok": True, "reran_serial": False} and calls[1] == 2 and calls[0] == 1
+    flaky = [dict(c) for c in cxs]
+    flaky[1]["flaky"] = True                                              # C1 is the canary: its pipelined result will not reproduce
+    calls.clear(); can = {}; msgs = []
+    rows_f, _ = driver.run_set(None, flaky, num_samples=3, overlap=True, canary_out=can, log=msgs.append)
+    assert can["ok"] is False and can["reran_serial"] is True and rows_f == rows
+    assert any("canary" in m for m in msgs) and all(calls[k] >= 2 for k in range(8))      # every complex was sampled again, serially
