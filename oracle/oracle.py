@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdfm_oracle.so")
+_LIB_PATH = os.environ.get("DFM_ORACLE_LIB") or os.path.join(_HERE, "libdfm_oracle.so")      # DFM_ORACLE_LIB: a sanitizer build (oracle/Makefile: asan)
 
 F32P = C.POINTER(C.c_float)
 I32P = C.POINTER(C.c_int32)
@@ -52,7 +52,7 @@ def build(force: bool = False) -> str:
     """(Re)build the oracle library; `make` decides whether anything is stale."""
     if force and os.path.exists(_LIB_PATH):
         os.remove(_LIB_PATH)
-    if os.path.exists(os.path.join(_HERE, "dfm_oracle.c")):
+    if os.path.exists(os.path.join(_HERE, "dfm_oracle.c")) and not os.environ.get("DFM_ORACLE_LIB"):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     if not os.path.exists(_LIB_PATH):
         raise RuntimeError("oracle library missing: run `make -C oracle`")

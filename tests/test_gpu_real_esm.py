@@ -102,6 +102,33 @@ def test_rollout_vs_reference(cid, prec, table, model):
     gx.close()
 
 
+def test_c2_named_pair_1avx_batch64(model):
+    """BASELINE config 2 on the pair SURVEY 8(d) names: DB5 1AVX (223+172) with its real ESM-2 block, 64 parallel trajectories, the
+    16-bit engine as dfm_sample runs it (layer 0 through the message table, ligand-only last layer).  The reference run's draws
+    (rollout_esm_1AVX.npz: src/inference_base.py:390-468 with every draw recorded) tiled 64x: every row bitwise equal to the B = 1
+    row, within the 16-bit rollout gate (0.5 A) of the reference's poses, the table path taken in all S + 1 evaluations; then a native
+    B = 64 x 40-step run: finite, seed-reproducible, independent of the batch it is sampled in."""
+    g = load_golden("rollout_esm_1AVX.npz")
+    gx, _ = _gx(model, "1AVX")
+    S, B = int(g["num_steps"]), 64
+    one = dict(R0=g["R0"].astype(np.float32).reshape(1, 9), tr_draw=g["tr_draw"].reshape(1, 3), z_rot=g["z_rot"].reshape(1, S, 3),
+               z_tr=g["z_tr"].reshape(1, S, 3), edges=g["edges"].astype(np.int32)[None])
+    many = {k: np.ascontiguousarray(np.repeat(v, B, 0)) for k, v in one.items()}
+    r1 = gx.sample(B=1, num_steps=S, inject=one, trace=True, mfma16=True, l0_table=True)
+    rb = gx.sample(B=B, num_steps=S, inject=many, trace=True, mfma16=True, l0_table=True, profile=True)
+    assert gx.profile()["l0_evals"] == S + 1 == 6
+    for k in ("lig_pos", "trace_pose", "trace_scores", "energy", "rot_update", "tr_update", "num_clashes"):
+        assert (rb[k] == r1[k][0]).all(), k
+    rmsd = np.sqrt(((rb["trace_pose"][37][:, :, 1] - g["poses"][:, :, 1]) ** 2).sum(-1).mean(-1))
+    assert rmsd.max() < 0.5, rmsd
+    nat = gx.sample(B=B, num_steps=40, seed=42, mfma16=True)
+    assert np.isfinite(nat["lig_pos"]).all() and np.isfinite(nat["energy"]).all()
+    assert np.abs(nat["lig_pos"][0] - nat["lig_pos"][1]).max() > 1.0
+    np.testing.assert_array_equal(nat["lig_pos"], gx.sample(B=B, num_steps=40, seed=42, mfma16=True)["lig_pos"])
+    np.testing.assert_array_equal(nat["lig_pos"][:16], gx.sample(B=16, num_steps=40, seed=42, mfma16=True)["lig_pos"])
+    gx.close()
+
+
 @pytest.mark.parametrize("cid", IDS)
 def test_pair_family_on_real_features(cid, blob_pair):
     """Second model family (DFMDock.forward, src/models/DFMDock.py:68-75 -> src/models/egnn_net.py:408-505) on the same real
