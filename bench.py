@@ -52,7 +52,7 @@ def cpu_baseline(blob, cx, num_steps, repeats=2):
 
     value = TRAJECTORY-PARALLEL throughput on ALL host cores: the metric is trajectories/s and trajectories are
     independent until the final arg-min (inference_base.py:644-657), so the honest all-cores CPU figure is one single-threaded
-    trajectory per core (ora_sample_many), not one evaluation spread over the cores.  Sample: host_cores trajectories x 3 score
+    trajectory per core (ora_sample_many), not one evaluation spread over the cores.  Sample: host_cores trajectories x 2 score
     evaluations each after one untimed evaluation per trajectory, extrapolated to the 41 evaluations of a trajectory.  The
     intra-evaluation OpenMP numbers of r01-r05 (which peak near 32 threads and fall at 128) stay under by_mode for comparison."""
     import statistics
@@ -60,7 +60,7 @@ def cpu_baseline(blob, cx, num_steps, repeats=2):
     L = ora.lib()
     o = ora.Oracle(blob, cx)
     all_cores = int(L.ora_num_threads())
-    n_eval = 3
+    n_eval = 2
     o.sample_many(all_cores, num_steps=num_steps, max_forwards=1, seed=1, n_threads=all_cores)      # warm-up: pages, thread pool
     t0 = time.perf_counter()
     res = o.sample_many(all_cores, num_steps=num_steps, max_forwards=n_eval, seed=2, n_threads=all_cores)

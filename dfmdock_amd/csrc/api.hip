@@ -716,7 +716,7 @@ extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, con
     ok = ok && P.alloc(&cx->Bm0, (size_t)N * H) == hipSuccess && P.alloc(&cx->Bmb0, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->A0s, (size_t)N * H) == hipSuccess;
     ok = ok && P.alloc(&cx->A0h, (size_t)N * H) == hipSuccess;
-#ifdef DFM_EDGE_STAMP
+#if defined(DFM_EDGE_STAMP) || defined(DFM_EDGE_TRACE)
     ok = ok && P.alloc(&cx->stamp_dev, 48 + 8 * 130) == hipSuccess && hipMemsetAsync(cx->stamp_dev, 0, (48 + 8 * 130) * 8, cx->stream) == hipSuccess;
 #endif
     if (ok) {
@@ -1272,7 +1272,6 @@ static int finish_profile(dfm_complex *cx)
         cx->prof.l0_miss_rows = (int64_t)tot;
     }
 #ifdef DFM_EDGE_TRACE      // diagnostic build: raw wave timelines of workgroup 0 -> $DFM_EDGE_TRACE_FILE (tools/edge_trace.py)
-    fprintf(stderr, "[DFM_EDGE_TRACE] finish_profile: stamp_dev %p file %s\n", (void *)cx->stamp_dev, getenv("DFM_EDGE_TRACE_FILE") ? getenv("DFM_EDGE_TRACE_FILE") : "(unset)");
     if (cx->stamp_dev && getenv("DFM_EDGE_TRACE_FILE")) {
         static unsigned long long tr[8 * 130];
         HIPCHK(hipMemcpyAsync(tr, cx->stamp_dev + 48, sizeof(tr), hipMemcpyDeviceToHost, cx->stream));

@@ -16,6 +16,7 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#include <malloc.h>
 #endif
 
 /* ------------------------------------------------------------------------- */
@@ -1051,6 +1052,13 @@ int ora_sample_many(const ora_hparams *hp, const float *blob, int R, int L, cons
     if (n_threads > n_traj) n_threads = n_traj;
     const int levels = omp_get_max_active_levels();
     omp_set_max_active_levels(1);      /* the evaluations' own parallel regions stay on the trajectory's thread */
+#ifdef __GLIBC__
+    /* every evaluation allocates and frees megabyte-sized temporaries: by default glibc serves those with mmap / munmap, and a
+     * hundred threads of ONE process then queue on the address-space lock and re-fault their pages each time.  Keep them in the
+     * per-thread arenas instead (first touch only). */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+#endif
     int total = 0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : total)
     for (int k = 0; k < n_traj; ++k) {

@@ -140,3 +140,53 @@ def test_no_kernel_uses_scratch():
         assert not bad, bad
     finally:
         shutil.rmtree(td, ignore_errors=True)
+
+
+def test_no_compiler_made_packed_fp32_in_geometry_and_head_kernels():
+    """r05: hipcc's SLP vectoriser turned the dihedral code of k_edge_feat<0> into packed-fp32 instructions (v_pk_mul_f32 /
+    v_pk_add_f32 with SGPR-pair operands and op_sel), and waves of that kernel then computed WRONG theta bins from correct inputs
+    whenever another complex handle's message kernel was resident - never with the -O1 / -fno-slp-vectorize builds of the same source
+    (profiles/r05_concurrency.txt; reference arithmetic: src/utils/coords6d.py:25-43).  The mechanism is not identified, so the whole
+    library is built with -fno-slp-vectorize (csrc/Makefile) and this test keeps compiler-made packed fp32 out of every kernel of
+    kernels_geom.hip and kernels_heads.hip - the parity-sensitive fp32 code that never writes float2 arithmetic itself.  (The packed
+    fp32 of the message / GEMM / pair kernels is hand-written vector code and has run next to itself since r01.)"""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from dfmdock_amd import _lib
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(tools, "llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    names = set()
+    for src in ("kernels_geom.hip", "kernels_heads.hip"):
+        txt = open(os.path.join(ROOT, "dfmdock_amd", "csrc", src)).read()
+        names |= set(re.findall(r"__global__[^;{]*?\bvoid\s+(k_\w+)\s*\(", txt))
+    assert {"k_edge_feat", "k_knn_sample", "k_prep_pose", "k_heads", "k_init_pose"} <= names, names
+    mk = open(os.path.join(ROOT, "dfmdock_amd", "csrc", "Makefile")).read()
+    assert re.search(r"^COMMON\s*:=.*-fno-slp-vectorize", mk, re.M), "csrc/Makefile: every translation unit is built without SLP vectorisation"
+    td = tempfile.mkdtemp()
+    try:
+        lib = os.path.join(td, "lib.so")
+        shutil.copy(_lib.LIB_PATH, lib)
+        subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", lib], cwd=td, check=True, capture_output=True)
+        seen, bad = set(), {}
+        for f in sorted(os.listdir(td)):
+            if "gfx950" not in f:
+                continue
+            asm = subprocess.run([os.path.join(tools, "llvm-objdump"), "-d", os.path.join(td, f)], capture_output=True, text=True).stdout
+            cur = None
+            for line in asm.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    hit = [n for n in names if re.search(r"\d+" + n + r"(I|E|P|N|\b)", m.group(1))]
+                    cur = m.group(1) if hit else None
+                    if cur:
+                        seen.add(hit[0])
+                    continue
+                if cur and re.search(r"\bv_pk_(mul|add|fma)_f32\b", line):
+                    bad[cur] = bad.get(cur, 0) + 1
+        assert {"k_edge_feat", "k_knn_sample", "k_prep_pose", "k_heads"} <= seen, seen
+        assert not bad, bad
+    finally:
+        shutil.rmtree(td, ignore_errors=True)

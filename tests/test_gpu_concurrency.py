@@ -62,7 +62,7 @@ def _aggressors(h):
 
     def create_close():
         g = engine.Complex(model, cb["rec_x"], cb["lig_x"], cb["rec_pos"], cb["lig_pos"])
-        g.sample(B=8, num_steps=1, seed=1, mfma16=True)      # builds the layer-0 table on the new handle's stream
+        g.sample(B=8, num_steps=2, seed=1, mfma16=True)      # builds the layer-0 table on the new handle's stream
         g.close()
 
     return {

@@ -5,7 +5,7 @@
 set -e
 NAME=$1; EXTRA=$2
 ROOT=$(cd $(dirname $0)/.. && pwd); SRC=$ROOT/dfmdock_amd/csrc; OBJ=/tmp/dfm_ev_$NAME; mkdir -p $OBJ $ROOT/tools/variants
-COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $EXTRA"
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize $EXTRA"
 hipcc $COMMON -c $SRC/kernels_edge.hip -o $OBJ/kernels_edge.o
 API=$SRC/api.o
 case "$EXTRA" in *TRACE*|*STAMP*) hipcc $COMMON -c $SRC/api.hip -o $OBJ/api.o; API=$OBJ/api.o;; esac
