@@ -325,7 +325,8 @@ def main():
     ap.add_argument("--num-steps", type=int, default=40, help="diffusion steps per trajectory")
     ap.add_argument("--precision", choices=["mfma16", "bf16", "f16", "fp32"], default="mfma16",
                     help="mfma16: the 16-bit MFMA engine as shipped (DFM_F_MFMA16: fp16 operands, fp32 accumulation; dfm_config_string() "
-                         "in the JSON line says what that is); f16: the same with fp32 A_i; fp32: exact; bf16: deprecated alias of mfma16")
+                         "in the JSON line says what that is; reported as dtype f16); f16: the same with fp32 A_i; fp32: exact; "
+                         "bf16: deprecated ALIAS of mfma16 kept for BASELINE's wording - the operands are fp16, not bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-l0-table", action="store_true", help="A/B: layer 0 evaluated edge by edge (DFM_F_NO_L0_TABLE)")
     ap.add_argument("--no-fp32-line", action="store_true", help="skip the secondary measurement of the fp32 engine (one more batched call)")

@@ -1,14 +1,14 @@
 """Every BASELINE.json configuration through the C ABI, at the benchmark dtype, against the CPU oracle and the goldens
 captured from the reference (tests/golden/make_golden_r02.py):
 
-  C2  DB5 pair 7CEI, 64 parallel trajectories, bf16 sampler         test_c2_*
-  C3  synthetic 300+300, batch 256, bf16 / fp32 score evaluations   test_c3_*
+  C2  DB5 pair 7CEI, 64 parallel trajectories, 16-bit (fp16 MFMA) sampler  test_c2_*  (the named pair 1AVX: test_gpu_real_esm.py)
+  C3  synthetic 300+300, batch 256, 16-bit / fp32 score evaluations  test_c3_*
   C4  the 24 DB5 test complexes x 40 trajectories on one GPU        test_c4_*   (8-GPU sharding: tests/test_gpu_multiproc.py)
   C5  synthetic 1000+1000, batch 32                                 test_c5_*
 (C1 = the reference's own CPU case is what the goldens are.)
 
 Gates are SURVEY.md 8(d)'s: fp32 engine <= 1e-4 rel (L-inf / |.|-inf) on tr_score / rot_score / f and <= 1e-4 abs on energy;
-bf16 engine <= 1e-2 rel on scores / f and <= 3e-2 rel on energy; injected rollouts: CA-RMSD <= 0.05 A (fp32) / 0.5 A (bf16)
+16-bit engine (fp16 MFMA operands; BASELINE's "bf16" configs: the 16-bit plan is fp16 since r03) <= 1e-2 rel on scores / f and <= 3e-2 rel on energy; injected rollouts: CA-RMSD <= 0.05 A (fp32) / 0.5 A (16-bit)
 over five steps.
 """
 import csv
@@ -60,7 +60,7 @@ def check_vs(ref, r, b, tol, etol, name):
 # ---- C3 ------------------------------------------------------------------------------------------------------------
 def test_c3_batch256_vs_oracle_and_reference(model, blob):
     """The bench configuration itself: 300+300, B = 256, the engine's own graphs.  Four spread-out trajectories are replayed
-    through the oracle (same edge lists): bf16 engine at the bf16 gates, fp32 engine at 1e-4; plus the reference's own
+    through the oracle (same edge lists): 16-bit engine at the 16-bit gates, fp32 engine at 1e-4; plus the reference's own
     evaluation of this complex (fwd_c3_300_300.npz)."""
     from dfmdock_amd import engine
     from oracle import oracle as ora
@@ -78,19 +78,19 @@ def test_c3_batch256_vs_oracle_and_reference(model, blob):
     for b in (0, 85, 170, 255):
         ref = o.score(poses[b], float(ts[b]), edges=r16["edges"][b])
         check_vs(ref, r32, b, 1e-4, 1e-4, f"fp32 b={b}")
-        check_vs(ref, r16, b, 1e-2, 3e-2, f"bf16 b={b}")
+        check_vs(ref, r16, b, 1e-2, 3e-2, f"mfma16 b={b}")
         check_vs(ref, rh, b, 1e-2, 3e-2, f"f16 b={b}")
     g = load_golden("fwd_c3_300_300.npz")
     e = g["edges"].astype(np.int32)
     check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True), 0, 1e-4, 1e-4, "golden fp32")
-    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, mfma16=True), 0, 1e-2, 3e-2, "golden bf16")
+    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, mfma16=True), 0, 1e-2, 3e-2, "golden mfma16")
     gx.close()
 
 
 # ---- C2 ------------------------------------------------------------------------------------------------------------
 def test_c2_7cei_batch64_bf16_sampler(model):
     """64 parallel trajectories on the DB5 pair: with the reference run's draws tiled 64x every row equals the B = 1 row
-    bit for bit and stays within the bf16 rollout gate of the reference's poses; natively drawn trajectories differ."""
+    bit for bit and stays within the 16-bit rollout gate of the reference's poses; natively drawn trajectories differ."""
     from dfmdock_amd import engine
     g = load_golden("rollout_7CEI.npz")
     cx = complex_for("7CEI")
@@ -119,7 +119,7 @@ def test_c2_7cei_batch64_bf16_sampler(model):
 # ---- C5 ------------------------------------------------------------------------------------------------------------
 def test_c5_large_complex(model, blob):
     """1000+1000: reference evaluation (injected edges), the native N = 2000 graph build (kNN slots exact against the oracle,
-    sampled slots unique and disjoint), fp32 / bf16 engines against the oracle on the engine's own graph, and a finite 40-step
+    sampled slots unique and disjoint), fp32 / 16-bit engines against the oracle on the engine's own graph, and a finite 40-step
     run at B = 32."""
     from dfmdock_amd import engine
     from oracle import oracle as ora
@@ -128,7 +128,7 @@ def test_c5_large_complex(model, blob):
     gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
     e = g["edges"].astype(np.int32)
     check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True), 0, 1e-4, 1e-4, "golden fp32")
-    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, mfma16=True), 0, 1e-2, 3e-2, "golden bf16")
+    check_vs(g, gx.score(g["lig_pos"], float(g["t"]), edges=e, energy=True, mfma16=True), 0, 1e-2, 3e-2, "golden mfma16")
     poses = np.stack([g["lig_pos"], g["lig_pos"] + np.float32(2.0)])
     r = gx.score(poses, np.array([0.4, 0.9], np.float32), seed=3, energy=True, return_edges=True)
     for b in range(2):
@@ -143,7 +143,7 @@ def test_c5_large_complex(model, blob):
     ref = o.score(poses[1], 0.9, edges=r["edges"][1])
     check_vs(ref, r, 1, 1e-4, 1e-4, "native graph fp32")
     r16 = gx.score(poses, np.array([0.4, 0.9], np.float32), edges=r["edges"], energy=True, mfma16=True)
-    check_vs(ref, r16, 1, 1e-2, 3e-2, "native graph bf16")
+    check_vs(ref, r16, 1, 1e-2, 3e-2, "native graph mfma16")
     s = gx.sample(B=32, num_steps=40, seed=5, mfma16=True)
     assert np.isfinite(s["lig_pos"]).all() and np.isfinite(s["energy"]).all() and np.isfinite(s["tr_update"]).all()
     gx.close()

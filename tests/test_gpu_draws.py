@@ -3,7 +3,7 @@ WEIGHT_DRAWS), both model families, all three engines, through the C ABI against
 (tests/golden/make_golden_draws.py; reference src/models/score_net_mlsb.py:343-425, src/models/egnn_net.py:408-505).
 
 Gates are SURVEY 8(d)'s, unchanged: fp32 <= 1e-4 rel (L-inf / |.|-inf) on tr_score / rot_score / f, 1e-4 abs on energy;
-bf16 <= 1e-2 on scores and f, 3e-2 on energy; the fp32-A_i variant (f16) the same.  40-step rollouts with every draw replayed:
+16-bit (fp16 MFMA operands) <= 1e-2 on scores and f, 3e-2 on energy; the fp32-A_i variant (f16) the same.  40-step rollouts with every draw replayed:
 ligand CA-RMSD <= 0.05 A over the first 5 steps and 0.5 A over all 40 (fp32), 0.5 A over all 40 steps (16-bit engines).
 tools/tol_report.py prints the per-draw worst table (profiles/r03_tol_report.txt).
 """

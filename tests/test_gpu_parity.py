@@ -2,8 +2,8 @@
 golden vectors captured from the reference.  Run on the MI355X box with `pytest -m gpu`.
 
 Gates: fp32 path <= 1e-4 rel (L-inf / |.|-inf) on tr_score, rot_score, f and <= 1e-4
-abs on energy; bf16-MFMA path <= 1e-2 rel on tr_score / rot_score / f, <= 3e-2 on energy; the fp32-A_i variant (f16) the same; injected EM update
-<= 1e-5 A per step; injected 5-step rollout CA RMSD <= 0.05 A (fp32) / 0.5 A (bf16).
+abs on energy; 16-bit MFMA path (fp16 operands) <= 1e-2 rel on tr_score / rot_score / f, <= 3e-2 on energy; the fp32-A_i variant (f16) the same; injected EM update
+<= 1e-5 A per step; injected 5-step rollout CA RMSD <= 0.05 A (fp32) / 0.5 A (16-bit).
 """
 import numpy as np
 import pytest
@@ -104,7 +104,7 @@ def test_batched_equals_single(model):
 @pytest.mark.parametrize("case,steps", [("rollout_syn_24_16", 40), ("rollout_syn_64_48", 40), ("rollout_7CEI", 6)])
 @pytest.mark.parametrize("prec", ["fp32", "mfma16", "f16"])
 def test_sampler_injected_rollout(case, steps, prec, model):
-    bf16 = prec != "fp32"
+    sixteen = prec != "fp32"
     g = load_golden(case + ".npz")
     gx, _ = gpu_complex(model, case)
     inj = dict(R0=g["R0"].astype(np.float32), tr_draw=g["tr_draw"], z_rot=g["z_rot"], z_tr=g["z_tr"], edges=g["edges"])
@@ -113,12 +113,12 @@ def test_sampler_injected_rollout(case, steps, prec, model):
     ca, ref = r["trace_pose"][0][:, :, 1, :], g["poses"][:, :, 1, :]
     rmsd = np.sqrt(((ca - ref) ** 2).sum(-1).mean(-1))
     n5 = min(5, steps)
-    assert rmsd[:n5].max() < (0.5 if bf16 else 0.05), rmsd[:n5]          # gate 3
-    assert rmsd.max() < 0.5, rmsd.max()      # all 40 steps, every engine (measured: 3.4e-2 A bf16, 3.1e-3 A f16)
+    assert rmsd[:n5].max() < (0.5 if sixteen else 0.05), rmsd[:n5]          # gate 3
+    assert rmsd.max() < 0.5, rmsd.max()      # all 40 steps, every engine (measured: 3.4e-2 A mfma16, 3.1e-3 A f16)
     tol = {"fp32": 1e-4, "mfma16": 1e-2, "f16": 1e-2}[prec]
     assert rel_inf(r["trace_scores"][0][0, 0:3], g["tr_score"][0]) < tol     # first evaluation = same pose
     assert rel_inf(r["trace_scores"][0][0, 3:6], g["rot_score"][0]) < tol
-    if not bf16 and rmsd.max() < 1e-3:
+    if not sixteen and rmsd.max() < 1e-3:
         assert abs(float(r["energy"][0]) - float(g["final_energy"])) < 1e-3
         np.testing.assert_allclose(r["tr_update"], g["tr_update"], atol=2e-3)
         np.testing.assert_allclose(r["rot_update"], g["rot_update"], atol=2e-4)

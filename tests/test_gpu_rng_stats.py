@@ -166,3 +166,60 @@ def test_free_running_sampler_vs_reference_distribution(case, model):
     print("\n" + "\n".join(lines))
     assert worst > 1e-3
     gx.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def argmin_rank(energy, l_rmsd, group):
+    """inference() keeps the minimum-energy trajectory of a complex (src/inference_base.py:654-657).  Per group of `group` consecutive
+    free runs: the rank (0 = best) of the selected trajectory's l_rmsd among the group's l_rmsd values, as a fraction of the group."""
+    n = (energy.size // group) * group
+    e, l = energy[:n].reshape(-1, group), l_rmsd[:n].reshape(-1, group)
+    pick = e.argmin(1)
+    chosen = l[np.arange(l.shape[0]), pick]
+    return (l < chosen[:, None]).sum(1) / float(group)
+
+
+@pytest.mark.parametrize("case", ["sticky_syn_64_48", "sticky_7CEI"])
+def test_free_running_sampler_on_the_sticky_draw(case):
+    """the free-run gate on a weight draw whose trajectories END IN CONTACT (weights.make_sticky_weights: shrunk
+    scale heads + an attractive coordinate head), so that the final energy / clash count are NOT degenerate and the arg-min over
+    energies has something to select on.  512 free runs of the REFERENCE's Euler_Maruyama_sampler (tests/golden/make_golden_freerun.py:
+    scipy / torch.normal / torch.multinomial streams, nothing injected) on syn_64_48 and on 7CEI with its real ESM-2 block, against 2 048
+    native (Philox) trajectories per engine: two-sample KS at p > 1e-3 on |tr_update|, the rotation angle, the final energy, the clash
+    count and l_rmsd of the final pose; P(energy == 0) < 0.2 on both sides; and a two-sample test on the RANK of the arg-min
+    trajectory's l_rmsd inside groups of 16 runs - what selection (a-15) delivers."""
+    from dfmdock_amd import engine
+    from dfmdock_amd.metrics import NativeContext, compute_metrics
+    from dfmdock_amd.weights import make_sticky_weights, pack_blob
+    from scipy import stats
+    g = load_golden(f"freerun_{case}.npz")
+    ref = _outcomes(g)
+    ref["l_rmsd"] = g["l_rmsd"].astype(np.float64)
+    assert ref["energy"].size >= 512 and int(g["num_steps"]) == 40
+    assert (ref["energy"] == 0).mean() < 0.2 and np.unique(ref["energy"]).size > 400 and np.unique(ref["num_clashes"]).size > 10
+    engine.set_device(0)
+    model = engine.Model(pack_blob(make_sticky_weights()))
+    cx = complex_for("7CEI" if "7CEI" in case else "fwd_syn_64_48")
+    gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+    native = NativeContext((cx["rec_pos"], cx["lig_pos"]))
+    ref_rank = argmin_rank(ref["energy"], ref["l_rmsd"], 16)
+    lines = []
+    for prec in ("fp32", "mfma16"):
+        parts = [gx.sample(B=256, num_steps=40, seed=7000 + k, **engine.precision_kwargs(prec)) for k in range(8)]
+        r = {k: np.concatenate([p[k] for p in parts]) for k in ("tr_update", "rot_update", "energy", "num_clashes", "lig_pos")}
+        got = _outcomes(r)
+        got["l_rmsd"] = np.array([compute_metrics((cx["rec_pos"], lp), (cx["rec_pos"], cx["lig_pos"]), native)["l_rmsd"] for lp in r["lig_pos"]])
+        assert (got["energy"] == 0).mean() < 0.2, (prec, (got["energy"] == 0).mean())
+        for k in ("tr_norm", "rot_angle", "energy", "num_clashes", "l_rmsd"):
+            ks = stats.ks_2samp(got[k], ref[k])
+            lines.append(f"{prec} {k}: KS D = {ks.statistic:.4f} p = {ks.pvalue:.3f} (engine median {np.median(got[k]):.4g}, reference median {np.median(ref[k]):.4g})")
+            assert ks.pvalue > 1e-3, lines
+        rk = argmin_rank(got["energy"], got["l_rmsd"], 16)
+        ks = stats.ks_2samp(rk, ref_rank)
+        lines.append(f"{prec} rank of the arg-min trajectory's l_rmsd in groups of 16: KS D = {ks.statistic:.4f} p = {ks.pvalue:.3f} "
+                     f"(engine mean rank {rk.mean():.3f} over {rk.size} groups, reference {ref_rank.mean():.3f} over {ref_rank.size})")
+        assert ks.pvalue > 1e-3, lines
+        lines.append(f"{prec} P(energy == 0): engine {(got['energy'] == 0).mean():.3f} reference {(ref['energy'] == 0).mean():.3f}")
+    print("\n" + "\n".join(lines))
+    gx.close()
+    model.close()
