@@ -158,6 +158,16 @@ struct DevPool {
         }
         ptrs.clear();
     }
+    // hand back the blocks allocated after `mark` (= ptrs.size() before a group of allocations that failed half way); the caller has
+    // synchronised the owning stream
+    void release_tail(size_t mark)
+    {
+        if (mark >= ptrs.size()) return;
+        std::vector<Block> tail(ptrs.begin() + mark, ptrs.end()), head(ptrs.begin(), ptrs.begin() + mark);
+        ptrs.swap(tail);
+        release(true);
+        ptrs.swap(head);
+    }
     template <typename T> hipError_t alloc(T **out, size_t n)
     {
         size_t bytes = (n ? n : 1) * sizeof(T);
@@ -796,7 +806,8 @@ extern "C" int dfm_complex_degree(const dfm_complex *cx) { return cx ? cx->K : -
 
 extern "C" long long dfm_trim_cache(int device)
 {
-    return (long long)g_block_cache.trim(device < 0 || device >= MAX_DEVICES ? -1 : device);
+    if (device >= MAX_DEVICES) return 0;      // no such device: nothing parked there (a negative index means every device)
+    return (long long)g_block_cache.trim(device < 0 ? -1 : device);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -875,16 +886,36 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
     }
     if (wants_mbuf && !W.mbuf) { HIPCHK(W.pool.alloc(&W.mbuf, (size_t)W.Bcap * cx->L * KPAD * H)); cx->buf_gen++; }
     if (l0) {
+        // the layer-0 buffers of this batch capacity: all of them or none.  A batch whose row buffers do not fit does not
+        // leave a half-allocated workspace behind, and the error says how to run it anyway.
         const size_t cap = (size_t)W.Bcap * cx->N * cx->K;      // every edge of a batched evaluation may miss the table
-        if (!W.l0_src) {
+        const size_t mark = W.pool.ptrs.size();
+        const bool had_src = W.l0_src != nullptr, had_x = W.l0_x != nullptr, had_x32 = W.l0_x32 != nullptr;
+        hipError_t e = hipSuccess;
+        if (!had_src) {
             cx->buf_gen++;
-            HIPCHK(W.pool.alloc(&W.l0_src, cap)); HIPCHK(W.pool.alloc(&W.l0_rows, cap));
-            HIPCHK(W.pool.alloc(&W.l0_counter, 1)); HIPCHK(W.pool.alloc(&W.l0_miss_total, 1));
-            HIPCHK(hipMemsetAsync(W.l0_counter, 0, sizeof(uint32_t), cx->stream));
-            HIPCHK(hipMemsetAsync(W.l0_miss_total, 0, sizeof(unsigned long long), cx->stream));
+            e = W.pool.alloc(&W.l0_src, cap);
+            if (e == hipSuccess) e = W.pool.alloc(&W.l0_rows, cap);
+            if (e == hipSuccess) e = W.pool.alloc(&W.l0_counter, 1);
+            if (e == hipSuccess) e = W.pool.alloc(&W.l0_miss_total, 1);
+            if (e == hipSuccess) e = hipMemsetAsync(W.l0_counter, 0, sizeof(uint32_t), cx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(W.l0_miss_total, 0, sizeof(unsigned long long), cx->stream);
         }
-        if (bf16 && !W.l0_x) { cx->buf_gen++; HIPCHK(W.pool.alloc(&W.l0_x, (cap + 32) * H)); }      // the last tile of the row list stores all of its 32 rows
-        if (!bf16 && !W.l0_x32) { cx->buf_gen++; HIPCHK(W.pool.alloc(&W.l0_x32, cap * H)); }      // fp32 engine: only the list's own rows are stored
+        if (e == hipSuccess && bf16 && !had_x) { cx->buf_gen++; e = W.pool.alloc(&W.l0_x, (cap + 32) * H); }      // the last tile of the row list stores all of its 32 rows
+        if (e == hipSuccess && !bf16 && !had_x32) { cx->buf_gen++; e = W.pool.alloc(&W.l0_x32, cap * H); }         // fp32 engine: only the list's own rows are stored
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(cx->stream);
+            W.pool.release_tail(mark);
+            if (!had_src) { W.l0_src = nullptr; W.l0_rows = nullptr; W.l0_counter = nullptr; W.l0_miss_total = nullptr; }
+            if (!had_x) W.l0_x = nullptr;
+            if (!had_x32) W.l0_x32 = nullptr;
+            char msg[256];
+            snprintf(msg, sizeof(msg), "layer-0 message table: the row buffers of a batch of %d (%zu B per edge, %.1f GB) do not fit (%s): split the "
+                     "batch or evaluate layer 0 directly (DFM_F_NO_L0_TABLE / leave DFM_F_L0_TABLE out)", W.Bcap, bf16 ? (size_t)532 : (size_t)1044,
+                     (double)cap * (bf16 ? 532.0 : 1044.0) / 1e9, hipGetErrorString(e));
+            return fail(e == hipErrorOutOfMemory ? DFM_E_OOM : DFM_E_HIP, msg);
+        }
     }
     return DFM_OK;
 }

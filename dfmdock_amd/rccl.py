@@ -56,11 +56,13 @@ def exchange_uid_file(uid: bytes | None, rank: int, world: int, gather_dir: str,
     """Rank 0 hands the 128-byte id to the other ranks through files in `gather_dir`, with a handshake that a leftover file of
     an EARLIER job with the same token (no DFM_JOB_ID: the token is just MASTER_PORT) cannot satisfy:
 
-      rank r > 0   writes `<token>_rccl_hello_<r>` = a fresh 16-byte nonce, then waits for a `<token>_rccl_uid` file that carries
-                   ITS nonce in slot r, answers with `<token>_rccl_ack_<r>` = the nonce and returns the id;
-      rank 0       collects the hello nonces, publishes id + nonces (atomic rename), waits for every ack to match - a stale hello
-                   file gives a nonce nobody acknowledges, so it re-reads the hellos and publishes again - and finally removes
-                   every file of the exchange, so that nothing is left behind for the next job.
+      rank r > 0   removes its own leftover ack, writes `<token>_rccl_hello_<r>` = a fresh 16-byte nonce, then waits for a
+                   `<token>_rccl_uid` file that carries ITS nonce in slot r, answers with `<token>_rccl_ack_<r>` = nonce + the first
+                   16 bytes of the id it just read, and returns the id;
+      rank 0       collects the hello nonces, publishes id + nonces (atomic rename), waits for every ack to equal nonce + ITS id's
+                   first 16 bytes - a stale hello gives a nonce nobody acknowledges, and the hello / ack PAIR a crashed job left
+                   behind (equal nonces: rank r had acked, rank 0 died before the clean-up) acknowledges the DEAD job's id, not this
+                   one - so it re-reads the hellos and publishes again; finally it removes every file of the exchange.
 
     A dead id read from a stale file would make ncclCommInitRank hang."""
     base = os.path.join(gather_dir, f"{token}_rccl")
@@ -77,7 +79,7 @@ def exchange_uid_file(uid: bytes | None, rank: int, world: int, gather_dir: str,
                 if blob != published:
                     _write_atomic(uid_path, blob)
                     published = blob
-                if all(_read(f"{base}_ack_{r}") == nonces[r] for r in others):
+                if all(_read(f"{base}_ack_{r}") == nonces[r] + uid[:16] for r in others):
                     for r in others:
                         for kind in ("hello", "ack"):
                             try:
@@ -90,15 +92,19 @@ def exchange_uid_file(uid: bytes | None, rank: int, world: int, gather_dir: str,
                         pass
                     return uid
             if time.time() - t0 > timeout_s:
-                raise TimeoutError(f"rccl unique id: ranks {[r for r in others if _read(f'{base}_ack_{r}') != nonces.get(r)]} never acknowledged {uid_path}")
+                raise TimeoutError(f"rccl unique id: ranks {[r for r in others if _read(f'{base}_ack_{r}') != (nonces.get(r) or b'') + uid[:16]]} never acknowledged {uid_path}")
             time.sleep(0.01)
+    try:
+        os.remove(f"{base}_ack_{rank}")      # an ack of an earlier job must not outlive this rank's new hello
+    except OSError:
+        pass
     nonce = os.urandom(16)
     _write_atomic(f"{base}_hello_{rank}", nonce)
     lo = NCCL_UNIQUE_ID_BYTES + 16 * (rank - 1)
     while True:
         blob = _read(uid_path)
         if blob is not None and len(blob) == NCCL_UNIQUE_ID_BYTES + 16 * (world - 1) and blob[lo:lo + 16] == nonce:
-            _write_atomic(f"{base}_ack_{rank}", nonce)
+            _write_atomic(f"{base}_ack_{rank}", nonce + blob[:16])
             return blob[:NCCL_UNIQUE_ID_BYTES]
         if time.time() - t0 > timeout_s:
             raise TimeoutError(f"rccl unique id for this job never appeared at {uid_path}")

@@ -272,7 +272,8 @@ int dfm_complex_degree(const dfm_complex *cx);
 /* Device blocks released by destroyed handles are parked per device for the next handle (a set driver creates and destroys a
  * complex every ~100 ms; hipMalloc / hipFree of gigabyte workspaces cost milliseconds and drain the device): at most
  * DFM_ALLOC_CACHE_FRAC (default 0.25) of the device's memory, DFM_ALLOC_CACHE=0 disables it.  dfm_trim_cache hands every parked
- * block of `device` (< 0: all devices) back to the driver - for processes that share a GPU - and returns the bytes freed. */
+ * block of `device` (< 0: all devices; an index past the last device: nothing, returns 0) back to the driver - for processes that
+ * share a GPU - and returns the bytes freed. */
 long long dfm_trim_cache(int device);
 
 /* B score evaluations of poses lig_pos[B,L,9] at times t[B] */

@@ -371,6 +371,24 @@ def test_rccl_uid_file_ignores_leftovers_of_an_earlier_job(tmp_path):
             t.join(30)
         assert res == {r: new for r in range(1, world)}
         assert [f for f in os.listdir(d) if f.startswith("29500_rccl")] == []
+    # the NORMAL leftover of a crashed job - rank 1 had acknowledged (hello and ack carry the SAME nonce) and rank 0 died
+    # before its clean-up.  A new rank 0 that starts first must not take that pair for this job's acknowledgement: the ack is bound
+    # to the id it acknowledges, and a late rank 1 still completes the exchange.
+    n_old = os.urandom(16)
+    open(os.path.join(d, "29500_rccl_hello_1"), "wb").write(n_old)
+    open(os.path.join(d, "29500_rccl_ack_1"), "wb").write(n_old + old[:16])       # this round's ack format, of the dead job's id
+    res = {}
+    t0 = threading.Thread(target=lambda: res.update({0: rccl.exchange_uid_file(new, 0, 2, d, "29500", timeout_s=30)}))
+    t0.start()
+    time.sleep(0.3)
+    assert not res                                                                    # rank 0 is still waiting for a REAL rank 1
+    assert rccl.exchange_uid_file(None, 1, 2, d, "29500", timeout_s=30) == new
+    t0.join(30)
+    assert res == {0: new} and [f for f in os.listdir(d) if f.startswith("29500_rccl")] == []
+    open(os.path.join(d, "29500_rccl_hello_1"), "wb").write(n_old)                    # ... and the r05 ack format (bare nonce) is no ack at all
+    open(os.path.join(d, "29500_rccl_ack_1"), "wb").write(n_old)
+    with pytest.raises(TimeoutError):
+        rccl.exchange_uid_file(new, 0, 2, d, "29500", timeout_s=0.4)
 
 
 def test_set_run_assignment_over_eight_ranks_with_the_measured_cost_model():
