@@ -272,6 +272,7 @@ struct Workspace {
     float *ir1 = nullptr, *ir2 = nullptr, *ir3 = nullptr;      // to_ires scratch, allocated on the first DFM_F_IRES call
     // layer 0 behind the message table (allocated on first use): per edge the source of its gated message, the row list of the
     // edges the edge model still evaluates, their messages, the list's length and the running total for the profile
+    uint32_t *task_ctr = nullptr;      // [8] per-XCD task counters of the 16-bit message kernel (dynamic tasks, kernels_edge.hip)
     uint32_t *l0_src = nullptr; uint4 *l0_rows = nullptr; uint16_t *l0_x = nullptr; uint32_t *l0_counter = nullptr;
     float *l0_x32 = nullptr;      // fp32 engine: the row list's messages (1 KiB per row)
     unsigned long long *l0_miss_total = nullptr;
@@ -881,6 +882,7 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
         HIPCHK(W.pool.alloc(&W.lig_cur, b * L * 9)); HIPCHK(W.pool.alloc(&W.tr_update, b * 3));
         HIPCHK(W.pool.alloc(&W.rot_update, b * 3));
         HIPCHK(W.pool.alloc(&W.step_ctl, 4));
+        HIPCHK(W.pool.alloc(&W.task_ctr, 8));
         { const int rc = ensure_time_grid(cx, b); if (rc) return rc; }
         W.Bcap = B;
     }
@@ -1107,6 +1109,7 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         e.lig_only = lig_only ? 1 : 0;
         e.agg_is_zero = (l > 0 && tile_tasks) ? 1 : 0;      // zeroed by the previous layer's node_mlp.3 GEMM
         e.stamp = (o.profile && l == 2) ? cx->stamp_dev : nullptr;
+        e.task_ctr = W.task_ctr;
         {   // selfcheck telemetry: what enters this layer
             const long long nrow = l == 0 ? N : M;      // layer 0's operands are per complex, not per trajectory
             if (o.range) {

@@ -222,6 +222,7 @@ struct EdgeArgs {
     int agg_is_zero;       // 16-bit kernel with tile tasks: agg is known to be zero (zeroed by the previous layer's node_mlp.3 GEMM, GemmArgs::zbuf)
     unsigned long long *stamp;   // diagnostic builds (DFM_EDGE_STAMP): [8 waves][4 phases] cycle sums of workgroup 0, or nullptr
     uint32_t *range;             // fp32 kernel, selfcheck only: [2] running maxima of |pre-activation| of edge_mlp.0 / edge_mlp.2 (float bits)
+    uint32_t *task_ctr;          // 16-bit message kernel: [8] per-XCD task counters of this handle (launch_edge_bf16 zeroes them on the stream), or nullptr
 };
 hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s);

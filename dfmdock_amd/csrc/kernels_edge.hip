@@ -66,6 +66,8 @@ struct EdgeKArgs {
     uint32_t n_rows;
     uint16_t *rows_out;
     float *rows_out32;           // k_edge_f32m<1>: gated messages of the row list, row-major fp32 [row][256]
+    uint32_t *task_ctr;          // k_edge_msg, node tasks of large launches: [8] per-XCD counters (zero at launch) - the waves of an XCD take
+                                 // their tasks after the first from here instead of a fixed stride (see "dynamic tasks" in the kernel), or nullptr
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -861,6 +863,22 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
                                                                                // (a few waves each, a SIMD to themselves) instead of filling the first ones
     int b = 0, i = 0, mt = 0;
     const bool has_task = next_task(tt, b, i, mt);      // (a wave without a task still helps to fill the weights and meets the barrier)
+    // Dynamic tasks (r06).  The two waves of a SIMD do not run at the same speed: issue arbitration favours the OLDER wave, and the trace
+    // of a C3 launch (tools/edge_trace.py, profiles/r06_edge_trace.txt) shows waves 0..3 of a workgroup finishing a tile every 21.4 k cycles
+    // and waves 4..7 every 30.0 k.  With a fixed stride every wave gets the same number of nodes, so the older half is done after ~70 % of
+    // the launch and the younger half finishes alone, one wave per SIMD.  Instead a wave's FIRST task is the static one and every later
+    // task index comes from a per-XCD counter (XCD-aware order kept: an XCD still walks whole trajectories).  The fetch is one returning
+    // atomic per task issued by lane 0 at the START of the epilogue of the tile before the task's last tile and read at the END of that
+    // epilogue: the vector-memory counter completes in order, and there it delays no gather (the only loads in flight are older).
+    // Results cannot depend on which wave runs a node: a task writes its own rows of agg / mbuf, nothing else.
+    const bool dyn = !ROWS && !split && nsplit == 1 && p.task_ctr != nullptr;
+    uint32_t dyn_next = ~0u;      // index of the task after the current one, valid from the end of the epilogue that fetched it
+    auto fetch_task = [&]() -> uint32_t {      // per-lane result of lane 0's atomic; consumed through readfirstlane
+        uint32_t v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(p.task_ctr + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    if (dyn && has_task && ntile == 1) dyn_next = tstride + (uint32_t)__builtin_amdgcn_readfirstlane((int)fetch_task());      // one-tile tasks: needed at once
 
     // raw edge data of the tile in lookahead (rows past K read the node's last edge and are masked in set_tile)
     int jqn[2]; uint32_t codeqn[2]; float radqn[2];
@@ -1064,8 +1082,13 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         int nb = b, ni = i, nmt = mt + 1;
         bool have_next = true;
         if (split || nmt == ntile) {
-            ntt = tt + tstride;
-            have_next = next_task(ntt, nb, ni, nmt);
+            if (dyn) {
+                ntt = dyn_next;
+                have_next = ntt < ntask && task_tile(ntt, nb, ni, nmt);
+            } else {
+                ntt = tt + tstride;
+                have_next = next_task(ntt, nb, ni, nmt);
+            }
         }
         if (!have_next) { nb = b; ni = i; nmt = mt; }
 
@@ -1133,6 +1156,11 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
 #ifdef DFM_EDGE_TRACE
         ++tr_n;
 #endif
+        // dynamic tasks: the tile after this one is the last of its task -> its iteration will need the task after that one
+        const bool fetch_now = dyn && have_next && nmt == ntile - 1;
+        uint32_t fetched = 0;
+        if (fetch_now) fetched = fetch_task();
+        __builtin_amdgcn_sched_barrier(0);      // (the read of `fetched` stays at the END of the epilogue: hoisted next to the atomic it would expose its latency here)
 
         // ---- epilogue on the 32 x 256 tile: lane owns columns nt*32 + l31, rows rowof(r) = (r & 3) + 8 (r >> 2) + 4 h
         float part[16];
@@ -1288,6 +1316,12 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         }      // !ROWS
         STAMP(3);
         if (!have_next) break;
+        if (fetch_now) {
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t got;
+            asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(got) : "v"(fetched));
+            dyn_next = tstride + got;
+        }
         // the rest of the next tile's chunk 1 (kept out of the epilogue's register budget): the second pass is first used at slot 8
         if constexpr (DFM_EDGE_DEFER >= 2) gather(1, 1, r1);
         if constexpr (DFM_EDGE_DEFER >= 1) gather_chunk(1);
@@ -1489,7 +1523,7 @@ static EdgeKArgs to_kargs(const EdgeArgs &a)
     k.agg = a.agg; k.last = a.last; k.fout = a.fout; k.mbuf = a.mbuf; k.stamp = a.stamp; k.split = 0;
     k.node0 = a.lig_only ? a.R : 0; k.nodes = a.lig_only ? a.N - a.R : a.N;
     k.no_agg = a.lig_only ? 1 : 0;      // the ligand-only last layer feeds the coordinate update alone (api.hip: no node model follows)
-    k.Ah = a.Ah; k.range = a.range;
+    k.Ah = a.Ah; k.range = a.range; k.task_ctr = nullptr;
     return k;
 }
 // the 16-bit MFMA kernels take the -log2(e)-scaled operands (SILU_S, api.hip)
@@ -1580,6 +1614,15 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
         if (!a.agg_is_zero && !k.no_agg) {
             hipError_t e = hipMemsetAsync(a.agg, 0, (size_t)a.B * a.N * H * sizeof(float), s);
             if (e != hipSuccess) return e;
+        }
+    }
+    else if (a.task_ctr && a.B >= 8 && tasks > (long long)device_cus() * EDGE_WAVES) {
+        // node tasks, more tasks than waves: every wave's tasks after its first come from the per-XCD counters (dynamic tasks, k_edge_msg)
+        static const bool off = [] { const char *e = getenv("DFM_EDGE_DYNAMIC"); return e && atoi(e) == 0; }();      // diagnostics: the fixed stride of r01-r05
+        if (!off) {
+            hipError_t e = hipMemsetAsync(a.task_ctr, 0, 8 * sizeof(uint32_t), s);
+            if (e != hipSuccess) return e;
+            k.task_ctr = a.task_ctr;
         }
     }
     if (a.f16) return a.Ah ? launch_msg_t<1, 1>(k, tasks, s) : launch_msg_t<1, 0>(k, tasks, s);

@@ -6,7 +6,7 @@ set -e
 NAME=$1; EXTRA=$2
 ROOT=$(cd $(dirname $0)/.. && pwd); SRC=$ROOT/dfmdock_amd/csrc; OBJ=/tmp/dfm_ev_$NAME; mkdir -p $OBJ $ROOT/tools/variants
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize $EXTRA"
-hipcc $COMMON -c $SRC/kernels_edge.hip -o $OBJ/kernels_edge.o
+hipcc $COMMON -mllvm -amdgpu-atomic-optimizer-strategy=None -c $SRC/kernels_edge.hip -o $OBJ/kernels_edge.o
 API=$SRC/api.o
 case "$EXTRA" in *TRACE*|*STAMP*) hipcc $COMMON -c $SRC/api.hip -o $OBJ/api.o; API=$OBJ/api.o;; esac
 hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/variants/$NAME.so $API $OBJ/kernels_edge.o $SRC/kernels_geom.o $SRC/kernels_heads.o $SRC/kernels_dense.o $SRC/kernels_pair.o
