@@ -272,7 +272,7 @@ struct Workspace {
     float *ir1 = nullptr, *ir2 = nullptr, *ir3 = nullptr;      // to_ires scratch, allocated on the first DFM_F_IRES call
     // layer 0 behind the message table (allocated on first use): per edge the source of its gated message, the row list of the
     // edges the edge model still evaluates, their messages, the list's length and the running total for the profile
-    uint32_t *task_ctr = nullptr;      // [8] per-XCD task counters of the 16-bit message kernel (dynamic tasks, kernels_edge.hip)
+    uint32_t *task_ctr = nullptr;      // per-workgroup task + exit counters of the 16-bit message kernel (dynamic tasks, kernels_edge.hip)
     uint32_t *l0_src = nullptr; uint4 *l0_rows = nullptr; uint16_t *l0_x = nullptr; uint32_t *l0_counter = nullptr;
     float *l0_x32 = nullptr;      // fp32 engine: the row list's messages (1 KiB per row)
     unsigned long long *l0_miss_total = nullptr;
@@ -882,7 +882,8 @@ static int ensure_workspace(dfm_complex *cx, int B, bool bf16, bool l0 = false)
         HIPCHK(W.pool.alloc(&W.lig_cur, b * L * 9)); HIPCHK(W.pool.alloc(&W.tr_update, b * 3));
         HIPCHK(W.pool.alloc(&W.rot_update, b * 3));
         HIPCHK(W.pool.alloc(&W.step_ctl, 4));
-        HIPCHK(W.pool.alloc(&W.task_ctr, 8));
+        HIPCHK(W.pool.alloc(&W.task_ctr, 2 * TASK_CTR_WGS));
+        HIPCHK(hipMemsetAsync(W.task_ctr, 0, 2 * TASK_CTR_WGS * sizeof(uint32_t), cx->stream));
         { const int rc = ensure_time_grid(cx, b); if (rc) return rc; }
         W.Bcap = B;
     }

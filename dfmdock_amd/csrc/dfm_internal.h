@@ -201,6 +201,7 @@ hipError_t launch_edge_feat(const float4 *n4, const float4 *ca4, const float4 *c
 hipError_t launch_l0_pairs(const float4 *n4, const float4 *ca4, const float4 *cb4, int R, int L, float mask_dist, uint2 *code0,
                            uint4 *rows, hipStream_t s);
 
+constexpr int TASK_CTR_WGS = 1024;      // workgroups the message kernel's task counters are sized for (its persistent grid is one workgroup per CU)
 struct EdgeArgs {
     const float *A;        // [Ab][N][256]  Wa h_i + b1   (Ab = 1 when a_bstride == 0)
     const float *Bm;       // [Ab][N][256]  Wb h_j        fp32
@@ -222,7 +223,7 @@ struct EdgeArgs {
     int agg_is_zero;       // 16-bit kernel with tile tasks: agg is known to be zero (zeroed by the previous layer's node_mlp.3 GEMM, GemmArgs::zbuf)
     unsigned long long *stamp;   // diagnostic builds (DFM_EDGE_STAMP): [8 waves][4 phases] cycle sums of workgroup 0, or nullptr
     uint32_t *range;             // fp32 kernel, selfcheck only: [2] running maxima of |pre-activation| of edge_mlp.0 / edge_mlp.2 (float bits)
-    uint32_t *task_ctr;          // 16-bit message kernel: [8] per-XCD task counters of this handle (launch_edge_bf16 zeroes them on the stream), or nullptr
+    uint32_t *task_ctr;          // 16-bit message kernel: [2 * TASK_CTR_WGS] per-workgroup task + exit counters of this handle (zero between launches: the kernel resets them), or nullptr
 };
 hipError_t launch_edge_f32(const EdgeArgs &a, hipStream_t s);
 hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s);

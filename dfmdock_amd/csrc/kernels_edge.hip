@@ -66,8 +66,9 @@ struct EdgeKArgs {
     uint32_t n_rows;
     uint16_t *rows_out;
     float *rows_out32;           // k_edge_f32m<1>: gated messages of the row list, row-major fp32 [row][256]
-    uint32_t *task_ctr;          // k_edge_msg, node tasks of large launches: [8] per-XCD counters (zero at launch) - the waves of an XCD take
-                                 // their tasks after the first from here instead of a fixed stride (see "dynamic tasks" in the kernel), or nullptr
+    uint32_t *task_ctr;          // k_edge_msg, node tasks of large launches: [TASK_CTR_WGS] per-workgroup task counters + as many exit counters, all
+                                 // zero at launch (the last wave out of a workgroup zeroes its pair again) - the waves of a workgroup take the
+                                 // workgroup's tasks in order from here instead of by a fixed stride ("dynamic tasks" in the kernel), or nullptr
 };
 
 __device__ inline void row_dot(const float *lds_rows /*[KF][256]*/, const float *__restrict__ Wt /*[256][256]*/,
@@ -866,19 +867,26 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
     // Dynamic tasks (r06).  The two waves of a SIMD do not run at the same speed: issue arbitration favours the OLDER wave, and the trace
     // of a C3 launch (tools/edge_trace.py, profiles/r06_edge_trace.txt) shows waves 0..3 of a workgroup finishing a tile every 21.4 k cycles
     // and waves 4..7 every 30.0 k.  With a fixed stride every wave gets the same number of nodes, so the older half is done after ~70 % of
-    // the launch and the younger half finishes alone, one wave per SIMD.  Instead a wave's FIRST task is the static one and every later
-    // task index comes from a per-XCD counter (XCD-aware order kept: an XCD still walks whole trajectories).  The fetch is one returning
-    // atomic per task issued by lane 0 at the START of the epilogue of the tile before the task's last tile and read at the END of that
-    // epilogue: the vector-memory counter completes in order, and there it delays no gather (the only loads in flight are older).
-    // Results cannot depend on which wave runs a node: a task writes its own rows of agg / mbuf, nothing else.
+    // the launch and the younger half finishes alone, one wave per SIMD.  Instead the WORKGROUP keeps its fixed share of the XCD's task
+    // list - tasks slot, slot + wg_per_xcd, slot + 2 wg_per_xcd ... exactly the set its eight waves walk with the fixed stride, so the
+    // XCD-aware order (an XCD walks whole trajectories, all its workgroups at the same pace) is untouched - and its waves take them in
+    // order from a per-workgroup counter: a wave's first task is the static one (position = wave), every later position is one returning
+    // atomic by lane 0, issued at the START of the epilogue of the tile before the task's last tile and read at the END of that epilogue
+    // (the vector-memory counter completes in order: there it delays no gather, the only loads in flight are older).  Eight waves per
+    // counter: a first version with one counter per XCD lost 3 - 22 % on launches with few tasks per wave, where all 256 waves of the XCD
+    // reach their fetch at the same moment and queue on one address (profiles/r06_edge_trace.txt).
+    // Results cannot depend on which wave runs a node: a task writes its own rows of agg / mbuf, nothing else.  The counters reset
+    // themselves: every wave that had a task counts itself out on a second per-workgroup word when it leaves, and the last one out
+    // stores zeros into both.
     const bool dyn = !ROWS && !split && nsplit == 1 && p.task_ctr != nullptr;
     uint32_t dyn_next = ~0u;      // index of the task after the current one, valid from the end of the epilogue that fetched it
     auto fetch_task = [&]() -> uint32_t {      // per-lane result of lane 0's atomic; consumed through readfirstlane
         uint32_t v = 0;
-        if (lane == 0) v = __hip_atomic_fetch_add(p.task_ctr + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) v = __hip_atomic_fetch_add(p.task_ctr + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return v;
     };
-    if (dyn && has_task && ntile == 1) dyn_next = tstride + (uint32_t)__builtin_amdgcn_readfirstlane((int)fetch_task());      // one-tile tasks: needed at once
+    auto dyn_index = [&](uint32_t pos) -> uint32_t { return (uint32_t)slot + (uint32_t)wg_per_xcd * ((uint32_t)EDGE_WAVES + pos); };
+    if (dyn && has_task && ntile == 1) dyn_next = dyn_index((uint32_t)__builtin_amdgcn_readfirstlane((int)fetch_task()));      // one-tile tasks: needed at once
 
     // raw edge data of the tile in lookahead (rows past K read the node's last edge and are masked in set_tile)
     int jqn[2]; uint32_t codeqn[2]; float radqn[2];
@@ -1320,12 +1328,21 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             __builtin_amdgcn_sched_barrier(0);
             uint32_t got;
             asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(got) : "v"(fetched));
-            dyn_next = tstride + got;
+            dyn_next = dyn_index(got);
         }
         // the rest of the next tile's chunk 1 (kept out of the epilogue's register budget): the second pass is first used at slot 8
         if constexpr (DFM_EDGE_DEFER >= 2) gather(1, 1, r1);
         if constexpr (DFM_EDGE_DEFER >= 1) gather_chunk(1);
         tt = ntt; b = nb; i = ni; mt = nmt;
+    }
+    if (dyn && lane == 0) {      // count this wave out; the last of the workgroup's waves that had a task leaves the counters zeroed for the next launch
+        uint32_t active = 0;      // waves of this workgroup whose static first task exists
+        for (int w = 0; w < EDGE_WAVES; ++w) active += (uint32_t)w * (uint32_t)wg_per_xcd + (uint32_t)slot < ntask ? 1u : 0u;
+        const uint32_t gone = __hip_atomic_fetch_add(p.task_ctr + TASK_CTR_WGS + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone + 1u == active) {
+            __hip_atomic_store(p.task_ctr + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.task_ctr + TASK_CTR_WGS + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #ifdef DFM_EDGE_STAMP
     if (p.stamp && blockIdx.x == 0 && lane == 0)
@@ -1616,14 +1633,10 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
             if (e != hipSuccess) return e;
         }
     }
-    else if (a.task_ctr && a.B >= 8 && tasks > (long long)device_cus() * EDGE_WAVES) {
+    else if (a.task_ctr && a.B >= 8 && tasks >= 2 * (long long)device_cus() * EDGE_WAVES) {
         // node tasks, more tasks than waves: every wave's tasks after its first come from the per-XCD counters (dynamic tasks, k_edge_msg)
         static const bool off = [] { const char *e = getenv("DFM_EDGE_DYNAMIC"); return e && atoi(e) == 0; }();      // diagnostics: the fixed stride of r01-r05
-        if (!off) {
-            hipError_t e = hipMemsetAsync(a.task_ctr, 0, 8 * sizeof(uint32_t), s);
-            if (e != hipSuccess) return e;
-            k.task_ctr = a.task_ctr;
-        }
+        if (!off && device_cus() <= TASK_CTR_WGS) k.task_ctr = a.task_ctr;      // zero at allocation, zeroed again by the last wave of every launch
     }
     if (a.f16) return a.Ah ? launch_msg_t<1, 1>(k, tasks, s) : launch_msg_t<1, 0>(k, tasks, s);
     return a.Ah ? launch_msg_t<0, 1>(k, tasks, s) : launch_msg_t<0, 0>(k, tasks, s);
