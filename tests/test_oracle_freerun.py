@@ -50,6 +50,47 @@ def test_oracle_free_runs_match_the_reference_distribution():
     assert abs(z) < 4.0, (a, b, z)
 
 
+def _sticky_runs(args):
+    lo, hi = args
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from dfmdock_amd.metrics import compute_metrics
+    from dfmdock_amd.synthetic import make_complex
+    from dfmdock_amd.weights import make_sticky_weights, pack_blob
+    from oracle import oracle as ora
+    ora.lib().ora_set_num_threads(1)
+    cx = make_complex(24, 16, seed=5)
+    o = ora.Oracle(pack_blob(make_sticky_weights()), cx)
+    out = np.zeros((hi - lo, 9))
+    for i, s in enumerate(range(lo, hi)):
+        r = o.sample(num_steps=40, seed=81000 + s)
+        l_rmsd = compute_metrics((cx["rec_pos"], r["lig_pos"]), (cx["rec_pos"], cx["lig_pos"]))["l_rmsd"]
+        out[i] = np.concatenate([r["tr_update"].reshape(3), r["rot_update"].reshape(3), [float(r["energy"]), float(r["num_clashes"]), l_rmsd]])
+    return out
+
+
+def test_oracle_free_runs_on_the_sticky_draw_match_the_reference():
+    """The same comparison on the weight draw whose free runs END IN CONTACT (weights.make_sticky_weights): the final
+    energy and clash count are not degenerate here (P(energy == 0) < 0.2 on both sides), so the oracle's sampler, graph sampling and
+    energy head are held to the reference's own free runs (freerun_sticky_syn_24_16.npz, 512 runs) where the outcome depends on them:
+    KS on |tr_update|, rotation angle, energy, clash count and l_rmsd of the final pose."""
+    from scipy import stats
+    g = load_golden("freerun_sticky_syn_24_16.npz")
+    assert g["energy"].shape[0] >= 512 and (g["energy"] == 0).mean() < 0.2
+    n, workers = 64, min(8, os.cpu_count() or 1)
+    chunk = n // workers
+    with mp.get_context("spawn").Pool(workers) as pool:
+        got = np.concatenate(pool.map(_sticky_runs, [(k * chunk, (k + 1) * chunk) for k in range(workers)]))
+    ref = {"tr": np.linalg.norm(g["tr_update"], axis=1), "rot": np.linalg.norm(g["rot_update"], axis=1), "energy": g["energy"].astype(np.float64),
+           "clashes": g["num_clashes"].astype(np.float64), "l_rmsd": g["l_rmsd"].astype(np.float64)}
+    mine = {"tr": np.linalg.norm(got[:, 0:3], axis=1), "rot": np.linalg.norm(got[:, 3:6], axis=1), "energy": got[:, 6], "clashes": got[:, 7],
+            "l_rmsd": got[:, 8]}
+    assert (mine["energy"] == 0).mean() < 0.2
+    for k in ref:
+        ks = stats.ks_2samp(mine[k], ref[k])
+        assert ks.pvalue > 1e-3, (k, ks, np.median(mine[k]), np.median(ref[k]))
+
+
 def test_sample_many_equals_sequential_trajectories():
     """ora_sample_many (bench.py's trajectory-parallel CPU baseline: one single-threaded trajectory per OpenMP thread) is the same
     computation as ora_sample called once per seed (inference_base.py:644-657 runs the trajectories one after the other)."""
