@@ -99,11 +99,11 @@ def cpu_baseline(blob, cx, num_steps, repeats=2):
 
 
 def replayed_counters(args):
-    """Counters of the committed rocprofv3 --pmc run of this exact configuration (profiles/r05_traffic.json, tools/make_traffic_json.py;
+    """Counters of the committed rocprofv3 --pmc run of this exact configuration (profiles/r06_traffic.json, tools/make_traffic_json.py;
     collected as MI355X_MICROARCH.md prescribes: separate passes, FETCH_SIZE x 2 + WRITE_SIZE).  PMC counters cannot be read from inside
     this process: they are REPLAYED, per launch TYPE of the message kernel (full / ligand-only), and weighted here by the launch mix this
     run measures itself; absent for any other configuration."""
-    for name in ("r05_traffic.json", "r04_traffic.json"):      # the newest committed counter run of this configuration
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json"):      # the newest committed counter run of this configuration
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
@@ -120,11 +120,16 @@ def valu_issue(ctr, n_full, n_lig, rows_full, rows_lig, edge_ms):
     vector ALU can ISSUE, not by the matrix pipe it is priced against in `roofline.frac`.  Per launch type: T = 4 transcendentals
     per edge and channel (two SiLUs: v_exp + v_rcp each) / 64 lanes - from the algebra; the other VALU instructions = SQ_INSTS_VALU
     of the committed PMC pass - T - MFMAs, split packed / plain in the static proportion of the kernel's ISA
-    (profiles/r05_valu_mix.json, tools/valu_mix.py); each class priced at its measured issue cost per wave64 instruction and SIMD
+    (profiles/r06_valu_mix.json, tools/valu_mix.py); each class priced at its measured issue cost per wave64 instruction and SIMD
     at two waves per SIMD (tools/ubench).  frac = floor time / LIVE launch time (HIP events of this run)."""
-    try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r05_valu_mix.json")))
-    except OSError:
+    mix = None
+    for name in ("r06_valu_mix.json", "r05_valu_mix.json"):      # static ISA mix of the shipped kernel (tools/valu_mix.py)
+        try:
+            mix = json.load(open(os.path.join(ROOT, "profiles", name)))
+            break
+        except OSError:
+            continue
+    if mix is None:
         return None
     k, c = mix["k_edge_msg<1,1,0>"], mix["issue_cycles_per_wave64_instruction_at_2_waves_per_simd"]
     simds, clock = 256 * 4, c["clock_GHz"] * 1e9
@@ -146,7 +151,7 @@ def valu_issue(ctr, n_full, n_lig, rows_full, rows_lig, edge_ms):
             "by_launch_type": detail, "instruction_mix": {kk: k[kk] for kk in ("transcendental", "packed_f32", "packed_16", "plain", "mfma")},
             "issue_cycles": {kk: c[kk] for kk in ("transcendental", "packed_f32", "packed_16", "plain")},
             "source": "instruction counts: replayed SQ_INSTS_VALU (the committed counter run named in traffic_source) + algebra; class split: static ISA mix "
-                      "(profiles/r05_valu_mix.json); issue costs: tools/ubench on MI355X; time: live HIP events"}
+                      "(profiles/r06_valu_mix.json); issue costs: tools/ubench on MI355X; time: live HIP events"}
 
 
 def c5_line(engine, model, pk, num_steps):

@@ -173,9 +173,12 @@ int gemm_rows_per_tile();   // 64: the row tile of k_gemm_split (tiles of the fu
 // WITHOUT any LDS allocation can be placed on a CU whose LDS is entirely held by a 160 KiB workgroup of the message kernel of ANOTHER
 // complex handle (another stream, another hardware queue) - and then computed wrong values: k_edge_feat<0> returned theta bins of a
 // garbage N_i for scattered nodes in 11 of 12 concurrent calls, with GPU_MAX_HW_QUEUES <= 2 (both streams on one hardware queue) or
-// with as little as 64 bytes of LDS on the victim in 0 of 12.  The mechanism was not identified (no scratch, no LDS-DMA, no mode
-// change in either kernel; intra-stream serialisation does not help).  Every kernel of this library therefore holds at least a token
-// LDS allocation, which keeps it off CUs whose LDS is full.  DFM_TOKEN_LDS=0 restores the old launches (for reproducing the effect).
+// with as little as 64 bytes of LDS on the victim in 0 of 12.  r06 (profiles/r06_concurrency.txt): the wrong values come from ONE
+// instruction form - a packed fp32 VALU instruction with op_sel = [0,1], which hipcc's SLP vectoriser had made of the dihedral's cross
+// product - that miscomputes in such a wave (reproduced stand-alone, tools/pkmul_probe.py).  The library no longer contains the form
+// (-fno-slp-vectorize, audited by tests/test_abi_cpu.py); the token allocation stays as the second, independent fence: every kernel of
+// this library holds at least 64 bytes of LDS, which keeps it off CUs whose LDS is full.  DFM_TOKEN_LDS=0 restores the old launches
+// (for reproducing the effect together with tools/asm_variant.py).
 inline unsigned token_lds()
 {
     static const unsigned v = [] { const char *e = getenv("DFM_TOKEN_LDS"); return e ? (unsigned)atoi(e) : 64u; }();

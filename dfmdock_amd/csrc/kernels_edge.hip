@@ -878,7 +878,8 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
     // Results cannot depend on which wave runs a node: a task writes its own rows of agg / mbuf, nothing else.  The counters reset
     // themselves: every wave that had a task counts itself out on a second per-workgroup word when it leaves, and the last one out
     // stores zeros into both.
-    const bool dyn = !ROWS && !split && nsplit == 1 && p.task_ctr != nullptr;
+    // (AW16 = 0 - fp32 A_i: two more live registers per chunk - spills one register to scratch with the extra state: fixed stride there)
+    const bool dyn = AW16 != 0 && !ROWS && !split && nsplit == 1 && p.task_ctr != nullptr;
     uint32_t dyn_next = ~0u;      // index of the task after the current one, valid from the end of the epilogue that fetched it
     auto fetch_task = [&]() -> uint32_t {      // per-lane result of lane 0's atomic; consumed through readfirstlane
         uint32_t v = 0;

@@ -31,14 +31,16 @@
  * the next complex of a set overlaps the sampling of the current one
  * (dfmdock_amd/driver.py: run_set; the reference's loop is serial,
  * src/inference_mlsb.py:415-439).  One process per GPU.
- * Status of that guarantee (r05 / r06): concurrent handles once produced a silent miscompute - waves of an LDS-free, SLP-vectorised
- * geometry kernel binning wrong dihedrals from correct inputs while another handle's 160 KiB message-kernel workgroups were
- * resident; the mechanism was NOT identified (profiles/r05_concurrency.txt, profiles/r06_concurrency.txt).  It is fenced three ways:
- * every kernel launch of the library holds some LDS (token allocation), every translation unit is built with -fno-slp-vectorize
- * (csrc/Makefile), and dfmdock_amd/driver.py re-samples one complex alone after an overlapped run and compares bit for bit (falling
- * back to the serial driver on a mismatch).  tests/test_gpu_concurrency.py holds the shipped build to 0 deviations in a
- * victim x aggressor matrix over every kernel of the path.  A caller that needs no overlap loses nothing by driving its handles
- * from one thread.
+ * Status of that guarantee (r05 / r06): concurrent handles once produced a silent miscompute - waves of an LDS-free geometry kernel
+ * binning wrong dihedrals from correct inputs while another handle's 160 KiB message-kernel workgroups were resident.  r06 traced it to
+ * one instruction form hipcc's SLP vectoriser had emitted (a packed fp32 multiply with op_sel = [0,1]: low result from the HIGH half of
+ * source 1) and reproduced that form outside the engine: it is the hardware / runtime, not the engine's data flow
+ * (profiles/r06_concurrency.txt, tools/pkmul_probe.py).  Fenced three ways: no kernel of the library contains such an instruction
+ * (built with -fno-slp-vectorize, disassembly audited by tests/test_abi_cpu.py), every kernel launch holds some LDS (which alone
+ * removes the effect), and dfmdock_amd/driver.py re-samples one complex alone after an overlapped run and compares bit for bit
+ * (falling back to the serial driver on a mismatch).  tests/test_gpu_concurrency.py holds the shipped build to 0 deviations in a
+ * victim x aggressor matrix over every kernel of the path.  CALLERS that run their OWN kernels on the same GPU next to this library
+ * should know the form (tools/ubench/pkmul_victim.hip).
  * A model lives on the device that was current at dfm_model_create (dfm_set_device), a
  * complex on its model's device; every entry point switches to the handle's device for
  * the duration of the call and restores the caller's current device.

@@ -190,3 +190,46 @@ def test_no_compiler_made_packed_fp32_in_geometry_and_head_kernels():
         assert not bad, bad
     finally:
         shutil.rmtree(td, ignore_errors=True)
+
+
+def test_no_packed_instruction_reads_source1_high_half_for_its_low_result():
+    """r06 took the cross-handle miscompute of r05 down to one instruction form (profiles/r06_concurrency.txt): a packed fp32 VALU
+    instruction with op_sel = [0,1] - the LOW result reads the HIGH half of source 1 - returns wrong values in a wave that holds no LDS
+    while workgroups of the 16-bit message kernel are resident (stand-alone reproducer: tools/pkmul_probe.py; in the reference's
+    arithmetic it was the cross product of a dihedral, src/utils/coords6d.py:25-43, as hipcc's SLP vectoriser packed it).  The shipped
+    library contains NO packed instruction with an op_sel modifier at all (hand-written packed code uses op_sel_hi only, every
+    translation unit is built with -fno-slp-vectorize): this test disassembles every kernel of the code objects and keeps it so."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from dfmdock_amd import _lib
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(tools, "llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    td = tempfile.mkdtemp()
+    try:
+        lib = os.path.join(td, "lib.so")
+        shutil.copy(_lib.LIB_PATH, lib)
+        subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", lib], cwd=td, check=True, capture_output=True)
+        packed, bad, cur = 0, [], None
+        for f in sorted(os.listdir(td)):
+            if "gfx950" not in f:
+                continue
+            asm = subprocess.run([os.path.join(tools, "llvm-objdump"), "-d", os.path.join(td, f)], capture_output=True, text=True).stdout
+            for line in asm.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+                if m:
+                    cur = m.group(1)
+                    continue
+                m = re.search(r"\b(v_pk_\w+)\s+([^/]*)", line)
+                if not m:
+                    continue
+                packed += 1
+                sel = re.search(r"\bop_sel:\[([0-9,]+)\]", m.group(2))
+                if sel:      # any op_sel on a packed instruction; the known-bad pattern is source 0 low, source 1 high
+                    bad.append((cur, m.group(1), sel.group(0)))
+        assert packed > 2000, packed      # the audit saw the library's packed code (message, GEMM and pair kernels)
+        assert not bad, bad[:10]
+    finally:
+        shutil.rmtree(td, ignore_errors=True)

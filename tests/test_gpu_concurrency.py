@@ -1,7 +1,9 @@
 """Two complex handles driven at once from two host threads must not change each other's numbers (include/dfmdock_amd.h: "one stream
 per handle"; driver.run_set relies on it).  r05 found a silent miscompute here - waves of k_edge_feat<0> computing wrong theta bins
 while another handle's 160 KiB message-kernel workgroups were resident (profiles/r05_concurrency.txt) - and contained it (token LDS
-allocation on LDS-free kernels, no SLP vectorisation).  This file is the victim x aggressor matrix of that investigation as a test of
+allocation on LDS-free kernels, no SLP vectorisation); r06 traced it to one packed-fp32 instruction form (op_sel = [0,1]) that
+miscomputes under that co-residency even in a stand-alone kernel (profiles/r06_concurrency.txt) and removed the form from the library
+(static audit: tests/test_abi_cpu.py).  This file is the victim x aggressor matrix of that investigation as a test of
 the SHIPPED build: every cell must show 0 deviating calls.  What a victim call covers, kernel by kernel (reference path in brackets):
 
   sample mfma16 direct : k_prep_pose, k_knn_sample, k_edge_feat<0>, k_gemm_split, k_edge_msg<1,1,0>, k_edge_coord, k_heads
@@ -12,7 +14,8 @@ the SHIPPED build: every cell must show 0 deviating calls.  What a victim call c
                          h_first / h_last <- GEMMs + message kernels, f <- coordinate kernel + heads): says WHICH stage deviates first
   pair-family sample   : k_pair_head_m, k_pair_finish_s (src/models/egnn_net.py:430-482)
 
-tools/concurrency_probe*.py (r05) are folded into this file; DFM_TOKEN_LDS=0 with an -O3 build of kernels_geom.hip reproduces the effect.
+tools/concurrency_probe*.py (r05) are folded into this file; tools/concurrency_repro.py + tools/asm_variant.py reproduce the effect on purpose
+(DFM_TOKEN_LDS=0 with an SLP-vectorised kernels_geom.hip), tools/pkmul_probe.py outside the engine.
 """
 import threading
 

@@ -23,10 +23,11 @@ pmc() {    # pmc <dir> <kernel regex> <bench args...>: one --pmc set per run, ke
   python tools/pmc_summary.py $OUT/$dir > $OUT/$dir.txt 2>&1
 }
 if [ -z "$SKIP_TESTS" ]; then timeout 2400 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log; fi
+python tools/valu_mix.py > $OUT/valu_mix.txt 2>&1
 prof bench_prof python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fp32-line --no-c4-line --no-c5-line; tail -1 $OUT/bench_prof.log | cut -c1-200; head -12 $OUT/bench_prof_kernel_stats.csv | cut -c1-160
 pmc pmc_all 'k_edge_msg|k_l0_gather|k_gemm_split|k_edge_coord|k_knn_sample|k_edge_feat|k_heads' --batch 256 --num-steps 3
 python tools/make_traffic_json.py $OUT > $OUT/traffic_summary.txt 2>&1; cat $OUT/traffic_summary.txt
-cp $OUT/traffic.json profiles/r05_traffic.json      # so that the bench line below replays THIS run's counters
+cp $OUT/traffic.json profiles/r06_traffic.json      # so that the bench line below replays THIS run's counters
 timeout 900 python bench.py > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log | cut -c1-400
 pmc pmc_knn_c5 'k_knn_sample' --R 1000 --L 1000 --batch 32 --num-steps 3; grep -E "INSTS_VALU |ACTIVE_INST_VALU|GRBM" $OUT/pmc_knn_c5.txt
 prof c5 python $GRAFT_REPO_ROOT/bench.py --R 1000 --L 1000 --batch 32 --steps 1 --warmup 1 --no-cpu-baseline --no-fp32-line; tail -1 $OUT/c5.log | cut -c1-200; head -8 $OUT/c5_kernel_stats.csv | cut -c1-160

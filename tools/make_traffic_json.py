@@ -1,4 +1,4 @@
-"""From the counter passes of tools/final_profile.sh: the JSON bench.py replays into `roofline` and `kernels` (profiles/r05_traffic.json).
+"""From the counter passes of tools/final_profile.sh: the JSON bench.py replays into `roofline` and `kernels` (profiles/r06_traffic.json).
 
   edge.full / edge.lig_only   HBM bytes and pipe-busy fractions of ONE launch of the message kernel k_edge_msg<1,1,0>, separately for a
                               full launch (all nodes) and a last-layer launch over the ligand nodes only - bench.py weights them by the

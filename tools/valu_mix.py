@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static VALU instruction mix of a kernel of libdfmdock_amd.so, by class, from its gfx950 disassembly (llvm-objdump) ->
-profiles/r05_valu_mix.json.  bench.py prices the message kernel's VALU-issue floor with it:
+profiles/r06_valu_mix.json.  bench.py prices the message kernel's VALU-issue floor with it:
 
     floor = (T * c_T + P * c_P + Q * c_Q) / (SIMDs * clock)
 
@@ -53,7 +53,7 @@ def main():
         "transcendental": 12.18, "packed_f32": 6.26, "packed_16": 5.70, "plain": 3.16, "clock_GHz": 2.4,
         "source": "profiles/r01_ubench_valu_rate.txt, profiles/r02_ubench_valu_rate16.txt (tools/ubench/valu_rate*.hip on MI355X)"}
     out["method"] = __doc__.split("\n\n")[1].strip()
-    path = os.path.join(ROOT, "profiles", "r05_valu_mix.json")
+    path = os.path.join(ROOT, "profiles", "r06_valu_mix.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "top"} for k, v in out.items() if k.startswith("k_")}, indent=1))
 
