@@ -233,3 +233,72 @@ def test_no_packed_instruction_reads_source1_high_half_for_its_low_result():
         assert not bad, bad[:10]
     finally:
         shutil.rmtree(td, ignore_errors=True)
+
+
+def _split_top_level(argstr):
+    out, depth, cur = [], 0, ""
+    for ch in argstr:
+        if ch in "([{":      # (template arguments of a kernel are inside the parentheses the launch macro needs anyway)
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    out.append(cur.strip())
+    return out
+
+
+def test_every_kernel_launch_holds_some_lds():
+    """a kernel launched WITHOUT any LDS can be placed on a CU whose LDS another handle's message kernel holds entirely - the
+    one placement in which the packed-fp32 erratum of profiles/r06_concurrency.txt was ever observed.  Every hipLaunchKernelGGL of the
+    library must therefore either pass a dynamic LDS size that is not the literal 0 (token_lds() or a real size) or launch a kernel whose
+    code object has a static LDS segment; a new LDS-free launch fails here."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from dfmdock_amd import _lib
+    tools = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(tools, "llvm-readelf")):
+        pytest.skip("llvm-readelf not available")
+    static_lds = {}
+    td = tempfile.mkdtemp()
+    try:
+        lib = os.path.join(td, "lib.so")
+        shutil.copy(_lib.LIB_PATH, lib)
+        subprocess.run([os.path.join(tools, "llvm-objdump"), "--offloading", lib], cwd=td, check=True, capture_output=True)
+        for f in sorted(os.listdir(td)):
+            if "gfx950" not in f:
+                continue
+            notes = subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", os.path.join(td, f)], capture_output=True, text=True).stdout
+            for blk in notes.split("- .agpr_count:")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+                static_lds[name] = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1))
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    launches, bad = 0, []
+    csrc = os.path.join(ROOT, "dfmdock_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith(".hip"):
+            continue
+        txt = open(os.path.join(csrc, fn)).read()
+        for m in re.finditer(r"hipLaunchKernelGGL\(", txt):
+            i, depth = m.end(), 1
+            while depth:
+                depth += {"(": 1, ")": -1}.get(txt[i], 0)
+                i += 1
+            args = _split_top_level(txt[m.end():i - 1])
+            launches += 1
+            if args[3] != "0":
+                continue
+            full = re.sub(r"[()\s]", "", args[0])
+            kern = full.split("<")[0].split("::")[-1]
+            targs = re.match(r"[^<]*<([0-9,]+)>$", full)      # literal template arguments select ONE instantiation (k_edge_feat<1> has static LDS, <0> is launched with the token)
+            mangled = kern + ("I" + "".join(f"Li{a}E" for a in targs.group(1).split(",")) + "E" if targs else "")
+            insts = {n: v for n, v in static_lds.items() if re.search(r"\d+" + re.escape(mangled) + (r"" if targs else r"(I|E|P|N|\b)"), n)}
+            if not insts or min(insts.values()) == 0:
+                bad.append((fn, kern, insts))
+    assert launches >= 30, launches
+    assert not bad, bad
