@@ -296,7 +296,7 @@ def test_every_kernel_launch_holds_some_lds():
             full = re.sub(r"[()\s]", "", args[0])
             kern = full.split("<")[0].split("::")[-1]
             targs = re.match(r"[^<]*<([0-9,]+)>$", full)      # literal template arguments select ONE instantiation (k_edge_feat<1> has static LDS, <0> is launched with the token)
-            mangled = kern + ("I" + "".join(f"Li{a}E" for a in targs.group(1).split(",")) + "E" if targs else "")
+            mangled = kern + ("I" + "".join(f"Li{a}E" for a in targs.group(1).split(",")) if targs else "")      # (prefix: defaulted template parameters follow)
             insts = {n: v for n, v in static_lds.items() if re.search(r"\d+" + re.escape(mangled) + (r"" if targs else r"(I|E|P|N|\b)"), n)}
             if not insts or min(insts.values()) == 0:
                 bad.append((fn, kern, insts))
