@@ -1292,6 +1292,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             }
 #endif
         }
+        if (!p.no_agg) {      // (the ligand-only last layer has no reader for the segment sums: its launches skip them, r06)
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
             f2 cs = {0.f, 0.f};
@@ -1303,6 +1304,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             float xt = (t + __shfl_xor(t, 32, 64)) * p.inv_s;
             asm volatile("" : "+v"(xt));
             colsum[nt] += xt;
+        }
         }
         if (split || mt == ntile - 1) {
             // The lane term of this address is re-derived HERE (v_mbcnt_lo = the lane index for the storing half-wave h == 0; the
