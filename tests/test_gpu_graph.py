@@ -74,11 +74,18 @@ def test_graph_pair_family(blob_pair):
     g.close(); m.close()
 
 
+DYN_CASES = [(24, 150, 110, 5), (9, 301, 160, 3), (17, 129, 131, 3), (8, 380, 213, 2)]      # (B, R, L, steps): >= 2 node tasks per wave, ragged sizes
+
+
+def _dyn_case(g, B, steps):
+    return g.sample(B=B, num_steps=steps, seed=21, mfma16=True)
+
+
 def test_graph_and_dynamic_tasks_on_a_large_launch(blob):
     """r06: the message kernel's waves take their tasks from per-workgroup counters that reset themselves at the end of every launch
-    (no memset node, no host-side state), so a REPLAYED step graph and plain launches run the same kernel the same way.  At a size where
-    dynamic tasks engage (B >= 8 and at least two node tasks per wave: 24 x 260 = 6240 tasks over 2048 waves): graph == plain launches ==
-    the fixed stride of r01-r05 (DFM_EDGE_DYNAMIC=0 in a child process), bit for bit - a node's rows do not depend on which wave computes them
+    (no memset node, no host-side state), so a REPLAYED step graph and plain launches run the same kernel the same way.  At sizes where
+    dynamic tasks engage (B >= 8 and at least two node tasks per wave; ragged B / R / L included): graph == plain launches == the fixed
+    stride of r01-r05 (DFM_EDGE_DYNAMIC=0 in a child process), bit for bit - a node's rows do not depend on which wave computes them
     (reference: the trajectories of Euler_Maruyama_sampler are independent, src/inference_base.py:390-468)."""
     import json, os, subprocess, sys
     from conftest import ROOT
@@ -86,21 +93,29 @@ def test_graph_and_dynamic_tasks_on_a_large_launch(blob):
     from dfmdock_amd.synthetic import make_complex
     engine.set_device(0)
     m = engine.Model(blob)
-    cx = make_complex(150, 110, seed=12)
-    g = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
-    a = g.sample(B=24, num_steps=5, seed=21, mfma16=True, graph=True)
-    b = g.sample(B=24, num_steps=5, seed=21, mfma16=True)
-    c = g.sample(B=24, num_steps=5, seed=21, mfma16=True, graph=True)      # the replayed graph again: the counters were left at zero
-    assert same(a, b) and same(a, c) and np.isfinite(a["lig_pos"]).all()
-    g.close(); m.close()
-    code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+    mine = []
+    for k, (B, R, L, steps) in enumerate(DYN_CASES):
+        cx = make_complex(R, L, seed=12 + k)
+        g = engine.Complex(m, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
+        a = g.sample(B=B, num_steps=steps, seed=21, mfma16=True, graph=True)
+        b = _dyn_case(g, B, steps)
+        c = g.sample(B=B, num_steps=steps, seed=21, mfma16=True, graph=True)      # the replayed graph again: the counters were left at zero
+        assert same(a, b) and same(a, c) and np.isfinite(a["lig_pos"]).all(), (B, R, L)
+        mine.append(b)
+        g.close()
+    m.close()
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "from dfmdock_amd import engine\nfrom dfmdock_amd.synthetic import make_complex\n"
             "from dfmdock_amd.weights import make_random_weights, pack_blob\n"
-            "engine.set_device(0); m = engine.Model(pack_blob(make_random_weights(0))); cx = make_complex(150, 110, seed=12)\n"
-            "g = engine.Complex(m, cx['rec_x'], cx['lig_x'], cx['rec_pos'], cx['lig_pos'])\n"
-            "r = g.sample(B=24, num_steps=5, seed=21, mfma16=True)\n"
-            "print(json.dumps({'lig': r['lig_pos'].astype(np.float64).tolist(), 'e': r['energy'].astype(np.float64).tolist()}))\n" % ROOT)
-    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DFM_EDGE_DYNAMIC="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            "engine.set_device(0); m = engine.Model(pack_blob(make_random_weights(0))); out = []\n"
+            "for k, (B, R, L, steps) in enumerate(%r):\n"
+            "    cx = make_complex(R, L, seed=12 + k)\n"
+            "    g = engine.Complex(m, cx['rec_x'], cx['lig_x'], cx['rec_pos'], cx['lig_pos'])\n"
+            "    r = g.sample(B=B, num_steps=steps, seed=21, mfma16=True)\n"
+            "    out.append({'lig': r['lig_pos'].astype(np.float64).tolist(), 'e': r['energy'].astype(np.float64).tolist()}); g.close()\n"
+            "print(json.dumps(out))\n" % (ROOT, os.path.join(ROOT, "tests"), DYN_CASES))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DFM_EDGE_DYNAMIC="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     st = json.loads(p.stdout.decode().strip().splitlines()[-1])
-    assert np.array_equal(np.asarray(st["lig"], np.float32), a["lig_pos"]) and np.array_equal(np.asarray(st["e"], np.float32), a["energy"])
+    for k, r in enumerate(mine):
+        assert np.array_equal(np.asarray(st[k]["lig"], np.float32), r["lig_pos"]) and np.array_equal(np.asarray(st[k]["e"], np.float32), r["energy"]), DYN_CASES[k]
