@@ -34,10 +34,10 @@
  * Status of that guarantee (r05 / r06): concurrent handles once produced a silent miscompute - waves of an LDS-free geometry kernel
  * binning wrong dihedrals from correct inputs while another handle's 160 KiB message-kernel workgroups were resident.  r06 traced it to
  * one instruction form hipcc's SLP vectoriser had emitted (a packed fp32 multiply with op_sel = [0,1]: low result from the HIGH half of
- * source 1) and reproduced that form outside the engine: it is the hardware / runtime, not the engine's data flow
- * (profiles/r06_concurrency.txt, tools/pkmul_probe.py).  Fenced three ways: no kernel of the library contains such an instruction
- * (built with -fno-slp-vectorize, disassembly audited by tests/test_abi_cpu.py), every kernel launch holds some LDS (which alone
- * removes the effect), and dfmdock_amd/driver.py re-samples one complex alone after an overlapped run and compares bit for bit
+ * source 1) and reproduced it without the engine: while one wave of a SIMD executes a 16-bit-input MFMA, such an instruction issued by
+ * another wave of that SIMD returns wrong values (profiles/r06_concurrency.txt, tools/ubench/pk_erratum.hip) - hardware, not data flow.  Fenced three ways: no kernel of the library contains such an instruction
+ * (built with -fno-slp-vectorize, disassembly audited by tests/test_abi_cpu.py: THE fence), every kernel launch holds some LDS (keeps
+ * it off CUs that a message kernel's workgroup fills), and dfmdock_amd/driver.py re-samples one complex alone after an overlapped run and compares bit for bit
  * (falling back to the serial driver on a mismatch).  tests/test_gpu_concurrency.py holds the shipped build to 0 deviations in a
  * victim x aggressor matrix over every kernel of the path.  CALLERS that run their OWN kernels on the same GPU next to this library
  * should know the form (tools/ubench/pkmul_victim.hip).
