@@ -24,8 +24,37 @@ template <int FORM> __global__ __launch_bounds__(256) void k_victim(const f2 *__
         if (FORM == 0) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=&v"(o) : "v"(a), "v"(b));          // the failing form
         if (FORM == 1) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(o) : "v"(a), "v"(b));       // the library's form
         if (FORM == 2) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=&v"(o) : "v"(a), "v"(b));
+        if (FORM >= 3) {      // the other VOP3P forms the library's message kernel executes next to its partner wave's MFMAs all the time
+            const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(b0.x, b0.y));      // (lo, hi) fp16 of b
+            const float blo = (float)__builtin_bit_cast(_Float16, (unsigned short)(hb & 0xffffu)), bhi = (float)__builtin_bit_cast(_Float16, (unsigned short)(hb >> 16));
+            if (FORM == 3) { e = (f2){a0.x + blo, a0.y + bhi};      // add_half_lo / add_half_hi
+                asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(o.x) : "v"(hb), "v"(a.x));
+                asm volatile("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(o.y) : "v"(hb), "v"(a.y)); }
+            if (FORM == 4) { e = (f2){__builtin_fmaf(a0.x, a0.y, blo), __builtin_fmaf(a0.y, a0.x, bhi)};      // fma_half_lo / fma_half_hi
+                asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1]" : "=&v"(o.x) : "v"(a.x), "v"(a.y), "v"(hb));
+                asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=&v"(o.y) : "v"(a.y), "v"(a.x), "v"(hb)); }
+            if (FORM == 5) { e = (f2){__builtin_fmaf(a0.x, b0.x, b0.x), __builtin_fmaf(a0.y, b0.x, b0.x)};      // v_pk_fma_f32 op_sel_hi:[1,0,0]
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel_hi:[1,0,0]" : "=&v"(o) : "v"(a), "v"(b)); }
+            if (FORM == 6) { e = (f2){__builtin_fmaf(a0.x, b0.x, b0.x), __builtin_fmaf(a0.x, b0.y, b0.y)};      // v_pk_fma_f32 op_sel_hi:[0,1,1]
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %2 op_sel_hi:[0,1,1]" : "=&v"(o) : "v"(a), "v"(b)); }
+            if (FORM == 7) { e = (f2){a0.x + 1.0f, a0.y + 1.0f};                                                  // v_pk_add_f32 with an inline constant, op_sel_hi:[1,0]
+                asm volatile("v_pk_add_f32 %0, %1, 1.0 op_sel_hi:[1,0]" : "=&v"(o) : "v"(a)); }
+            if (FORM == 8) {      // v_pk_add_f16 / v_pk_max_f16 op_sel_hi:[1,0] on packed halves, checked bit for bit against per-half arithmetic
+                const unsigned ha = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0.x, a0.y));
+                const _Float16 al = __builtin_bit_cast(_Float16, (unsigned short)(ha & 0xffffu)), ah2 = __builtin_bit_cast(_Float16, (unsigned short)(ha >> 16));
+                const _Float16 bl = __builtin_bit_cast(_Float16, (unsigned short)(hb & 0xffffu)), bh2 = __builtin_bit_cast(_Float16, (unsigned short)(hb >> 16));
+                const _Float16 s0 = al + bl, s1 = ah2 + bh2;
+                const _Float16 m0 = s0 > bl ? s0 : bl, m1 = s1 > bl ? s1 : bl;
+                e = (f2){(float)m0, (float)m1};
+                unsigned r1, r2;
+                asm volatile("v_pk_add_f16 %0, %1, %2" : "=&v"(r1) : "v"(ha), "v"(hb));
+                asm volatile("v_pk_max_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=&v"(r2) : "v"(r1), "v"(hb));
+                o = (f2){(float)__builtin_bit_cast(_Float16, (unsigned short)(r2 & 0xffffu)), (float)__builtin_bit_cast(_Float16, (unsigned short)(r2 >> 16))}; }
+            asm volatile("" : "+v"(e));
+        }
         wrong += (__float_as_uint(o.x) != __float_as_uint(e.x)) || (__float_as_uint(o.y) != __float_as_uint(e.y));
-        b = (f2){e.y * 0.5f + 0.3f, e.x * 0.5f + 0.2f};
+        b = (f2){e.y * 0.25f + 0.3f, e.x * 0.25f + 0.2f};
+        b.x = b.x > 4.0f ? 0.5f : b.x; b.y = b.y > 4.0f ? 0.75f : b.y;
         a = (f2){a0.y, a0.x};
     }
     if (wrong) atomicAdd(bad, (unsigned long long)wrong);
@@ -76,7 +105,7 @@ template <int MIX> __global__ __launch_bounds__(512) void k_aggr(float *out, int
 }
 
 static const long long N = 948000;
-int main()
+int main(int argc, char **)
 {
     std::vector<f2> a(N), b(N);
     unsigned sd = 12345u;
@@ -92,8 +121,10 @@ int main()
                            "v_mfma_f32_32x32x16_f16", "DPP add + ds_swizzle + ds_bpermute", "v_fma_mix_f32", "v_pk_add_f16 + v_pk_max_f16 op_sel_hi:[1,0]", "v_cvt_pkrtz_f16_f32",
                            "everything together", "v_exp_f32 + v_rcp_f32", "LDS reads", "v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x2_f32", "v_mfma_f32_16x16x32_f16"};
     void (*ks[])(float *, int, volatile int *) = {k_aggr<0>, k_aggr<1>, k_aggr<2>, k_aggr<3>, k_aggr<4>, k_aggr<5>, k_aggr<6>, k_aggr<7>, k_aggr<8>, k_aggr<9>, k_aggr<10>, k_aggr<11>, k_aggr<12>, k_aggr<13>, k_aggr<14>, k_aggr<15>};
+    const bool only_mfma = argc > 1;
     for (int mix = -1; mix < 16; ++mix) {
-        for (int lds_try = 0; lds_try < 2; ++lds_try) {
+        if (only_mfma && !(mix < 0 || mix == 5 || mix == 13)) continue;
+        for (int lds_try = 0; lds_try < (only_mfma ? 1 : 2); ++lds_try) {
             const int lds = lds_try == 0 ? LDS : 64 * 1024;
             if (mix < 0 && lds_try) continue;
             *dstop = 0;
@@ -101,8 +132,8 @@ int main()
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ks[mix]), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
                 hipLaunchKernelGGL(ks[mix], dim3(cus), dim3(512), lds, sa, dout, 1 << 30, dstop);
             }
-            const bool mfma = mix == 5 || mix == 13 || mix == 14 || mix == 15;
-            for (int form = 0; form < (mfma ? 3 : 1); ++form) for (int vlds = 0; vlds <= (mfma && form == 0 ? 64 : 0); vlds += 64) {
+            const bool mfma = mix < 0 || mix == 5 || mix == 13 || mix == 14 || mix == 15;      // (no aggressor: every victim form must be clean)
+            for (int form = 0; form < (mfma ? 9 : 1); ++form) for (int vlds = 0; vlds <= (mfma && form == 0 ? 64 : 0); vlds += 64) {
                 int bad_launches = 0; long long tot = 0;
                 for (int r = 0; r < 32; ++r) {
                     (void)hipMemsetAsync(dbad, 0, 8, sv);
@@ -110,13 +141,20 @@ int main()
                     if (form == 0) hipLaunchKernelGGL(k_victim<0>, g, bl, vlds, sv, dA, dB, N, dbad, 64);
                     if (form == 1) hipLaunchKernelGGL(k_victim<1>, g, bl, vlds, sv, dA, dB, N, dbad, 64);
                     if (form == 2) hipLaunchKernelGGL(k_victim<2>, g, bl, vlds, sv, dA, dB, N, dbad, 64);
+                    if (form == 3) hipLaunchKernelGGL(k_victim<3>, g, bl, vlds, sv, dA, dB, N, dbad, 64);
+                    if (form == 4) hipLaunchKernelGGL(k_victim<4>, g, bl, vlds, sv, dA, dB, N, dbad, 64);
+                    if (form == 5) hipLaunchKernelGGL(k_victim<5>, g, bl, vlds, sv, dA, dB, N, dbad, 64);
+                    if (form == 6) hipLaunchKernelGGL(k_victim<6>, g, bl, vlds, sv, dA, dB, N, dbad, 64);
+                    if (form == 7) hipLaunchKernelGGL(k_victim<7>, g, bl, vlds, sv, dA, dB, N, dbad, 64);
+                    if (form == 8) hipLaunchKernelGGL(k_victim<8>, g, bl, vlds, sv, dA, dB, N, dbad, 64);
                     unsigned long long hbad = 0;
                     (void)hipMemcpyAsync(&hbad, dbad, 8, hipMemcpyDeviceToHost, sv);
                     (void)hipStreamSynchronize(sv);
                     if (hbad) { ++bad_launches; tot += (long long)hbad; }
                 }
                 printf("aggressor %-46s LDS %3d KiB | victim %-28s LDS %2d B: wrong in %2d of 32 launches (%lld element-rounds)\n", mix < 0 ? "none" : names[mix], mix < 0 ? 0 : lds / 1024,
-                       form == 0 ? "v_pk_mul_f32 op_sel:[0,1]" : (form == 1 ? "v_pk_mul_f32 op_sel_hi:[1,0]" : "v_pk_mul_f32 plain"), vlds, bad_launches, tot);
+                       form == 0 ? "v_pk_mul_f32 op_sel:[0,1]" : (form == 1 ? "v_pk_mul_f32 op_sel_hi:[1,0]" : (form == 2 ? "v_pk_mul_f32 plain" : (form == 3 ? "v_fma_mix (f16 lo / hi) + f32" :
+                       (form == 4 ? "v_fma_mix f32*f32 + f16 lo/hi" : (form == 5 ? "v_pk_fma_f32 op_sel_hi:[1,0,0]" : (form == 6 ? "v_pk_fma_f32 op_sel_hi:[0,1,1]" : (form == 7 ? "v_pk_add_f32 1.0 op_sel_hi" : "v_pk_add_f16 + v_pk_max_f16"))))))), vlds, bad_launches, tot);
                 fflush(stdout);
             }
             *dstop = 1;
