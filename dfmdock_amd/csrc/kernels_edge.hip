@@ -1415,6 +1415,19 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_coord(EdgeKArgs p)
     int b = 0, i = 0, mt = 0;
     while (tt < ntask && !task_node(tt, b, i)) tt += tstride;
     if (tt >= ntask) return;
+    // dynamic tasks as in k_edge_msg (r06): the workgroup's share of the task list, taken in order from a per-workgroup counter; the fetch
+    // for the task after the current one is issued right behind a tile's neighbour-coordinate load (the youngest load at that point, so no
+    // earlier load waits for it) and read at the top of the next tile
+    const bool dyn = nsplit == 1 && p.task_ctr != nullptr;
+    uint32_t dyn_next = ~0u, fetched = 0;
+    auto fetch_task = [&]() -> uint32_t {
+        uint32_t v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(p.task_ctr + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    };
+    auto dyn_index = [&](uint32_t pos) -> uint32_t { return (uint32_t)slot + (uint32_t)wg_per_xcd * ((uint32_t)EDGE_WAVES + pos); };
+    if (dyn && ntile == 1) dyn_next = dyn_index((uint32_t)__builtin_amdgcn_readfirstlane((int)fetch_task()));
+    bool fetch_pending = false;
     float cacc0 = 0.f, cacc1 = 0.f, cacc2 = 0.f;   // sum_s cdiff * w of the open node
     bool more = true;
     uint4 cur[16];
@@ -1423,11 +1436,24 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_coord(EdgeKArgs p)
         unsigned ntt = tt;
         int nb_ = b, ni = i, nmt = mt + 1;
         bool have_next = true;
-        if (nmt == ntile) {
-            nmt = 0; ntt = tt + tstride;
-            while (ntt < ntask && !task_node(ntt, nb_, ni)) ntt += tstride;
-            have_next = ntt < ntask;
+        if (fetch_pending) {      // the fetch issued during the previous tile
+            uint32_t got;
+            asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(got) : "v"(fetched));
+            dyn_next = dyn_index(got);
+            fetch_pending = false;
         }
+        if (nmt == ntile) {
+            nmt = 0;
+            if (dyn) {
+                ntt = dyn_next;
+                have_next = ntt < ntask && task_node(ntt, nb_, ni);
+            } else {
+                ntt = tt + tstride;
+                while (ntt < ntask && !task_node(ntt, nb_, ni)) ntt += tstride;
+                have_next = ntt < ntask;
+            }
+        }
+        const bool fetch_now = dyn && have_next && nmt == ntile - 1;      // the next tile is the last of its task
         const uint4 *Mn = tile_ptr(have_next ? nb_ : b, have_next ? ni : i, have_next ? nmt : mt);      // (last tile: re-reads itself, unused)
         const size_t node = (size_t)b * p.N + i;
         const size_t ebase = node * K;
@@ -1469,7 +1495,10 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_coord(EdgeKArgs p)
                         cur[m >> 2] = make_uint4(v.x, v.y, v.z, v.w);
                     }
                 }
-                if (hf == 0 && g == 0) c_xj = p.ca4[(size_t)b * p.N + c_j];     // the edge index has landed under the first 32 MFMAs
+                if (hf == 0 && g == 0) {
+                    c_xj = p.ca4[(size_t)b * p.N + c_j];     // the edge index has landed under the first 32 MFMAs
+                    if (fetch_now) { fetched = fetch_task(); fetch_pending = true; }
+                }
                 __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting the next group's reads (spills)
             }
             // bias k-step: acc += 1 * hi + 1 * lo (the accumulators were opened with C = 0)
@@ -1526,6 +1555,15 @@ __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_coord(EdgeKArgs p)
     };
     load_tile(tile_ptr(b, i, 0), cur);
     while (more) tile_step();
+    if (dyn && lane == 0) {      // count this wave out; the last one of the workgroup leaves the counters zeroed for the next launch
+        uint32_t active = 0;
+        for (int w = 0; w < EDGE_WAVES; ++w) active += (uint32_t)w * (uint32_t)wg_per_xcd + (uint32_t)slot < ntask ? 1u : 0u;
+        const uint32_t gone = __hip_atomic_fetch_add(p.task_ctr + TASK_CTR_WGS + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone + 1u == active) {
+            __hip_atomic_store(p.task_ctr + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.task_ctr + TASK_CTR_WGS + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1647,8 +1685,10 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
 
 hipError_t launch_coord_bf16(const EdgeArgs &a, hipStream_t s)
 {
-    const EdgeKArgs k = to_kargs_mfma(a, 1);
+    EdgeKArgs k = to_kargs_mfma(a, 1);
     const long long tasks = (long long)a.B * (a.N - a.R);
+    static const bool off = [] { const char *e = getenv("DFM_EDGE_DYNAMIC"); return e && atoi(e) == 0; }();
+    if (!off && a.task_ctr && a.B >= 8 && tasks >= 2 * (long long)device_cus() * EDGE_WAVES && device_cus() <= TASK_CTR_WGS) k.task_ctr = a.task_ctr;
     return a.f16 ? launch_coord_t<1>(k, tasks, s) : launch_coord_t<0>(k, tasks, s);
 }
 
