@@ -122,6 +122,17 @@ def db5_complex(cid):
 
 
 REAL_ESM_IDS = ("1QA9", "1AVX", "1H1V", "7CEI")      # DB5 complexes whose ESM-2 block is committed (fp16)
+# the other 20: ESM-2 block committed as int8 + one fp16 scale per residue (tests/golden/make_golden_r06.py; the goldens were generated
+# on the DEQUANTISED values, which both sides use)
+Q8_ESM_IDS = ("1HCF", "1IRA", "1JIW", "1JPS", "1MLC", "1NW9", "1VFB", "1ZHI", "2A1A", "2A9K", "2AYO", "2SIC", "2SNI", "2VDB", "3SZK", "4POU",
+              "5C7X", "5HGG", "5JMO", "6B0S")
+_q8 = None
+
+
+def q8_golden(cid):
+    """The reference's evaluation of `cid` on its dequantised ESM block (fwd_esmq_db5.npz: keys <id>/<name>)."""
+    g = load_golden("fwd_esmq_db5.npz")
+    return {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith(cid + "/")}
 
 
 def real_db5_complex(cid):
@@ -134,6 +145,19 @@ def real_db5_complex(cid):
         d = load_golden("cx_7CEI.npz")
         return dict(cx, id=cid, rec_seq=str(d["rec_seq"]), lig_seq=str(d["lig_seq"]))
     db5_ids()
+    if cid in Q8_ESM_IDS:
+        global _q8
+        if _q8 is None:
+            _q8 = load_golden("esm_db5_q8.npz")
+        x = _q8[cid + "_q"].astype(np.float32) * _q8[cid + "_s"].astype(np.float32)[:, None]
+        out, R = {"id": cid}, len(str(_db5[f"{cid}_rec_seq"]))
+        for side, blk in (("rec", x[:R]), ("lig", x[R:])):
+            seq = str(_db5[f"{cid}_{side}_seq"])
+            assert blk.shape[0] == len(seq)
+            out[side + "_x"] = np.concatenate([blk, seq_to_onehot(seq)], 1)
+            out[side + "_pos"] = _db5[f"{cid}_{side}_pos"]
+            out[side + "_seq"] = seq
+        return out
     e = load_golden(f"esm_{cid}.npz")
     out = {"id": cid}
     for side in ("rec", "lig"):

@@ -166,3 +166,58 @@ def test_selfcheck_on_real_features(cid, model):
         assert r["ok"] and r["range_ok"] and r["dev_ok"], line
         assert r["saturated"] == 0 and r["headroom"] >= 4.0, line
     gx.close()
+
+
+# ---- the other 20 DB5 test complexes: ESM-2 blocks committed as int8 + per-residue scale (tests/golden/make_golden_r06.py) -----------
+from conftest import Q8_ESM_IDS, q8_golden  # noqa: E402
+
+
+SELFCHECK_OVER_GATE = {"1JPS"}
+
+
+@pytest.mark.parametrize("cid", Q8_ESM_IDS)
+def test_all_db5_complexes_on_esm_features(cid, model, blob):
+    """VERDICT r05 "missing" 4: every complex of the DB5 test set now runs on ESM-2 features (the reference's loader:
+    src/datasets/ppi_dataset.py:249-265), 4 as fp16 blocks (above), these 20 quantised to int8 per residue - both sides use the
+    dequantised values.  One reference evaluation each (src/models/score_net_mlsb.py:343-425): fp32 engine at 1e-4 (bins element by
+    element, <= 2 boundary flips, then held to the oracle on the engine's own bins), 16-bit engine direct and through the layer-0 table at
+    1e-2 / 3e-2, and the run-time self-check of the 16-bit engine: nothing saturated, fp16 headroom >= 4, OK on 19 - and on 1JPS a
+    deviation verdict that sends the driver to the fp32 engine."""
+    from dfmdock_amd import engine
+    from oracle import oracle as ora
+    g = q8_golden(cid)
+    gx, cx = _gx(model, cid)
+    e, t = g["edges"].astype(np.int32), float(g["t"])
+    r32 = gx.score(g["lig_pos"], t, edges=e, energy=True, debug=True)
+    flips = r32["bins"][0] != g["bins"]
+    assert flips.sum() <= 2, int(flips.sum())
+    np.testing.assert_array_equal(r32["relpos"][0], g["relpos"])
+    ref = {k: g[k] for k in ("f", "tr_score", "rot_score", "energy", "num_clashes")}
+    if flips.any():
+        o = ora.Oracle(blob, cx).score(g["lig_pos"], t, edges=e, bins=r32["bins"][0])
+        ref = {k: o[k] for k in ("f", "tr_score", "rot_score", "energy", "num_clashes")}
+    for name, r, tol, etol in (("fp32", r32, 1e-4, 1e-4),
+                               ("mfma16", gx.score(g["lig_pos"], t, edges=e, energy=True, mfma16=True), 1e-2, 3e-2),
+                               ("mfma16+table", gx.score(g["lig_pos"], t, edges=e, energy=True, mfma16=True, l0_table=True), 1e-2, 3e-2)):
+        assert rel_inf(r["f"][0], ref["f"]) < tol, (cid, name, "f", rel_inf(r["f"][0], ref["f"]))
+        assert rel_inf(r["tr_score"][0], np.asarray(ref["tr_score"]).reshape(3)) < tol, (cid, name, "tr_score")
+        assert rel_inf(r["rot_score"][0], np.asarray(ref["rot_score"]).reshape(3)) < tol, (cid, name, "rot_score")
+        e_ref = float(ref["energy"])
+        assert abs(float(r["energy"][0]) - e_ref) < (etol * max(abs(e_ref), 0.1) if etol > 1e-3 else 1e-4), (cid, name, "energy")
+        assert int(r["num_clashes"][0]) == int(ref["num_clashes"]), (cid, name)
+    assert float(np.abs(r32["h_last"]).max()) == pytest.approx(float(g["h_absmax"][-1]), rel=1e-4)
+    sc = gx.selfcheck(n_eval=2, seed=3, precision="mfma16")
+    line = engine.format_selfcheck(sc, cid)
+    assert sc["range_ok"] and sc["saturated"] == 0 and sc["headroom"] >= 4.0, line
+    if cid in SELFCHECK_OVER_GATE:
+        # the one complex of the 24 whose NATIVE pose (what the self-check draws its graphs around) puts the 16-bit engine's per-residue
+        # output past the 1e-2 gate on this weight draw (1.27e-2; profiles/r06_selfcheck_db5.txt) although the reference pose above
+        # is inside it: the check must say so, and the driver must then run this complex on the fp32 engine, not carry on in 16 bit
+        from dfmdock_amd import driver
+        assert not sc["ok"] and not sc["dev_ok"] and sc["gate_f"] < sc["dev_f"] < 2e-2, line
+        said = []
+        used, _ = driver.checked_precision(gx, "mfma16", cid, log=said.append, seed=3)
+        assert used == "fp32" and any("fp32 engine" in m for m in said), (used, said)
+    else:
+        assert sc["ok"], line
+    gx.close()

@@ -335,6 +335,31 @@ def test_score_matches_reference_real_esm(case, blob):
     assert rel_inf(r["ires"], g["ires"][:, 0]) < 1e-4
 
 
+def test_score_matches_reference_on_the_other_twenty_db5_complexes(blob):
+    """The 20 DB5 test complexes without a committed fp16 block, on their ESM-2 features quantised to int8 per residue
+    (tests/golden/make_golden_r06.py: both sides use the dequantised values): one reference evaluation each at a noised pose, the same
+    checks as above (bins element by element, <= 2 boundary flips re-evaluated on the reference's bins, everything else at 1e-4)."""
+    from conftest import Q8_ESM_IDS, q8_golden, real_db5_complex
+    flips_total = 0
+    for cid in Q8_ESM_IDS:
+        g = q8_golden(cid)
+        o = ora.Oracle(blob, real_db5_complex(cid))
+        e = g["edges"].astype(np.int32)
+        r = o.score(g["lig_pos"], float(g["t"]), edges=e)
+        flips = r["bins"] != g["bins"]
+        assert flips.sum() <= 2, (cid, int(flips.sum()))
+        flips_total += int(flips.sum())
+        if flips.any():
+            r = o.score(g["lig_pos"], float(g["t"]), edges=e, bins=g["bins"])
+        np.testing.assert_array_equal(r["relpos"], g["relpos"])
+        assert r["num_clashes"] == int(g["num_clashes"]), cid
+        assert rel_inf(r["f"], g["f"]) < 1e-4, (cid, rel_inf(r["f"], g["f"]))
+        assert rel_inf(r["tr_score"], g["tr_score"]) < 1e-4 and rel_inf(r["rot_score"], g["rot_score"]) < 1e-4, cid
+        assert abs(float(r["energy"]) - float(g["energy"])) < 1e-4, cid
+        np.testing.assert_allclose(np.abs(r["h_layers"]).reshape(o.hp.depth, -1).max(1), g["h_absmax"], rtol=1e-4)
+    assert flips_total <= 6
+
+
 @pytest.mark.parametrize("case", ["fwd2_esm_1QA9", "fwd2_esm_1AVX", "fwd2_esm_1H1V"])
 def test_pair_family_matches_reference_real_esm(case, blob_pair):
     """Second model family on the REAL ESM-2 feature blocks (tests/golden/make_golden_r05.py pair).  No per-edge bins in these
