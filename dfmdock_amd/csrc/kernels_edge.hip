@@ -236,6 +236,17 @@ constexpr int LDS_WF_BYTES = 16 * 8 * 64 * 16;     // 131072: bf16 B-fragments o
 constexpr int LDS_STAGE_BYTES = 32 * 64 * 2;       // 4096 per wave: 32 rows x 64 channels bf16
 constexpr int EDGE_WAVES = DFM_EDGE_WAVES;         // waves per workgroup: 8 = two per SIMD (256 registers each), 4 = one per SIMD (512)
 constexpr int LDS_EDGE_BYTES = LDS_WF_BYTES + EDGE_WAVES * LDS_STAGE_BYTES;   // 163840 = the whole CU with 8 waves
+// Diagnostic build (WRONG RESULTS BY DESIGN, r06): DFM_EDGE_HALF = the per-wave work of a kernel in which TWO waves share a 32-row tile
+// (each: 16 of the 32 producer rows, 128 of the 256 output columns = 64 accumulators) without the pair's hand-shakes; DFM_MSG_WAVES waves
+// per workgroup run it (12 = three per SIMD at <= 168 registers; staging areas of waves >= 8 alias those of waves 0..3: timing only).
+#ifndef DFM_EDGE_HALF
+#define DFM_EDGE_HALF 0
+#endif
+#ifndef DFM_MSG_WAVES
+#define DFM_MSG_WAVES DFM_EDGE_WAVES
+#endif
+constexpr int MSG_WAVES = DFM_MSG_WAVES;
+constexpr int MSG_NT = DFM_EDGE_HALF ? 4 : 8;      // n-tiles (32 columns) of the output a wave owns
 
 typedef float f2 __attribute__((ext_vector_type(2)));   // packed fp32 pair -> v_pk_{mul,add,fma}_f32 (2 results / instr)
 // a + (float)half of a packed fp16 pair in ONE plain-rate instruction (v_fma_mix_f32: f16 source 0 times 1.0 plus f32 source 2);
@@ -797,14 +808,14 @@ template <int ROWS> __global__ __launch_bounds__(256, 1) void k_edge_f32m(EdgeKA
 // (i, j, code, radial), A_i is gathered per row like Bm_j, and instead of the segment sum the gated messages are stored row-major
 // as fp16 (S * gate * m, the unit of the last layer's message buffer).  Rows are independent in the contraction, so a row's result
 // does not depend on which other rows share its tile.
-template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAVES * 64) void k_edge_msg(EdgeKArgs p)
+template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVES * 64) void k_edge_msg(EdgeKArgs p)
 {
     static_assert(!ROWS || (F16 && AW16), "the row-list form exists for the shipped 16-bit plan only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *Wf = reinterpret_cast<uint4 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform BY ANALYSIS too: the tile walk below stays in SGPRs
-    char *stage = smem + LDS_WF_BYTES + wave * LDS_STAGE_BYTES;
+    char *stage = smem + LDS_WF_BYTES + (wave % EDGE_WAVES) * LDS_STAGE_BYTES;
     const int h = lane >> 5, l31 = lane & 31;
     uint32_t n_rows = 0, n_row_tiles = 0;
     if constexpr (ROWS) {
@@ -829,7 +840,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
     const int U = p.B * nsplit;
     const int nb_x = U > xcd ? (U - xcd + 7) >> 3 : 0;
     const unsigned ntask = ROWS ? n_row_tiles : (unsigned)nb_x * (unsigned)NTc;
-    const unsigned tstride = ROWS ? gridDim.x * EDGE_WAVES : (unsigned)wg_per_xcd * EDGE_WAVES;
+    const unsigned tstride = ROWS ? gridDim.x * MSG_WAVES : (unsigned)wg_per_xcd * MSG_WAVES;
     auto task_tile = [&](unsigned tt, int &b, int &i, int &mt) -> bool {      // first tile of task tt
         if constexpr (ROWS) { b = 0; i = (int)tt; mt = 0; return true; }      // row-list form: "node" i = the tile of the list
         const unsigned tq = tt / (unsigned)NTc, tr = tt - tq * (unsigned)NTc;
@@ -886,7 +897,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         if (lane == 0) v = __hip_atomic_fetch_add(p.task_ctr + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return v;
     };
-    auto dyn_index = [&](uint32_t pos) -> uint32_t { return (uint32_t)slot + (uint32_t)wg_per_xcd * ((uint32_t)EDGE_WAVES + pos); };
+    auto dyn_index = [&](uint32_t pos) -> uint32_t { return (uint32_t)slot + (uint32_t)wg_per_xcd * ((uint32_t)MSG_WAVES + pos); };
     if (dyn && has_task && ntile == 1) dyn_next = dyn_index((uint32_t)__builtin_amdgcn_readfirstlane((int)fetch_task()));      // one-tile tasks: needed at once
 
     // raw edge data of the tile in lookahead (rows past K read the node's last edge and are masked in set_tile)
@@ -1034,6 +1045,9 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             if (k == 7) {
                 const int row = q * 16 + r16;
                 *reinterpret_cast<uint4 *>(buf + ((c4 * 32 + (row ^ (4 * c4))) << 4)) = pf[q].u;
+#if DFM_EDGE_HALF      // (rows 16..31 belong to the partner wave of the pair form: filled with a copy so that the wrong results stay finite)
+                *reinterpret_cast<uint4 *>(buf + ((c4 * 32 + ((row + 16) ^ (4 * c4))) << 4)) = pf[q].u;
+#endif
             }
         }
     };
@@ -1065,22 +1079,23 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         set_tile(b, i, mt);
         radq[0] = radq_nx[0]; radq[1] = radq_nx[1];
         gather_chunk(0);
-        gather(0, 0, r0); gather(0, 1, r1);
+        gather(0, 0, r0);
+        if constexpr (!DFM_EDGE_HALF) gather(0, 1, r1);
     }
     // The workgroup's weight fragments, global -> LDS, with the first tile's index loads and gathers already in flight: a launch with
     // one round of tiles (small batches, the row-list launches) otherwise pays the two dependent round trips of its prologue AFTER
     // the 128 KiB fill instead of under it.
-    for (int q = tid; q < LDS_WF_BYTES / 16; q += EDGE_WAVES * 64) Wf[q] = p.Wf[q];
+    for (int q = tid; q < LDS_WF_BYTES / 16; q += MSG_WAVES * 64) Wf[q] = p.Wf[q];
     __syncthreads();
     if (!has_task) return;
     if constexpr (DFM_EDGE_PRIO) { if (wave >= EDGE_WAVES / 2) __builtin_amdgcn_s_setprio(DFM_EDGE_PRIO); }      // the second wave of every SIMD
     compute_store(0, r0, stage); gather(1, 0, r0);
-    compute_store(1, r1, stage); gather(1, 1, r1);
+    if constexpr (!DFM_EDGE_HALF) { compute_store(1, r1, stage); gather(1, 1, r1); }
     gather_chunk(1);
 
-    float colsum[8];
+    float colsum[MSG_NT];
 #pragma unroll
-    for (int nt = 0; nt < 8; ++nt) colsum[nt] = 0.f;
+    for (int nt = 0; nt < MSG_NT; ++nt) colsum[nt] = 0.f;
     const float *dot_v = p.att_w;
 
     while (true) {
@@ -1101,9 +1116,9 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         }
         if (!have_next) { nb = b; ni = i; nmt = mt; }
 
-        f32x16 acc[8];
-        float dv[8];
-        uint32_t bp[8];
+        f32x16 acc[MSG_NT];
+        float dv[MSG_NT];
+        uint32_t bp[MSG_NT];
         // one chunk: 16 MFMAs of chunk c; PRODUCE: the arithmetic of the next chunk (chunk 7: chunk 0 of the next tile), one slice after
         // every MFMA; the loads of the chunk after that go out at the slots DFM_EDGE_G0 / GC / G1; FIRST: opens the accumulators;
         // LAST: the epilogue's bias operand is requested instead of the (already built) staging being idle
@@ -1118,6 +1133,28 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
                 af[ks].u = *reinterpret_cast<const uint4 *>(bufc + ((un * 32 + (l31 ^ (4 * un))) << 4));
             }
             const uint4 *wq = Wf + (size_t)c * 16 * 64 + lane;
+#if DFM_EDGE_HALF
+            {
+                Frag bq[2];
+                bq[0].u = wq[0];
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {      // 8 slots: k-step sl >> 2, n-tile sl & 3; one producer slice of the wave's ONE pass after each
+                    if (sl < 7) bq[(sl + 1) & 1].u = wq[((((sl + 1) >> 2) * 8) + ((sl + 1) & 3)) * 64];
+                    if constexpr (decltype(first)::value) {
+                        if (sl < 4) acc[sl] = mfma16<F16>(af[0], bq[sl & 1], zero16);
+                        else acc[sl & 3] = mfma16<F16>(af[1], bq[sl & 1], acc[sl & 3]);
+                    } else {
+                        acc[sl & 3] = mfma16<F16>(af[sl >> 2], bq[sl & 1], acc[sl & 3]);
+                    }
+                    if constexpr (decltype(last)::value) { if (sl < 4) bp[sl] = p.biasp[sl * 64 + lane]; }
+                    slice(0, sl, r0, bufn);
+                    if (sl == 3) gather(cg, 0, r0);
+                    if constexpr (!decltype(last)::value || DFM_EDGE_DEFER < 1) { if (sl == 4) gather_chunk(cg); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
+#endif
             constexpr int BD = DFM_EDGE_BD;
             Frag bq[BD];
 #pragma unroll
@@ -1152,10 +1189,10 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         radq[0] = radq_nx[0]; radq[1] = radq_nx[1];
         chunk(7, std::false_type{}, std::true_type{});      // builds chunk 0 of the next tile, requests its chunk 1
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) dv[nt] = dot_v[nt * 32 + l31];
+        for (int nt = 0; nt < MSG_NT; ++nt) dv[nt] = dot_v[nt * 32 + l31];
         // bias k-step: acc += 1 * hi + 1 * lo (the accumulators were opened with C = 0)
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
+        for (int nt = 0; nt < MSG_NT; ++nt) {
             Frag bb;
             bb.u = make_uint4(bp[nt], 0u, 0u, 0u);
             acc[nt] = mfma16<F16>(onef, bb, acc[nt]);
@@ -1178,7 +1215,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
 #pragma unroll
             for (int q = 0; q < 8; ++q) part2[q] = (f2){0.f, 0.f};
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
+            for (int nt = 0; nt < MSG_NT; ++nt) {
                 const f2 vv = {dv[nt], dv[nt]};
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -1224,7 +1261,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
                 wr[k2] = row * 32 + uu;
             }
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
+            for (int nt = 0; nt < MSG_NT; ++nt) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const uint32_t pk = pack_f16_sat_lo(acc[nt][r] * part[r], acc[nt][r + 1] * part[r + 1]);
@@ -1263,7 +1300,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
 #pragma unroll
             for (int r = 0; r < 16; ++r) { ps[r] = part[r]; asm volatile("" : "+v"(ps[r])); }
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
+            for (int nt = 0; nt < MSG_NT; ++nt) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const float g0 = acc[nt][r] * ps[r], g1 = acc[nt][r + 1] * ps[r + 1];
@@ -1282,7 +1319,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
 #else
             uint16_t *Mout = p.mbuf + (((size_t)b * p.L + (i - p.R)) * 2 + mt) * (32 * H);
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
+            for (int nt = 0; nt < MSG_NT; ++nt) {
                 const int cbase = (((nt * 2 + (l31 >> 4)) * 2 + ((l31 >> 3) & 1)) * 32) * 8 + (l31 & 7);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1294,7 +1331,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
         }
         if (!p.no_agg) {      // (the ligand-only last layer has no reader for the segment sums: its launches skip them, r06)
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
+        for (int nt = 0; nt < MSG_NT; ++nt) {
             f2 cs = {0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 8; ++q) cs = (f2){acc[nt][2 * q], acc[nt][2 * q + 1]} * (f2){part[2 * q], part[2 * q + 1]} + cs;
@@ -1317,7 +1354,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0" : "=v"(le));
             float *out = p.agg + ((size_t)b * p.N + i) * H + le;
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
+            for (int nt = 0; nt < MSG_NT; ++nt) {
                 if (h == 0 && !p.no_agg) {
                     if (split) atomicAdd(out + nt * 32, colsum[nt]); else store_stream(out + nt * 32, colsum[nt]);
                 }
@@ -1334,13 +1371,13 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(EDGE_WAV
             dyn_next = dyn_index(got);
         }
         // the rest of the next tile's chunk 1 (kept out of the epilogue's register budget): the second pass is first used at slot 8
-        if constexpr (DFM_EDGE_DEFER >= 2) gather(1, 1, r1);
+        if constexpr (DFM_EDGE_DEFER >= 2 && !DFM_EDGE_HALF) gather(1, 1, r1);
         if constexpr (DFM_EDGE_DEFER >= 1) gather_chunk(1);
         tt = ntt; b = nb; i = ni; mt = nmt;
     }
     if (dyn && lane == 0) {      // count this wave out; the last of the workgroup's waves that had a task leaves the counters zeroed for the next launch
         uint32_t active = 0;      // waves of this workgroup whose static first task exists
-        for (int w = 0; w < EDGE_WAVES; ++w) active += (uint32_t)w * (uint32_t)wg_per_xcd + (uint32_t)slot < ntask ? 1u : 0u;
+        for (int w = 0; w < MSG_WAVES; ++w) active += (uint32_t)w * (uint32_t)wg_per_xcd + (uint32_t)slot < ntask ? 1u : 0u;
         const uint32_t gone = __hip_atomic_fetch_add(p.task_ctr + TASK_CTR_WGS + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gone + 1u == active) {
             __hip_atomic_store(p.task_ctr + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1634,7 +1671,7 @@ template <int F16, int AW16> static hipError_t launch_msg_t(const EdgeKArgs &k, 
         hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_msg<F16, AW16>), LDS_EDGE_BYTES, attr_done);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_edge_msg<F16, AW16>), dim3(persistent_grid(wave_tasks)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
+    hipLaunchKernelGGL((k_edge_msg<F16, AW16>), dim3(persistent_grid(wave_tasks)), dim3(MSG_WAVES * 64), LDS_EDGE_BYTES, s, k);
     return hipGetLastError();
 }
 template <int F16> static hipError_t launch_coord_t(const EdgeKArgs &k, long long wave_tasks, hipStream_t s)
@@ -1674,7 +1711,7 @@ hipError_t launch_edge_bf16(const EdgeArgs &a, hipStream_t s)
             if (e != hipSuccess) return e;
         }
     }
-    else if (a.task_ctr && a.B >= 8 && tasks >= 2 * (long long)device_cus() * EDGE_WAVES) {
+    else if (a.task_ctr && a.B >= 8 && tasks >= 2 * (long long)device_cus() * MSG_WAVES) {
         // node tasks, more tasks than waves: every wave's tasks after its first come from the per-XCD counters (dynamic tasks, k_edge_msg)
         static const bool off = [] { const char *e = getenv("DFM_EDGE_DYNAMIC"); return e && atoi(e) == 0; }();      // diagnostics: the fixed stride of r01-r05
         if (!off && device_cus() <= TASK_CTR_WGS) k.task_ctr = a.task_ctr;      // zero at allocation, zeroed again by the last wave of every launch
@@ -1815,7 +1852,7 @@ hipError_t launch_edge_rows(const EdgeArgs &a, const uint4 *rows, const uint32_t
     static std::atomic<bool> attr_done[MAX_DEVICES];
     hipError_t e = ensure_lds_attr(reinterpret_cast<const void *>(k_edge_msg<1, 1, 1>), LDS_EDGE_BYTES, attr_done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_edge_msg<1, 1, 1>), dim3(persistent_grid(((long long)n_rows_cap + 31) / 32)), dim3(EDGE_WAVES * 64), LDS_EDGE_BYTES, s, k);
+    hipLaunchKernelGGL((k_edge_msg<1, 1, 1>), dim3(persistent_grid(((long long)n_rows_cap + 31) / 32)), dim3(MSG_WAVES * 64), LDS_EDGE_BYTES, s, k);
     return hipGetLastError();
 }
 
