@@ -42,6 +42,15 @@
 #ifndef DFM_EDGE_PRIO       // n > 0: s_setprio n for waves 4..7 (the second-dispatched wave of every SIMD)
 #define DFM_EDGE_PRIO 0
 #endif
+#ifndef DFM_EDGE_ROT        // 1: a slot is {producer slice, MFMA} instead of {MFMA, slice}: the chunk's first MFMA no longer follows its fragment reads directly
+#define DFM_EDGE_ROT 0
+#endif
+#ifndef DFM_EDGE_NOFENCE    // 1: no s_waitcnt lgkmcnt(0) between the producer's ds_write and the fragment reads of the same wave (LDS executes a wave's instructions in order)
+#define DFM_EDGE_NOFENCE 0
+#endif
+#ifndef DFM_EDGE_EARLYA     // 1: k-step 0's A fragment and the first weight fragment of chunk c + 1 are requested at the end of chunk c (chunks 1..7)
+#define DFM_EDGE_EARLYA 0
+#endif
 #ifndef DFM_EDGE_KO         // knock-out builds, WRONG RESULTS: bit 0 no MFMA, bit 1 no producer transcendentals, bit 2 no epilogue transcendentals
 #define DFM_EDGE_KO 0
 #endif

@@ -1117,6 +1117,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVE
         if (!have_next) { nb = b; ni = i; nmt = mt; }
 
         f32x16 acc[MSG_NT];
+        Frag af0c, bq0c;      // DFM_EDGE_EARLYA: k-step 0's A fragment / first weight fragment of the next chunk, carried over the chunk boundary
         float dv[MSG_NT];
         uint32_t bp[MSG_NT];
         // one chunk: 16 MFMAs of chunk c; PRODUCE: the arithmetic of the next chunk (chunk 7: chunk 0 of the next tile), one slice after
@@ -1125,12 +1126,16 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVE
         auto chunk = [&](int c, auto first, auto last) {
             char *bufc = stage + (c & 1) * 2048, *bufn = stage + ((c + 1) & 1) * 2048;
             const int cg = (c + 2) & 7;
-            wave_lds_fence();
+            // (the staging area is wave-private and a wave's LDS instructions execute in order: the fragment reads below see the producer's
+            // ds_write without waiting for it to complete - DFM_EDGE_NOFENCE keeps only the compiler from reordering them)
+            if constexpr (DFM_EDGE_NOFENCE) asm volatile("" ::: "memory"); else wave_lds_fence();
             Frag af[2];
+            constexpr bool carried = DFM_EDGE_EARLYA && !decltype(first)::value;      // k-step 0's fragments were requested at the end of the chunk before
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int un = ks * 2 + h;
-                af[ks].u = *reinterpret_cast<const uint4 *>(bufc + ((un * 32 + (l31 ^ (4 * un))) << 4));
+                if (ks == 0 && carried) af[0] = af0c;
+                else af[ks].u = *reinterpret_cast<const uint4 *>(bufc + ((un * 32 + (l31 ^ (4 * un))) << 4));
             }
             const uint4 *wq = Wf + (size_t)c * 16 * 64 + lane;
 #if DFM_EDGE_HALF
@@ -1158,10 +1163,21 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVE
             constexpr int BD = DFM_EDGE_BD;
             Frag bq[BD];
 #pragma unroll
-            for (int d = 0; d < BD - 1; ++d) bq[d].u = wq[d * 64];
+            for (int d = 0; d < BD - 1; ++d) { if (d == 0 && carried) bq[0] = bq0c; else bq[d].u = wq[d * 64]; }
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 if (m + BD - 1 < 16) bq[(m + BD - 1) % BD].u = wq[(m + BD - 1) * 64];
+                auto do_slice = [&]() {
+                    if constexpr (DFM_EDGE_ILV) { if (m & 1) slice(1, m >> 1, r1, bufn); else slice(0, m >> 1, r0, bufn); }      // passes interleaved slot by slot
+                    else { if (m < 8) slice(0, m & 7, r0, bufn); else slice(1, m & 7, r1, bufn); }
+                    if constexpr (DFM_EDGE_EARLYA && !decltype(last)::value) {
+                        if (m == 15) {      // the next chunk is complete in bufn: its k-step 0 operands go out now, one MFMA (and the loop's back edge) ahead of their use
+                            af0c.u = *reinterpret_cast<const uint4 *>(bufn + ((h * 32 + (l31 ^ (4 * h))) << 4));
+                            bq0c.u = wq[16 * 64];
+                        }
+                    }
+                };
+                if constexpr (DFM_EDGE_ROT) do_slice();      // slice BEFORE the slot's MFMA: the fragment reads at the top of the chunk fly under slice 0
                 if constexpr (decltype(first)::value) {
                     if (m < 8) acc[m] = mfma16<F16>(af[0], bq[m % BD], zero16);
                     else acc[m & 7] = mfma16<F16>(af[1], bq[m % BD], acc[m & 7]);
@@ -1171,8 +1187,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVE
                 if constexpr (decltype(last)::value) {
                     if (m < 8) bp[m] = p.biasp[m * 64 + lane];      // older than this chunk's gathers: the bias step does not wait for them
                 }
-                if constexpr (DFM_EDGE_ILV) { if (m & 1) slice(1, m >> 1, r1, bufn); else slice(0, m >> 1, r0, bufn); }      // passes interleaved slot by slot
-                else { if (m < 8) slice(0, m & 7, r0, bufn); else slice(1, m & 7, r1, bufn); }
+                if constexpr (!DFM_EDGE_ROT) do_slice();
                 if (m == DFM_EDGE_G0) gather(cg, 0, r0);
                 if constexpr (!decltype(last)::value || DFM_EDGE_DEFER < 1) { if (m == DFM_EDGE_GC) gather_chunk(cg); }
                 if constexpr (!decltype(last)::value || DFM_EDGE_DEFER < 2) { if (m == DFM_EDGE_G1) gather(cg, 1, r1); }
