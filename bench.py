@@ -35,6 +35,7 @@ H, K_DEG = 256, 60
 FLOP_PER_NODE_LAYER = 2 * K_DEG * H * H + 2 * K_DEG * H
 PEAK_MFMA16_TFLOPS = 2500.0   # dense MFMA bf16 / fp16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3       # fp32 vector / f32-input MFMA
+PEAK_SCLK_MHZ = 2400          # the engine clock the peak figures are quoted at
 
 
 def cpu_model():
@@ -387,6 +388,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     edge_ms, edge_launches, edge_rows, lig_launches, lig_ms = 0.0, 0, 0, 0, 0.0
+    clk_cycles = clk_ticks = 0.0      # the message kernel's own clock stamps (dfm_profile::edge_shader_cycles / edge_ref_ticks)
     l0 = dict(l0_evals=0, l0_edges=0, l0_miss_rows=0, l0_rows_ms=0.0, l0_gather_ms=0.0)
     allrec = None
     for it in range(args.steps):
@@ -397,6 +399,8 @@ def main():
         edge_rows += p["edge_rows"]
         lig_launches += p["edge_lig_launches"]
         lig_ms += p["edge_lig_ms"]
+        clk_cycles += p.get("edge_shader_cycles") or 0.0
+        clk_ticks += p.get("edge_ref_ticks") or 0.0
         for k in l0:
             l0[k] += p[k]
     barrier()
@@ -438,6 +442,7 @@ def main():
         achieved = flop_total / (edge_ms * 1e-3) / 1e12 if edge_ms > 0 else 0.0
         peak = PEAK_MFMA16_TFLOPS if mfma16 else PEAK_F32_TFLOPS
         ctr, ctr_src = replayed_counters(args)
+        sclk_mhz = 100.0 * clk_cycles / clk_ticks if clk_ticks > 0 else None
         n_full, n_lig = edge_launches - lig_launches, lig_launches
         traffic = mfma_busy = valu_busy = None
         if ctr:      # weight the two launch types by THIS run's mix (bytes: per launch; busy fractions: by active cycles)
@@ -483,6 +488,12 @@ def main():
             "roofline": {"bound": "valu" if mfma16 else "mfma", "kernel": "k_edge_msg<1,%d> (fp16 operands, all six layers)" % (0 if f16 else 1) if mfma16 else "k_edge_f32",
                          "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "sclk_mhz": sclk_mhz, "peak_at_sclk": peak * sclk_mhz / PEAK_SCLK_MHZ if sclk_mhz else None,
+                         "frac_at_sclk": achieved / (peak * sclk_mhz / PEAK_SCLK_MHZ) if sclk_mhz else None,
+                         "sclk_note": "sclk_mhz = the shader clock the message kernel ran at in THIS run: its first wave reads s_memtime (shader cycles) and "
+                                      "s_memrealtime (100 MHz) at start and exit, summed over the timed launches. `peak` assumes %d MHz; the chip's power "
+                                      "management holds this kernel lower (the MFMA's energy, not its issue rate, is what the clock pays for: "
+                                      "profiles/r06_clock.txt), so frac_at_sclk is the fraction of what the matrix pipe can deliver at the clock it was given" % PEAK_SCLK_MHZ,
                          "avg_launch_ms": avg_launch_s * 1e3, "launches": int(edge_launches),
                          "flop_per_launch": flop_per_launch, "traffic": traffic, "traffic_source": ctr_src,
                          "traffic_gbps": (traffic / avg_launch_s / 1e9) if traffic else None,

@@ -68,7 +68,8 @@ class ProfileC(C.Structure):
                 ("total_ms", C.c_double), ("phase_cycles", C.c_double * 4), ("slot_cycles", C.c_double * 16),
                 ("l0_evals", C.c_int64), ("l0_edges", C.c_int64), ("l0_miss_rows", C.c_int64),
                 ("l0_rows_ms", C.c_double), ("l0_gather_ms", C.c_double), ("l0_build_ms", C.c_double),
-                ("edge_lig_launches", C.c_int64), ("edge_lig_ms", C.c_double)]
+                ("edge_lig_launches", C.c_int64), ("edge_lig_ms", C.c_double),
+                ("edge_shader_cycles", C.c_double), ("edge_ref_ticks", C.c_double)]
 
 
 class SelfcheckC(C.Structure):

@@ -729,6 +729,8 @@ extern "C" dfm_complex *dfm_complex_create(dfm_model *m, const float *rec_x, con
     ok = ok && P.alloc(&cx->A0h, (size_t)N * H) == hipSuccess;
 #if defined(DFM_EDGE_STAMP) || defined(DFM_EDGE_TRACE)
     ok = ok && P.alloc(&cx->stamp_dev, 48 + 8 * 130) == hipSuccess && hipMemsetAsync(cx->stamp_dev, 0, (48 + 8 * 130) * 8, cx->stream) == hipSuccess;
+#else      // product: four words for the message kernel's clock stamps (profiled calls only, dfm_profile::edge_shader_cycles)
+    ok = ok && P.alloc(&cx->stamp_dev, 8) == hipSuccess && hipMemsetAsync(cx->stamp_dev, 0, 8 * 8, cx->stream) == hipSuccess;
 #endif
     if (ok) {
         // node = single_embed(cat[rec_x, lig_x]) (score_net_mlsb.py:365-366): pose independent, once per complex
@@ -1109,7 +1111,11 @@ static int enqueue_forward(dfm_complex *cx, int B, const FwdOpts &o)
         e.f16 = layer_f16(l) ? 1 : 0;
         e.lig_only = lig_only ? 1 : 0;
         e.agg_is_zero = (l > 0 && tile_tasks) ? 1 : 0;      // zeroed by the previous layer's node_mlp.3 GEMM
+#if defined(DFM_EDGE_STAMP) || defined(DFM_EDGE_TRACE)
         e.stamp = (o.profile && l == 2) ? cx->stamp_dev : nullptr;
+#else
+        e.stamp = o.profile ? cx->stamp_dev : nullptr;      // every profiled message launch adds its clock stamps
+#endif
         e.task_ctr = W.task_ctr;
         {   // selfcheck telemetry: what enters this layer
             const long long nrow = l == 0 ? N : M;      // layer 0's operands are per complex, not per trajectory
@@ -1306,10 +1312,20 @@ static int finish_profile(dfm_complex *cx)
         HIPCHK(hipStreamSynchronize(cx->stream));
         cx->prof.l0_miss_rows = (int64_t)tot;
     }
+#if !defined(DFM_EDGE_STAMP) && !defined(DFM_EDGE_TRACE)
+    if (cx->stamp_dev && cx->ev_used) {      // the clock stamps of this call's message launches (k_edge_msg), then back to zero for the next call
+        unsigned long long st[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(st, cx->stamp_dev, sizeof(st), hipMemcpyDeviceToHost, cx->stream));
+        HIPCHK(hipMemsetAsync(cx->stamp_dev, 0, 2 * 8, cx->stream));
+        HIPCHK(hipStreamSynchronize(cx->stream));
+        cx->prof.edge_shader_cycles = (double)st[0];
+        cx->prof.edge_ref_ticks = (double)st[1];
+    }
+#endif
 #ifdef DFM_EDGE_TRACE      // diagnostic build: raw wave timelines of workgroup 0 -> $DFM_EDGE_TRACE_FILE (tools/edge_trace.py)
     if (cx->stamp_dev && getenv("DFM_EDGE_TRACE_FILE")) {
-        static unsigned long long tr[8 * 130];
-        HIPCHK(hipMemcpyAsync(tr, cx->stamp_dev + 48, sizeof(tr), hipMemcpyDeviceToHost, cx->stream));
+        static unsigned long long tr[48 + 8 * 130];      // [0..15]: s_memrealtime of every wave at its tiles 0 and 63; [48..]: the timelines
+        HIPCHK(hipMemcpyAsync(tr, cx->stamp_dev, sizeof(tr), hipMemcpyDeviceToHost, cx->stream));
         HIPCHK(hipStreamSynchronize(cx->stream));
         if (FILE *f = fopen(getenv("DFM_EDGE_TRACE_FILE"), "wb")) { fwrite(tr, 1, sizeof(tr), f); fclose(f); }
     }

@@ -1066,12 +1066,21 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVE
 #ifdef DFM_EDGE_TRACE      // diagnostic build: absolute s_memtime of tile start / epilogue start of the first 64 tiles of every wave of workgroup 0
     int tr_n = 0;          // -> p.stamp[48 + wave * 130 ...] ([0] = HW_ID register: SIMD id in bits 5:4); tools/edge_trace.py
 #define TRACE(w) { if (p.stamp && blockIdx.x == 0 && tr_n < 64) { __builtin_amdgcn_sched_barrier(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
-                   if (lane == 0) p.stamp[48 + wave * 130 + 1 + 2 * tr_n + (w)] = _t; __builtin_amdgcn_sched_barrier(0); } }
+                   if (lane == 0) p.stamp[48 + wave * 130 + 1 + 2 * tr_n + (w)] = _t; \
+                   if ((w) == 0 && (tr_n == 0 || tr_n == 63) && lane == 0) p.stamp[wave * 2 + (tr_n ? 1 : 0)] = __builtin_amdgcn_s_memrealtime();      /* 100 MHz: the clock the kernel ran at */ \
+                   __builtin_amdgcn_sched_barrier(0); } }
     if (p.stamp && blockIdx.x == 0 && lane == 0) p.stamp[48 + wave * 130] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
 #else
 #define TRACE(w)
 #endif
 
+#if !defined(DFM_EDGE_STAMP) && !defined(DFM_EDGE_TRACE)
+    // Profiled calls (DFM_F_PROFILE: p.stamp set): the shader clock this launch runs at.  The chip's power management holds the message kernel well below
+    // the 2.4 GHz the peak figures assume (profiles/r06_clock.txt), so the bench reports the clock next to the fraction.  stamp[0] += shader cycles,
+    // stamp[1] += 100 MHz ticks between this wave's start and its exit; one writer (launches of a handle are serialised on its stream).
+    const bool clk_wave = p.stamp != nullptr && blockIdx.x == 0 && wave == 0;
+    if (clk_wave && lane == 0) { p.stamp[2] = __builtin_amdgcn_s_memtime(); p.stamp[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     // ---- the only prologue of the wave: first tile's chunk 0 built, its chunk 1 requested
     RawP r0, r1;
     if (has_task) {
@@ -1402,6 +1411,13 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVE
 #ifdef DFM_EDGE_STAMP
     if (p.stamp && blockIdx.x == 0 && lane == 0)
         for (int k = 0; k < 4; ++k) p.stamp[wave * 4 + k] = st_t[k];
+#endif
+#if !defined(DFM_EDGE_STAMP) && !defined(DFM_EDGE_TRACE)
+    if (clk_wave && lane == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1c = __builtin_amdgcn_s_memrealtime();
+        p.stamp[0] += t1 - p.stamp[2];
+        p.stamp[1] += r1c - p.stamp[3];
+    }
 #endif
 #undef STAMP
 #undef STAMP0

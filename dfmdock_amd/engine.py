@@ -286,4 +286,6 @@ class Complex:
         return dict(edge_kernel_ms=p.edge_kernel_ms, edge_kernel_launches=p.edge_kernel_launches,
                     edge_rows=p.edge_rows, total_ms=p.total_ms, phase_cycles=list(p.phase_cycles), slot_cycles=list(p.slot_cycles),
                     l0_evals=p.l0_evals, l0_edges=p.l0_edges, l0_miss_rows=p.l0_miss_rows, l0_rows_ms=p.l0_rows_ms,
-                    l0_gather_ms=p.l0_gather_ms, l0_build_ms=p.l0_build_ms, edge_lig_launches=p.edge_lig_launches, edge_lig_ms=p.edge_lig_ms)
+                    l0_gather_ms=p.l0_gather_ms, l0_build_ms=p.l0_build_ms, edge_lig_launches=p.edge_lig_launches, edge_lig_ms=p.edge_lig_ms,
+                    edge_shader_cycles=p.edge_shader_cycles, edge_ref_ticks=p.edge_ref_ticks,
+                    edge_sclk_mhz=(100.0 * p.edge_shader_cycles / p.edge_ref_ticks) if p.edge_ref_ticks > 0 else None)

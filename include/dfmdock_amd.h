@@ -199,6 +199,11 @@ typedef struct {
     double l0_build_ms;       /* table build of this call (0 when the table already existed)                      */
     int64_t edge_lig_launches;/* of edge_kernel_launches: last-layer launches over the ligand nodes only          */
     double edge_lig_ms;       /* their share of edge_kernel_ms                                                    */
+    /* the shader clock the message kernel actually ran at (the chip's power management, not the kernel, sets it): workgroup 0's first wave
+     * reads s_memtime (shader cycles) and s_memrealtime (100 MHz) when it starts and when it leaves, summed over the call's launches;
+     * MHz = 100 * edge_shader_cycles / edge_ref_ticks.  0 when the call had no profiled message launch.                              */
+    double edge_shader_cycles;
+    double edge_ref_ticks;
 } dfm_profile;
 
 /* Output of dfm_complex_selfcheck: how far the 16-bit MFMA engine is from the fp32 engine (the reference's own arithmetic) on THIS

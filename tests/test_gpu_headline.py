@@ -76,6 +76,10 @@ def test_c3_headline_call_vs_oracle(eps, model, blob):
     assert p["edge_lig_launches"] == S, p              # the step evaluations' last layer ran over the ligand nodes only
     assert p["edge_kernel_launches"] == 5 * (S + 1), p  # layers 1-5 of S + 1 evaluations; layer 0 is not a message launch
     assert 0 < p["l0_miss_rows"] < 0.5 * p["l0_edges"]
+    # the message kernel's own clock stamps (s_memtime against the 100 MHz s_memrealtime, first wave of workgroup 0, summed over the launches):
+    # a plausible shader clock, and the stamps cover the launches' time (one wave's lifetime <= its launch)
+    assert 500.0 < p["edge_sclk_mhz"] < 2600.0, p["edge_sclk_mhz"]
+    assert 0.5 * p["edge_kernel_ms"] < p["edge_ref_ticks"] / 1e5 <= 1.02 * p["edge_kernel_ms"], (p["edge_ref_ticks"], p["edge_kernel_ms"])
     r32 = gx.sample(B=B, num_steps=S, eps=eps, inject=inj, trace=True, step_energy=False, profile=True)      # fp32 engine, its own table
     assert gx.profile()["l0_evals"] == S + 1
     assert np.isfinite(r16["lig_pos"]).all() and np.isfinite(r32["lig_pos"]).all()

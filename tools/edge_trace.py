@@ -22,10 +22,12 @@ model = engine.Model(pack_blob(make_random_weights(0)))
 cx = make_complex(300, 300, seed=1)
 gx = engine.Complex(model, cx["rec_x"], cx["lig_x"], cx["rec_pos"], cx["lig_pos"])
 poses = np.repeat(cx["lig_pos"][None], B, 0)
-for it in range(2):
+for it in range(int(os.environ.get("REPS", "2"))):
     gx.score(poses, 0.5, seed=it, mfma16=True, energy=False, profile=True)
     gx.profile()
-tr = np.fromfile(path, dtype=np.uint64).reshape(8, 130)
+raw = np.fromfile(path, dtype=np.uint64)
+rt = raw[:16].reshape(8, 2).astype(np.int64)      # s_memrealtime (100 MHz) of every wave at the start of its tiles 0 and 63
+tr = raw[48:].reshape(8, 130)
 simd = [(int(t[0]) >> 4) & 3 for t in tr]
 t0 = tr[:, 1::2][:, :64].astype(np.int64); te = tr[:, 2::2][:, :64].astype(np.int64)
 base = t0[t0 > 0].min()
@@ -47,3 +49,16 @@ for s in range(4):
             ph.append((t - t0[b][j]) / (t0[b][j + 1] - t0[b][j]))
     ph = np.array(ph)
     print(f"SIMD {s}: waves {a},{b}: partner's tile fraction when wave {a} enters its epilogue: " + " ".join(f"{x:.2f}" for x in ph[:24]) + f"  | mean {ph.mean():.2f} std {ph.std():.2f}")
+
+# the shader clock this launch ran at: s_memtime (shader cycles) against s_memrealtime (100 MHz) between tile 0 and tile 63 of every wave
+for w in range(8):
+    dc, dr = int(t0[w][63] - t0[w][0]), int(rt[w][1] - rt[w][0])
+    if dr > 0:
+        print(f"wave {w}: tiles 0..63 took {dc} shader cycles = {dr / 100:.1f} us -> {100.0 * dc / dr:7.1f} MHz")
+
+per_old = np.median([np.median(np.diff(t0[w])[np.diff(t0[w]) > 0]) for w in range(4)])
+per_young = np.median([np.median(np.diff(t0[w])[np.diff(t0[w]) > 0]) for w in range(4, 8)])
+mhz = np.median([100.0 * (t0[w][63] - t0[w][0]) / max(int(rt[w][1] - rt[w][0]), 1) for w in range(8)])
+pair = 1.0 / (1.0 / per_old + 1.0 / per_young)
+print(f"SUMMARY {os.path.basename(os.environ.get('DFM_LIB', 'product'))}: tile period older {per_old:.0f} younger {per_young:.0f} cycles -> {pair:.0f} cycles per tile and SIMD; "
+      f"shader clock {mhz:.0f} MHz -> {pair / mhz:.3f} us per tile and SIMD")
