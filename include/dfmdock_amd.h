@@ -102,7 +102,7 @@ enum {
     DFM_F_NOISE_ANNEALING = 1u << 2, /* inference_base.py:428-430                                */
     DFM_F_CLASH_FORCE = 1u << 3,     /* inference_base.py:458-461                                */
     DFM_F_ODE = 1u << 4,             /* so3_diffuser.py:367-368                                  */
-    DFM_F_PROFILE = 1u << 5,         /* time the dominant kernel with HIP events (dfm_get_profile) */
+    DFM_F_PROFILE = 1u << 5,         /* time the dominant kernel with HIP events + its in-kernel clock stamps (dfm_get_profile) */
     DFM_F_STEP_ENERGY = 1u << 6,     /* dfm_sample: evaluate the energy head on every step (traces) */
     DFM_F_F16 = 1u << 7,             /* like DFM_F_MFMA16 but A_i = Wa h_i + b1 stays fp32 (one more load per chunk)     */
     DFM_F_IRES = 1u << 8,            /* dfm_score: also evaluate the interface-residue head (score_net_mlsb.py:383) */
