@@ -46,6 +46,9 @@ def test_bench_two_ranks_one_gpu():
     assert out["value"] > 0 and np.isfinite(out["best_energy"]) and "cpu_baseline" not in out
     assert out["config"]["trajectories_per_gpu"] == 8
     assert abs(out["value"] - 2 * 8 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-6 * out["value"]   # whole-job aggregate over both ranks
+    r = out["roofline"]      # the contract's roofline object, plus the clock the dominant kernel measured for itself
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and r["unit"] == "TFLOP/s"
+    assert 500.0 < r["sclk_mhz"] <= 2600.0 and r["frac_at_sclk"] == pytest.approx(r["frac"] * 2400.0 / r["sclk_mhz"])
 
 
 def test_bench_self_spawns_its_ranks_and_survives_a_broken_rccl():
