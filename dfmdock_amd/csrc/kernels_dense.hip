@@ -364,7 +364,7 @@ template <int HALF, int NJ, int QT = 0, int RING = QT> __global__ __launch_bound
     constexpr int SM = 64, SN = QT ? 64 : NJ * 128;      // rows; output columns per workgroup (QT 0: four waves along N, NJ 32-column tiles each)
     const GemmArgs &a = sa.g;
 #ifdef DFM_GEMM_STAMP
-    const unsigned long long g_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long g_entry = __builtin_amdgcn_s_memtime(), g_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // operand tiles; the epilogue reuses the space as 4 x 9216 B of transposition buffers
     constexpr int LDS_BUF = (2 * SM + 2 * SN) * SLD;      // one set of operand tiles (hi / lo activations, hi / lo weights)
@@ -768,8 +768,10 @@ template <int HALF, int NJ, int QT = 0, int RING = QT> __global__ __launch_bound
 #ifdef DFM_GEMM_STAMP
     GSTAMP(3)                      // [3] epilogue
     if (vb == (gridDim.x > 2048 ? 7 * 8 + 1536 : 3) && blockIdx.y == 0 && tid == 0 && a.C) {       // one mid-grid workgroup reports (debug buffer = first floats of ... stderr-free: printf)
-        printf("gemm stamp K=%d Nout=%d pro=%d epi=%d stats=%d gn=%d: entry->loop %llu  mfma+barrier %llu  fetch-wait+stage %llu  barrier2 %llu  epilogue %llu  total %llu cycles (100 MHz ticks x 21 at 2.1 GHz)\n",
-               a.K, a.Nout, a.pro, a.epi, a.stat_part ? 1 : 0, a.gn_part ? 1 : 0, g_first - g_entry, gs[0], gs[1], gs[2], gs[3], gprev - g_entry);
+        const unsigned long long g_rt1 = __builtin_amdgcn_s_memrealtime();
+        printf("gemm stamp K=%d Nout=%d pro=%d epi=%d stats=%d gn=%d: entry->loop %llu  mfma+barrier %llu  fetch-wait+stage %llu  barrier2 %llu  epilogue %llu  total %llu shader cycles in %llu ticks of 100 MHz = %llu MHz\n",
+               a.K, a.Nout, a.pro, a.epi, a.stat_part ? 1 : 0, a.gn_part ? 1 : 0, g_first - g_entry, gs[0], gs[1], gs[2], gs[3], gprev - g_entry, g_rt1 - g_rt0,
+               (g_rt1 > g_rt0) ? 100ull * (gprev - g_entry) / (g_rt1 - g_rt0) : 0ull);
     }
 #endif
 }
