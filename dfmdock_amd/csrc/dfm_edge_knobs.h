@@ -51,7 +51,7 @@
 #ifndef DFM_EDGE_EARLYA     // 1: k-step 0's A fragment and the first weight fragment of chunk c + 1 are requested at the end of chunk c (chunks 1..7)
 #define DFM_EDGE_EARLYA 0
 #endif
-#ifndef DFM_EDGE_KO         // knock-out builds, WRONG RESULTS: bit 0 no MFMA, bit 1 no producer transcendentals, bit 2 no epilogue transcendentals
+#ifndef DFM_EDGE_KO         // knock-out builds, WRONG RESULTS: bit 0 no MFMA, bit 1 no producer transcendentals, bit 2 no epilogue transcendentals, bit 3 one weight-fragment LDS read per chunk
 #define DFM_EDGE_KO 0
 #endif
 

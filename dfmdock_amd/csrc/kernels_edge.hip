@@ -1175,7 +1175,11 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVE
             for (int d = 0; d < BD - 1; ++d) { if (d == 0 && carried) bq[0] = bq0c; else bq[d].u = wq[d * 64]; }
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
+#if DFM_EDGE_KO & 8      // knock-out build (wrong results): ONE weight-fragment read per chunk instead of sixteen - what the 128 KiB of LDS reads per tile cost
+                if (m + BD - 1 < 16) asm volatile("" : "+v"(bq[(m + BD - 1) % BD].u.x), "+v"(bq[(m + BD - 1) % BD].u.y), "+v"(bq[(m + BD - 1) % BD].u.z), "+v"(bq[(m + BD - 1) % BD].u.w));
+#else
                 if (m + BD - 1 < 16) bq[(m + BD - 1) % BD].u = wq[(m + BD - 1) * 64];
+#endif
                 auto do_slice = [&]() {
                     if constexpr (DFM_EDGE_ILV) { if (m & 1) slice(1, m >> 1, r1, bufn); else slice(0, m >> 1, r0, bufn); }      // passes interleaved slot by slot
                     else { if (m < 8) slice(0, m & 7, r0, bufn); else slice(1, m & 7, r1, bufn); }
