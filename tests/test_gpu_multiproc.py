@@ -272,3 +272,26 @@ def test_bench_c4_sharded_record_on_two_ranks(tmp_path):
         assert all(q.returncode == 0 for q in procs), "\n".join(o[-3000:] for o in outs)
     a, b = open(tmp_path / "c4_w1.csv", "rb").read(), open(tmp_path / "c4_w2.csv", "rb").read()
     assert a == b and a.count(b"\n") == 961
+
+
+def test_bench_eight_ranks_headline_shape_carries_c4_sharded():
+    """The driver's 8-GPU command at the HEADLINE shape (no size overrides) on the 1-GPU box: eight self-spawned ranks share GPU 0.  After the weak-scaling C3
+    step (8 x 256 trajectories) the line must carry BASELINE config 4 as `c4_sharded`: 24 DB5-sized complexes x 40 trajectories sharded three per rank by the
+    cost model, 960 distinct (complex, trajectory) ids in ONE gather (the loop it replaces: src/inference_mlsb.py:415-439).  No scaling claim."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "DFM_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_in_gather"] == 8 and out["records_in_gather"] == 8 * 256 == out["distinct_record_ids"]
+    assert "300+300" in out["config"]["workload"] and out["config"]["trajectories_per_gpu"] == 256
+    c4 = out["c4_sharded"]
+    assert c4["records_in_gather"] == 960 == c4["distinct_record_ids"] and c4["complexes_in_gather"] == 24
+    assert sorted(c4["complexes_per_rank"]) == [3] * 8 and sum(c4["rows_per_rank"]) == 960
+    assert len(c4["per_rank_makespan_s"]) == 8 and c4["wall_s"] >= max(c4["per_rank_makespan_s"]) - 1e-3
+    assert c4["value"] == pytest.approx(960 / c4["wall_s"]) and c4["canary"]["ok"]
+    assert "c4" not in out and "cpu_baseline" not in out      # single-GPU secondary records stay at N = 1
