@@ -129,9 +129,10 @@ Q8_ESM_IDS = ("1HCF", "1IRA", "1JIW", "1JPS", "1MLC", "1NW9", "1VFB", "1ZHI", "2
 _q8 = None
 
 
-def q8_golden(cid):
-    """The reference's evaluation of `cid` on its dequantised ESM block (fwd_esmq_db5.npz: keys <id>/<name>)."""
-    g = load_golden("fwd_esmq_db5.npz")
+def q8_golden(cid, family=0):
+    """The reference's evaluation of `cid` on its dequantised ESM block (fwd_esmq_db5.npz, second model family: fwd2_esmq_db5.npz;
+    keys <id>/<name>)."""
+    g = load_golden("fwd2_esmq_db5.npz" if family else "fwd_esmq_db5.npz")
     return {k.split("/", 1)[1]: v for k, v in g.items() if k.startswith(cid + "/")}
 
 

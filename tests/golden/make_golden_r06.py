@@ -12,7 +12,9 @@ unrounded file.
   fwd_esmq_db5.npz   per complex one reference score evaluation at a rigidly noised pose (src/models/score_net_mlsb.py:343-425):
                      <id>/lig_pos, t, f, tr_score, rot_score, energy, num_clashes, edges (int16), bins, relpos, h_absmax
 
-Usage:  python tests/golden/make_golden_r06.py
+  fwd2_esmq_db5.npz  the same for the second model family (`python tests/golden/make_golden_r06.py pair`): + confidence_logits, ires_logits
+
+Usage:  python tests/golden/make_golden_r06.py [pair]
 """
 import os
 import sys
@@ -62,5 +64,34 @@ def main():
     mg.save("fwd_esmq_db5.npz", **fwd)
 
 
+def deq_complex(cid):
+    """The complex on the dequantised block of esm_db5_q8.npz (what every consumer builds)."""
+    d = load_db5_pt(os.path.join(mg.REF, f"data/db5_test/{cid}.pt"))
+    z = np.load(os.path.join(HERE, "esm_db5_q8.npz"))
+    deq = z[cid + "_q"].astype(np.float32) * z[cid + "_s"].astype(np.float32)[:, None]
+    R = d["rec_esm"].shape[0]
+    return {"rec_x": np.concatenate([deq[:R], d["rec_x"][:, 1280:]], 1), "lig_x": np.concatenate([deq[R:], d["lig_x"][:, 1280:]], 1),
+            "rec_pos": d["rec_pos"].astype(np.float32), "lig_pos": d["lig_pos"].astype(np.float32)}
+
+
+def pair_family():
+    """fwd2_esmq_db5.npz: the SECOND model family (DFMDock.forward = move_to_lig_center + EGNN_Net, src/models/DFMDock.py:68-75,
+    src/models/egnn_net.py:408-505) on the same 20 dequantised blocks and the poses of fwd_esmq_db5.npz - one reference evaluation each."""
+    import make_golden_pair as mgp
+    ids = [str(x) for x in np.load(os.path.join(HERE, "db5_backbones.npz"))["ids"] if str(x) not in HAVE_FP16]
+    net1 = mgp.build_net(0)
+    first = np.load(os.path.join(HERE, "fwd_esmq_db5.npz"))
+    out = {}
+    for k, cid in enumerate(ids):
+        cx = deq_complex(cid)
+        r = mgp.slim(mgp.forward_case(net1, cx, first[f"{cid}/lig_pos"], float(first[f"{cid}/t"]), seed=640 + k))
+        for key in ("lig_pos", "t", "tr_score", "rot_score", "energy", "f", "num_clashes", "confidence_logits", "ires_logits"):
+            out[f"{cid}/{key}"] = r[key]
+        out[f"{cid}/edges"] = r["edges"].astype(np.int16)
+        out[f"{cid}/h_absmax"] = np.array([np.abs(r["h_first"]).max(), np.abs(r["h_last"]).max()])
+        print(f"  {cid}: energy {float(r['energy']):.4f} confidence {float(r['confidence_logits']):.4f} |h| max {out[cid + '/h_absmax'][1]:.2f}", flush=True)
+    mg.save("fwd2_esmq_db5.npz", **out)
+
+
 if __name__ == "__main__":
-    main()
+    pair_family() if sys.argv[1:] == ["pair"] else main()

@@ -379,6 +379,24 @@ def test_pair_family_matches_reference_real_esm(case, blob_pair):
     assert rel_inf(r["ires"], g["ires_logits"]) < 1e-4
 
 
+def test_pair_family_matches_reference_on_the_other_twenty_db5_complexes(blob_pair):
+    """Second model family on the int8-quantised ESM blocks of the remaining 20 DB5 complexes (tests/golden/make_golden_r06.py pair): same gates
+    as the three fp16-block fixtures above."""
+    from conftest import Q8_ESM_IDS, q8_golden, real_db5_complex
+    for cid in Q8_ESM_IDS:
+        g = q8_golden(cid, family=1)
+        o = ora.Oracle(blob_pair, real_db5_complex(cid), pair_hparams())
+        r = o.score(g["lig_pos"], float(g["t"]), edges=g["edges"].astype(np.int32))
+        assert r["num_clashes"] == int(g["num_clashes"]), cid
+        assert float(np.abs(r["h_layers"][-1]).max()) == pytest.approx(float(g["h_absmax"][1]), rel=1e-4), cid
+        tol = 1e-4      # (worst of the 20 today: 2.2e-6 on f - no bin-boundary flip among these poses)
+        assert rel_inf(r["f"], g["f"]) < tol, (cid, rel_inf(r["f"], g["f"]))
+        assert rel_inf(r["tr_score"], g["tr_score"]) < tol and rel_inf(r["rot_score"], g["rot_score"]) < tol, cid
+        assert abs(float(r["energy"]) - float(g["energy"])) < tol * max(1.0, abs(float(g["energy"]))), cid
+        assert abs(float(r["confidence"]) - float(g["confidence_logits"])) < tol, cid
+        assert rel_inf(r["ires"], g["ires_logits"]) < tol, cid
+
+
 def test_phi_zero_pair_known_answer():
     """tests/golden/phi0_pair.npz: two residues of 1H1V (one rigid pose) whose planar angle is 0 to the last bit.  torch
     evaluates cos(phi) = 1.0 exactly -> phi = 0 -> bin 0; a left-to-right float32 evaluation gives 0.99999994 -> 0.02 degrees ->
