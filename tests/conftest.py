@@ -175,6 +175,8 @@ def complex_for(case):
     from dfmdock_amd.synthetic import make_complex, seq_to_onehot
     if "esm_" in case:       # DB5 backbone + the real ESM-2 block (tests/golden/make_golden_r05.py)
         return real_db5_complex(case.split("esm_")[1].split(".")[0])
+    if "esmq_" in case:      # ... + the int8-quantised block (tests/golden/make_golden_r06.py)
+        return real_db5_complex(case.split("esmq_")[1].split(".")[0])
     if "7CEI" in case:
         d = load_golden("cx_7CEI.npz")
         rx = np.concatenate([d["rec_esm16"].astype(np.float32), seq_to_onehot(str(d["rec_seq"]))], 1)

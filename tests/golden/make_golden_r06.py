@@ -14,7 +14,9 @@ unrounded file.
 
   fwd2_esmq_db5.npz  the same for the second model family (`python tests/golden/make_golden_r06.py pair`): + confidence_logits, ires_logits
 
-Usage:  python tests/golden/make_golden_r06.py [pair]
+  rollout_esmq_<id>.npz  5-step reference sampler runs with recorded draws on 1JPS, 2SNI, 1MLC, 5JMO (`... rollouts`)
+
+Usage:  python tests/golden/make_golden_r06.py [pair | rollouts]
 """
 import os
 import sys
@@ -93,5 +95,23 @@ def pair_family():
     mg.save("fwd2_esmq_db5.npz", **out)
 
 
+ROLLOUT_IDS = ("1JPS", "2SNI", "1MLC", "5JMO")      # 1JPS: the complex whose native pose fails the 16-bit self-check (profiles/r06_selfcheck_db5.txt)
+
+
+def rollouts():
+    """rollout_esmq_<id>.npz: the reference's Euler_Maruyama_sampler (src/inference_base.py:390-468), 5 steps, every draw recorded, on four of the
+    dequantised blocks (int16 edge lists, like rollout_esm_<id>.npz)."""
+    net = mg.build_net(0)
+    model = mg.Model(net).eval()
+    for k, cid in enumerate(ROLLOUT_IDS):
+        name = f"rollout_esmq_{cid}.npz"
+        mg.gen_rollout(model, deq_complex(cid), name, num_steps=5, seed=660 + k)
+        path = os.path.join(HERE, name)
+        d = dict(np.load(path))
+        d["edges"] = d["edges"].astype(np.int16)
+        np.savez_compressed(path, **d)
+        print(f"  {name}: {os.path.getsize(path) / 1024:.1f} KiB", flush=True)
+
+
 if __name__ == "__main__":
-    pair_family() if sys.argv[1:] == ["pair"] else main()
+    {"pair": pair_family, "rollouts": rollouts}.get((sys.argv[1:] or [""])[0], main)()

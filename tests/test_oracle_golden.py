@@ -173,7 +173,8 @@ def test_pair_family_score_matches_reference(case, blob_pair):
 
 # ---- a-1 / a-2: the sampler ------------------------------------------------------------
 @pytest.mark.parametrize("case,steps", [("rollout_syn_24_16", 40), ("rollout_syn_64_48", 40), ("rollout_7CEI", 6),
-                                        ("rollout_esm_1QA9", 5), ("rollout_esm_1AVX", 5), ("rollout_esm_1H1V", 5)])
+                                        ("rollout_esm_1QA9", 5), ("rollout_esm_1AVX", 5), ("rollout_esm_1H1V", 5),
+                                        ("rollout_esmq_1JPS", 5), ("rollout_esmq_2SNI", 5)])
 def test_sampler_rollout_injected(case, steps, blob):
     g = load_golden(case + ".npz")
     o = ora.Oracle(blob, complex_for(case))
