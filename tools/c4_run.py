@@ -18,9 +18,9 @@ engine.set_device(0)
 model = engine.Model(pack_blob(make_random_weights(0)))
 if "--db5" in sys.argv:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-    from conftest import REAL_ESM_IDS, db5_complex, db5_ids, real_db5_complex
-    cxs = [real_db5_complex(c) if c in REAL_ESM_IDS else db5_complex(c) for c in db5_ids()]
-    label = "the 24 DB5 test backbones (real ESM-2 features on %s, seeded stand-ins elsewhere)" % ", ".join(REAL_ESM_IDS)
+    from conftest import REAL_ESM_IDS, db5_ids, real_db5_complex
+    cxs = [real_db5_complex(c) for c in db5_ids()]
+    label = "the 24 DB5 test complexes on ESM-2 features (fp16 blocks: %s; int8-quantised blocks elsewhere, tests/golden/make_golden_r06.py)" % ", ".join(REAL_ESM_IDS)
 else:
     rng = np.random.default_rng(0)
     sizes = [(int(a), int(b)) for a, b in zip(rng.integers(90, 420, 24), rng.integers(60, 300, 24))]
