@@ -186,6 +186,43 @@ DB5_SIZES = [(223, 172), (368, 327), (242, 101), (311, 145), (470, 105), (426, 2
              (127, 246), (117, 471), (427, 65), (87, 127)]      # the 24 DB5 test complexes present in the reference
 
 
+def c4_complexes():
+    """The C4 set: the 24 DB5 test complexes with the reference loader's node features (src/datasets/ppi_dataset.py:249-265: ESM-2 block || one-hot) when
+    the committed fixtures are there - backbones + sequences tests/golden/db5_backbones.npz, ESM-2 blocks as fp16 (esm_<id>.npz, cx_7CEI.npz) or int8 +
+    per-residue scale (esm_db5_q8.npz; tests/golden/make_golden_r05.py / _r06.py wrote them from the reference's data/db5_test) -, else 24 synthetic
+    complexes of the same sizes.  Returns (complexes, label)."""
+    from dfmdock_amd.synthetic import make_complex, seq_to_onehot
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    try:
+        bb = np.load(os.path.join(gdir, "db5_backbones.npz"))
+        q8 = np.load(os.path.join(gdir, "esm_db5_q8.npz"))
+        cxs = []
+        for cid in [str(x) for x in bb["ids"]]:
+            if cid + "_q" in q8.files:
+                x = q8[cid + "_q"].astype(np.float32) * q8[cid + "_s"].astype(np.float32)[:, None]
+                R = len(str(bb[f"{cid}_rec_seq"]))
+                esm = {"rec": x[:R], "lig": x[R:]}
+            else:
+                e = np.load(os.path.join(gdir, "cx_7CEI.npz" if cid == "7CEI" else f"esm_{cid}.npz"))
+                esm = {"rec": e["rec_esm16"].astype(np.float32), "lig": e["lig_esm16"].astype(np.float32)}
+            c = {"id": cid}
+            for side in ("rec", "lig"):
+                seq = str(bb[f"{cid}_{side}_seq"])
+                c[side + "_x"] = np.concatenate([esm[side], seq_to_onehot(seq)], 1)
+                c[side + "_pos"] = bb[f"{cid}_{side}_pos"].astype(np.float32)
+                c[side + "_seq"] = seq
+            cxs.append(c)
+        assert len(cxs) == 24
+        return cxs, "the 24 DB5 test complexes (reference backbones, ESM-2 node features: 4 fp16 blocks, 20 int8-quantised; N = 197..695)"
+    except (OSError, KeyError, AssertionError):
+        cxs = []
+        for k, (R, L) in enumerate(DB5_SIZES):
+            c = make_complex(R, L, seed=300 + k)
+            c["id"] = f"S{k:02d}_{R}_{L}"
+            cxs.append(c)
+        return cxs, "24 complexes with the DB5 test set's sizes (N = 197..695, synthetic chains and features: tests/golden fixtures not found)"
+
+
 def c4_line(engine, model, precision, num_steps):
     """Secondary record: BASELINE config 4 on ONE GPU - 24 complexes of the DB5 test set's sizes (synthetic chains + features: the
     data set does not travel) x 40 trajectories through driver.run_set: handle creation, self-check, sampling, 40 x compute_metrics
@@ -193,14 +230,10 @@ def c4_line(engine, model, precision, num_steps):
     import tempfile
     from dfmdock_amd import driver
     from dfmdock_amd.synthetic import make_complex
-    cxs = []
-    for k, (R, L) in enumerate(DB5_SIZES):
-        c = make_complex(R, L, seed=300 + k)
-        c["id"] = f"S{k:02d}_{R}_{L}"
-        cxs.append(c)
+    cxs, what = c4_complexes()
     tmp = tempfile.mkdtemp(prefix="dfm_c4_")
     quiet = lambda m: None
-    out = {"workload": "C4 on one GPU: 24 complexes with the DB5 test set's sizes (N = 197..695, synthetic chains and features) x 40 "
+    out = {"workload": f"C4 on one GPU: {what} x 40 "
                        f"trajectories x {num_steps} steps through driver.run_set; clock includes handle creation, self-check, metrics, CSV",
            "unit": "trajectories/s"}
     driver.run_set(model, cxs[:3], num_samples=40, num_steps=num_steps, seed=0, precision=precision,
@@ -235,11 +268,7 @@ def c4_sharded_line(model, precision, num_steps, rank, world, backend):
     from dfmdock_amd import driver
     from dfmdock_amd.synthetic import make_complex
     import torch
-    cxs = []
-    for k, (R, L) in enumerate(DB5_SIZES):
-        c = make_complex(R, L, seed=300 + k)
-        c["id"] = f"S{k:02d}_{R}_{L}"
-        cxs.append(c)
+    cxs, what = c4_complexes()
     tmp = tempfile.mkdtemp(prefix=f"dfm_c4s_{rank}_")
     quiet = lambda m: None
     driver.run_set(model, cxs[:2], num_samples=max(8, world), num_steps=2, seed=0, precision=precision, log=quiet, canary=False)      # warm-up (collectives included)
@@ -258,7 +287,7 @@ def c4_sharded_line(model, precision, num_steps, rank, world, backend):
     shutil.rmtree(tmp, ignore_errors=True)
     costs = [D.complex_cost(R + L, 40) for R, L in DB5_SIZES]
     assign = D.assign_work(costs, world)
-    return {"workload": f"C4: 24 complexes with the DB5 test set's sizes (synthetic chains and features) x 40 trajectories x {num_steps} steps, "
+    return {"workload": f"C4: {what} x 40 trajectories x {num_steps} steps, "
                         f"sharded over {world} ranks by driver.run_set, one gather of the ranked energy records",
             "wall_s": wall, "value": n_rec / wall, "unit": "trajectories/s", "per_rank_makespan_s": [float(x) for x in per_rank[:, 0]],
             "complexes_per_rank": [int(x) for x in per_rank[:, 1]], "rows_per_rank": [int(x) for x in per_rank[:, 2]],
