@@ -492,3 +492,20 @@ def test_run_set_pipeline_stages_overlap_and_fail_cleanly(monkeypatch):
     rows_f, _ = driver.run_set(None, flaky, num_samples=3, overlap=True, canary_out=can, log=msgs.append)
     assert can["ok"] is False and can["reran_serial"] is True and rows_f == rows
     assert any("canary" in m for m in msgs) and all(calls[k] >= 2 for k in range(8))      # every complex was sampled again, serially
+
+
+def test_bench_c4_set_is_the_db5_fixtures(monkeypatch, tmp_path):
+    """bench.py's C4 records run on the 24 DB5 test complexes with the reference loader's features (src/datasets/ppi_dataset.py:249-265) rebuilt from the
+    committed fixtures - the same arrays the parity tests use - and fall back to synthetic complexes of the same sizes only when the fixtures are absent."""
+    import bench
+    from conftest import db5_ids, real_db5_complex
+    cxs, what = bench.c4_complexes()
+    assert [c["id"] for c in cxs] == db5_ids() and "ESM-2" in what
+    for c in cxs[::5]:
+        r = real_db5_complex(c["id"])
+        for k in ("rec_x", "lig_x", "rec_pos", "lig_pos"):
+            np.testing.assert_array_equal(c[k], r[k])
+    assert sorted((c["rec_x"].shape[0], c["lig_x"].shape[0]) for c in cxs) == sorted(bench.DB5_SIZES)      # the sizes SURVEY Appendix A lists
+    monkeypatch.setattr(bench.os.path, "abspath", lambda p: str(tmp_path / "bench.py"))      # no tests/golden next to it
+    syn, what2 = bench.c4_complexes()
+    assert len(syn) == 24 and "synthetic" in what2 and sorted((c["rec_x"].shape[0], c["lig_x"].shape[0]) for c in syn) == sorted(bench.DB5_SIZES)
