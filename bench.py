@@ -224,8 +224,8 @@ def c4_complexes():
 
 
 def c4_line(engine, model, precision, num_steps):
-    """Secondary record: BASELINE config 4 on ONE GPU - 24 complexes of the DB5 test set's sizes (synthetic chains + features: the
-    data set does not travel) x 40 trajectories through driver.run_set: handle creation, self-check, sampling, 40 x compute_metrics
+    """Secondary record: BASELINE config 4 on ONE GPU - the 24 DB5 test complexes (c4_complexes: committed backbones + ESM-2 feature
+    blocks) x 40 trajectories through driver.run_set: handle creation, self-check, sampling, 40 x compute_metrics
     and the CSV inside the clock.  Serial driver (the reference's loop shape, src/inference_mlsb.py:415-439) and the pipelined one."""
     import tempfile
     from dfmdock_amd import driver
