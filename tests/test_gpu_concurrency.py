@@ -26,7 +26,7 @@ from conftest import pair_hparams
 
 pytestmark = pytest.mark.gpu
 
-CALLS = 8      # victim calls per cell (r05: the un-fenced build deviated in 11-12 of 12)
+CALLS = int(__import__("os").environ.get("DFM_MATRIX_CALLS", "8"))      # victim calls per cell; DFM_MATRIX_CALLS=48: the soak of profiles/r06_concurrency.txt (r05: the un-fenced build deviated in 11-12 of 12)
 
 
 @pytest.fixture(scope="module")
