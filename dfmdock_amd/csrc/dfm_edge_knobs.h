@@ -51,6 +51,9 @@
 #ifndef DFM_EDGE_EARLYA     // 1: k-step 0's A fragment and the first weight fragment of chunk c + 1 are requested at the end of chunk c (chunks 1..7)
 #define DFM_EDGE_EARLYA 0
 #endif
+#ifndef DFM_EDGE_PAD0       // 1: the padded rows of a node's second tile (60 -> 64) gather node 0's Bm row (one hot line per trajectory) instead of the node's own
+#define DFM_EDGE_PAD0 0
+#endif
 #ifndef DFM_EDGE_KO         // knock-out builds, WRONG RESULTS: bit 0 no MFMA, bit 1 no producer transcendentals, bit 2 no epilogue transcendentals, bit 3 one weight-fragment LDS read per chunk
 #define DFM_EDGE_KO 0
 #endif

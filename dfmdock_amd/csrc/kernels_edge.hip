@@ -939,7 +939,7 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVE
 #pragma unroll
         for (int q = 0; q < 2; ++q) {      // masked rows (>= K; row-list form: past the end of the list): self edge, zero features -> finite values, gate forced to 0
             const bool v = ROWS ? (uint32_t)ti * 32u + (uint32_t)(q * 16 + r16) < n_rows : tm * 32 + q * 16 + r16 < K;
-            const int j = v ? jqn[q] : (ROWS ? 0 : ti);
+            const int j = v ? jqn[q] : (DFM_EDGE_PAD0 || ROWS ? 0 : ti);
             const uint32_t code = v ? codeqn[q] : 0u;
             radq_nx[q] = v ? radqn[q] : 0.f;
             if constexpr (ROWS) oa[q] = (uint32_t)(v ? iqn[q] : 0) * (H * 2) + c4 * 16;
