@@ -51,6 +51,9 @@
 #ifndef DFM_EDGE_EARLYA     // 1: k-step 0's A fragment and the first weight fragment of chunk c + 1 are requested at the end of chunk c (chunks 1..7)
 #define DFM_EDGE_EARLYA 0
 #endif
+#ifndef DFM_EDGE_MSTORE_NOFENCE   // 1: the transposing stores through the staging buffer rely on in-order LDS execution instead of s_waitcnt lgkmcnt(0) twice per n-tile
+#define DFM_EDGE_MSTORE_NOFENCE 0
+#endif
 #ifndef DFM_EDGE_PAD0       // 1: the padded rows of a node's second tile (60 -> 64) gather node 0's Bm row (one hot line per trajectory) instead of the node's own
 #define DFM_EDGE_PAD0 0
 #endif

@@ -337,6 +337,9 @@ __device__ inline float half_reduce_scatter(const float (&v)[16], int lane)
 
 // make every earlier LDS access of this wave visible/ordered before later ones (wave-private staging tile)
 __device__ inline void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Transposing stores (last layer's gated messages, row-list form): the staging area is wave-private and a wave's LDS instructions execute in order, so neither
+// the reads after the ds_write_b16 nor the next n-tile's writes after the reads need the counter drained - DFM_EDGE_MSTORE_NOFENCE keeps the compiler's order only
+__device__ inline void mstore_fence() { if constexpr (DFM_EDGE_MSTORE_NOFENCE) asm volatile("" ::: "memory"); else wave_lds_fence(); }
 
 #if DFM_TAB_MERGE
 struct RawP { uint4 bm, t0, t1; };            // gathered fp16 operands of one producer pass (8 channels of one row)
@@ -1296,9 +1299,9 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVE
                     *reinterpret_cast<uint16_t *>(tb + wbase[r & 3] + (r >> 2) * 128) = (uint16_t)pk;
                     *reinterpret_cast<uint16_t *>(tb + wbase[(r + 1) & 3] + (r >> 2) * 128) = (uint16_t)(pk >> 16);
                 }
-                wave_lds_fence();
+                mstore_fence();
                 const uint4 v0 = *reinterpret_cast<const uint4 *>(tb + rd[0]), v1 = *reinterpret_cast<const uint4 *>(tb + rd[1]);
-                wave_lds_fence();      // the reads have returned before the next n-tile overwrites the buffer
+                mstore_fence();      // the reads have returned before the next n-tile overwrites the buffer
                 Rout[wr[0] + nt * 4] = v0;
                 Rout[wr[1] + nt * 4] = v1;
             }
@@ -1338,9 +1341,9 @@ template <int F16, int AW16, int ROWS = 0> __global__ __launch_bounds__(MSG_WAVE
                     *reinterpret_cast<uint16_t *>(tb + wbase[r & 3] + (r >> 2) * 128) = (uint16_t)pk;
                     *reinterpret_cast<uint16_t *>(tb + wbase[(r + 1) & 3] + (r >> 2) * 128) = (uint16_t)(pk >> 16);
                 }
-                wave_lds_fence();
+                mstore_fence();
                 const uint4 v0 = *reinterpret_cast<const uint4 *>(tb + rd[0]), v1 = *reinterpret_cast<const uint4 *>(tb + rd[1]);
-                wave_lds_fence();      // the reads have returned before the next n-tile overwrites the buffer
+                mstore_fence();      // the reads have returned before the next n-tile overwrites the buffer
                 store_stream(Mout + nt * 128 + lane, v0);
                 store_stream(Mout + nt * 128 + 64 + lane, v1);
             }
